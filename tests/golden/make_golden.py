@@ -1,0 +1,456 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the GENUINE reference.
+
+Run once in the build container (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/make_golden.py
+
+Inputs are produced by this script's own seeded generators; expected outputs come from the reference
+binaries in oracle/_ref/ (itree.c compiled with -D SEARCH_GG / BUILD_GG / COMPRESS, 1 thread so that the
+output order is the input order).  Only data is committed: inputs, the reference's outputs, and compact
+node lists parsed out of the reference-built databases.  No reference source is stored here.
+
+Fixture sets:
+  toy     F1  reference BUILD_GG(complevel 2)+COMPRESS on 1000 seeded refs; 10 000 x 100 bp reads; +RC
+  edge    F1  parser edge cases on the toy DB (CRLF, tabs, lowercase, N, short, no trailing newline)
+  vote    F2  hand-built label sets with planted hit multisets (every vote branch)
+  kat     F3  direct-written DB: bin sizes 1,2,3.., min/max suffix, first-bin quirk; one probe per read
+  k64     F4  PACKSIZE=64 build of a smaller toy + reads (+RC)
+  ix32    F4  IXTYPE=uint32_t build of a smaller toy + reads
+"""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from utree_amd import ctrfile  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def run(cmd, cwd=None):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    return r.returncode, r.stdout, r.stderr
+
+
+def rand_seq(rng, n):
+    return BASES[rng.integers(0, 4, n)]
+
+
+def mutate(rng, seq, rate):
+    s = seq.copy()
+    m = rng.random(len(s)) < rate
+    s[m] = BASES[rng.integers(0, 4, int(m.sum()))]
+    return s
+
+
+RANKS = ["k", "p", "c", "o", "f", "g", "s", "t"]
+
+
+def make_taxonomy(rng, n_leaves, fan=(2, 3, 2, 3, 2, 3, 3, 3), empty_tail_frac=0.15):
+    """Random 8-rank GG-style strings; some leaves have empty trailing ranks (s__;t__)."""
+    names = {}
+
+    def nm(level, path):
+        key = (level, path)
+        if key not in names:
+            names[key] = "%s%d" % ("BPCOFGST"[level], len([k for k in names if k[0] == level]))
+        return names[key]
+
+    leaves = []
+    for _ in range(n_leaves):
+        path = tuple(int(rng.integers(0, f)) for f in fan)
+        toks = []
+        depth = 8
+        r = rng.random()
+        if r < empty_tail_frac:
+            depth = int(rng.integers(5, 8))      # ranks >= depth are empty
+        for lv in range(8):
+            if lv < depth:
+                toks.append("%s__%s" % (RANKS[lv], nm(lv, path[: lv + 1])))
+            else:
+                toks.append("%s__" % RANKS[lv])
+        leaves.append((path, ";".join(toks)))
+    return leaves
+
+
+def make_refs(rng, leaves, length, per_level_rate=0.012):
+    """Hierarchically mutated sequences so that related taxa share k-mers."""
+    cache = {(): rand_seq(rng, length)}
+
+    def seq_for(path):
+        if path not in cache:
+            cache[path] = mutate(rng, seq_for(path[:-1]), per_level_rate)
+        return cache[path]
+
+    out = []
+    for n, (path, tax) in enumerate(leaves):
+        s = mutate(rng, seq_for(path), 0.004)
+        out.append(("ref%05d sample" % n, tax, s))
+    return out
+
+
+def write_fasta(path, items, crlf=False):
+    nl = b"\r\n" if crlf else b"\n"
+    with open(path, "wb") as f:
+        for name, seq in items:
+            f.write(b">" + name.encode("latin-1") + nl + bytes(seq) + nl)
+
+
+def sample_reads(rng, refs, n, length, prefix="q"):
+    reads = []
+    L = len(refs[0][2])
+    for i in range(n):
+        r = rng.random()
+        ref = refs[int(rng.integers(0, len(refs)))][2]
+        if r < 0.08:
+            s = rand_seq(rng, length)                                   # no hit expected
+        elif r < 0.18:                                                  # chimera of two refs
+            ref2 = refs[int(rng.integers(0, len(refs)))][2]
+            a = int(rng.integers(0, L - length))
+            b = int(rng.integers(0, L - length))
+            h = length // 2
+            s = np.concatenate([ref[a : a + h], ref2[b : b + length - h]])
+        else:
+            a = int(rng.integers(0, L - length))
+            s = mutate(rng, ref[a : a + length], 0.01 if r < 0.7 else 0.0)
+        s = s.copy()
+        q = rng.random()
+        if q < 0.03:
+            s[int(rng.integers(0, len(s)))] = ord("N")
+        elif q < 0.05:
+            s = np.frombuffer(bytes(s).lower(), dtype=np.uint8).copy()
+        elif q < 0.06:
+            s = s[: int(rng.integers(1, 40))]                           # shorter than / around k
+        elif q < 0.08:                                                  # reverse strand
+            comp = {65: 84, 67: 71, 71: 67, 84: 65}
+            s = np.array([comp.get(int(c), 78) for c in s[::-1]], dtype=np.uint8)
+        reads.append(("%s%d" % (prefix, i), s))
+    return reads
+
+
+def ref_search(binname, ctr, fasta, rc):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "out.txt")
+        cmd = [os.path.join(REF, binname), ctr, fasta, out, "1"] + (["RC"] if rc else [])
+        code, so, se = run(cmd)
+        data = open(out, "rb").read() if os.path.exists(out) else b""
+        return code, data, so, se
+
+
+def gz_write(path, data):
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(data)
+
+
+def build_with_reference(td, refs, suffix, complevel):
+    fa = os.path.join(td, "refs.fa")
+    mp = os.path.join(td, "refs.map")
+    write_fasta(fa, [(n, s) for n, _, s in refs])
+    with open(mp, "wb") as f:
+        for n, tax, _ in refs:
+            f.write(n.encode() + b"\t" + tax.encode() + b"\n")
+    ubt = os.path.join(td, "db.ubt")
+    ctr = os.path.join(td, "db.ctr")
+    code, so, se = run([os.path.join(REF, "utree-buildGG" + suffix), fa, mp, ubt, "1", str(complevel)])
+    assert code == 0, (code, so[-500:], se[-500:])
+    code, so, se = run([os.path.join(REF, "xtree-compress" + suffix), ubt, ctr])
+    assert code == 0, (code, so[-500:], se[-500:])
+    return ctr
+
+
+def save_db_fixture(name, ctr_path, manifest):
+    d = ctrfile.read_ctr(ctr_path)
+    hi, lo = d.suffixes()
+    # records in file order + the bin table run-length coded (it is piecewise constant): exact for any
+    # table, including the first-bin-quirk one
+    b = d.binix
+    chg = (np.flatnonzero(b[1:] != b[:-1]) + 1).astype(np.uint32)
+    np.savez_compressed(
+        os.path.join(HERE, name + "_db.npz"),
+        W=np.int64(d.W), I=np.int64(d.I),
+        suf_hi=hi if d.W == 16 else np.zeros(0, dtype=np.uint64), suf_lo=lo, ix=d.ix().astype(np.uint32),
+        bin0=np.uint64(b[0]), bin_chg_idx=chg, bin_chg_val=b[chg].astype(np.uint64),
+        label_text=np.frombuffer(d.label_text, dtype=np.uint8),
+    )
+    manifest[name + "_ctr_sha256"] = ctrfile.sha256_file(ctr_path)
+    manifest[name + "_nodes"] = int(d.n_nodes)
+    manifest[name + "_labels"] = len(d.labels())
+    return d
+
+
+def gen_toy(manifest, name, suffix, searchbin, n_refs, ref_len, n_reads, read_len, seed, complevel=2):
+    rng = np.random.default_rng(seed)
+    leaves = make_taxonomy(rng, n_refs)
+    refs = make_refs(rng, leaves, ref_len)
+    with tempfile.TemporaryDirectory() as td:
+        ctr = build_with_reference(td, refs, suffix, complevel)
+        d = save_db_fixture(name, ctr, manifest)
+        reads = sample_reads(rng, refs, n_reads, read_len)
+        fa = os.path.join(td, "reads.fa")
+        write_fasta(fa, reads)
+        gz_write(os.path.join(HERE, name + "_reads.fa.gz"), open(fa, "rb").read())
+        for rc in (0, 1):
+            code, out, so, se = ref_search(searchbin, ctr, fa, rc)
+            assert code == 0, (code, se)
+            gz_write(os.path.join(HERE, "%s_out%s.txt.gz" % (name, "_rc" if rc else "")), out)
+            manifest["%s_out%s_lines" % (name, "_rc" if rc else "")] = out.count(b"\n")
+        if name == "toy":
+            gen_edge(manifest, td, ctr, refs, rng)
+    return d
+
+
+def gen_edge(manifest, td, ctr, refs, rng):
+    """Parser edge cases, each file run separately (some make the reference exit non-zero)."""
+    r0 = bytes(refs[3][2][100:200])
+    r1 = bytes(refs[7][2][300:420])
+    cases = {}
+    cases["crlf"] = b">readA extra words\r\n" + r0 + b"\r\n>readB\r\n" + r1 + b"\r\n"
+    cases["tabs_and_space"] = b">read\twith\ttabs and space\n" + r0 + b"\n>x y\n" + r1 + b"\n"
+    cases["no_trailing_newline"] = b">r1\n" + r0 + b"\n>r2\n" + r1
+    cases["lower_and_N"] = b">low\n" + r0.lower() + b"\n>nn\n" + r0[:50] + b"N" + r0[51:] + b"\n>n2\n" + r1[:33] + b"NN" + r1[35:70] + b"n" + r1[71:] + b"\n"
+    cases["short"] = b">s1\n" + r0[:31] + b"\n>s2\n" + r0[:32] + b"\n>s3\nA\n>s4\n" + r0[:33] + b"\n"
+    cases["blank_seq"] = b">b1\n\n>b2\n" + r0 + b"\n"
+    cases["iupac_and_misc"] = b">iu\n" + r0[:40] + b"RYKM" + r0[44:] + b"\n>gap\n" + r0[:60] + b"-" + r0[61:] + b"\n>dot\n" + r1[:64] + b"." + r1[65:] + b"\n"
+    cases["hdr_only_gt"] = b">\n" + r0 + b"\n> lead space\n" + r1 + b"\n"
+    cases["err_no_header"] = b">ok\n" + r0 + b"\nnot a header\n" + r1 + b"\n"
+    cases["err_seq_is_header"] = b">ok\n" + r0 + b"\n>h1\n>h2\n" + r1 + b"\n"
+    cases["err_missing_seq"] = b">ok\n" + r0 + b"\n>last\n"
+    cases["err_blank_line"] = b">ok\n" + r0 + b"\n\n>h\n" + r1 + b"\n"
+    out = {}
+    for nm, data in cases.items():
+        fa = os.path.join(td, "edge_%s.fa" % nm)
+        open(fa, "wb").write(data)
+        for rc in (0, 1):
+            code, res, so, se = ref_search("xtree-searchGG", ctr, fa, rc)
+            out["%s%s" % (nm, "_rc" if rc else "")] = {
+                "input_hex": data.hex(), "rc": rc, "exit": code, "output_hex": res.hex(),
+            }
+    json.dump(out, open(os.path.join(HERE, "edge_cases.json"), "w"), indent=0, sort_keys=True)
+    manifest["edge_cases"] = len(out)
+
+
+def unique_kmers(rng, n, k):
+    seen = set()
+    out = []
+    while len(out) < n:
+        s = bytes(rand_seq(rng, k)).decode()
+        if s not in seen:
+            seen.add(s)
+            out.append(s)
+    return out
+
+
+def gen_vote(manifest, seed=77):
+    """F2: label sets exercising every branch of the vote with planted hit multisets."""
+    rng = np.random.default_rng(seed)
+    k = 32
+    labels = []
+
+    def full(kd, p, c, o, f, g, s, t):
+        return "k__%s;p__%s;c__%s;o__%s;f__%s;g__%s;s__%s;t__%s" % (kd, p, c, o, f, g, s, t)
+
+    # three kingdoms, a bushy clade, empty ranks at various depths, truncated (interpolated) ancestors
+    for kd in ("Bacteria", "Archaea", "Viruses"):
+        for g in range(3):
+            for s in range(3):
+                for t in range(2):
+                    labels.append(full(kd, "P1", "C1", "O1", "F1", "G%d" % g, "G%d_s%d" % (g, s), "G%d_s%d_t%d" % (g, s, t)))
+                labels.append(full(kd, "P1", "C1", "O1", "F1", "G%d" % g, "G%d_s%d" % (g, s), ""))          # empty t__
+            labels.append(full(kd, "P1", "C1", "O1", "F1", "G%d" % g, "", ""))                               # empty s__;t__
+        labels.append("k__%s;p__P1;c__C1;o__;f__;g__;s__;t__" % kd)                                          # empty from o__ down
+        labels.append("k__%s;p__P2;c__C9;o__O9;f__F9;g__G9;s__G9_s;t__G9_s_t" % kd)
+        # interpolated ancestors (what BUILD_GG appends on k-mer collisions: truncated at a rank)
+        labels.append("k__%s;p__P1" % kd)
+        labels.append("k__%s;p__P1;c__C1" % kd)
+        labels.append("k__%s;p__P1;c__C1;o__O1" % kd)
+        labels.append("k__%s;p__P1;c__C1;o__O1;f__F1" % kd)
+        for g in range(3):
+            labels.append("k__%s;p__P1;c__C1;o__O1;f__F1;g__G%d" % (kd, g))
+            labels.append("k__%s;p__P1;c__C1;o__O1;f__F1;g__G%d;s__G%d_s0" % (kd, g, g))
+    # prefix-of-token neighbours (td stops inside a token)
+    labels += ["k__Bacteria;p__P1;c__C1;o__O1;f__F1;g__G1x;s__a;t__b",
+               "k__Bacteria;p__P1;c__C1;o__O1;f__F1;g__G10;s__a;t__b",
+               "k__Bact;p__P1", "k__Bacteria_X;p__P1;c__C1;o__O1;f__F1;g__G1;s__q;t__r"]
+    labels = list(dict.fromkeys(labels))
+    order = rng.permutation(len(labels))
+    labels = [labels[i] for i in order]                     # file order != lexical order
+    per = 6                                                 # k-mers per label
+    kms = unique_kmers(rng, per * len(labels), k)
+    hi, lo = ctrfile.encode_kmers(kms)
+    ix = np.repeat(np.arange(len(labels), dtype=np.uint32), per)
+    srt = np.argsort(lo, kind="stable")
+    kms_by_label = [[kms[l * per + j] for j in range(per)] for l in range(len(labels))]
+    lab_index = {s: i for i, s in enumerate(labels)}
+    reads = []
+
+    def plant(name, picks):
+        # picks: list of (label_index, copies); non-overlapping k-mers joined by a 'N' so that no
+        # spanning window is ever valid: the hit multiset is exactly what we plant
+        parts = []
+        for li, copies in picks:
+            for c in range(copies):
+                parts.append(kms_by_label[li][c % per])
+        reads.append((name, np.frombuffer("N".join(parts).encode(), dtype=np.uint8)))
+
+    L = lab_index
+    B = "Bacteria"
+    t000 = L[full(B, "P1", "C1", "O1", "F1", "G0", "G0_s0", "G0_s0_t0")]
+    t001 = L[full(B, "P1", "C1", "O1", "F1", "G0", "G0_s0", "G0_s0_t1")]
+    t00e = L[full(B, "P1", "C1", "O1", "F1", "G0", "G0_s0", "")]
+    t010 = L[full(B, "P1", "C1", "O1", "F1", "G0", "G0_s1", "G0_s1_t0")]
+    t100 = L[full(B, "P1", "C1", "O1", "F1", "G1", "G1_s0", "G1_s0_t0")]
+    g0e = L[full(B, "P1", "C1", "O1", "F1", "G0", "", "")]
+    anc_p = L["k__Bacteria;p__P1"]
+    anc_f = L["k__Bacteria;p__P1;c__C1;o__O1;f__F1"]
+    anc_g0 = L["k__Bacteria;p__P1;c__C1;o__O1;f__F1;g__G0"]
+    anc_s = L["k__Bacteria;p__P1;c__C1;o__O1;f__F1;g__G0;s__G0_s0"]
+    arch = L[full("Archaea", "P1", "C1", "O1", "F1", "G0", "G0_s0", "G0_s0_t0")]
+    vir = L[full("Viruses", "P1", "C1", "O1", "F1", "G2", "G2_s2", "G2_s2_t1")]
+    oe = L["k__Bacteria;p__P1;c__C1;o__;f__;g__;s__;t__"]
+    p2 = L["k__Bacteria;p__P2;c__C9;o__O9;f__F9;g__G9;s__G9_s;t__G9_s_t"]
+    hand = [
+        ("one_hit", [(t000, 1)]),
+        ("one_label_many", [(t000, 5)]),
+        ("full_label_wins", [(t000, 9), (t001, 1)]),
+        ("tie_strains", [(t000, 3), (t001, 3)]),
+        ("species_level", [(t000, 3), (t001, 3), (t00e, 2)]),
+        ("genus_level", [(t000, 2), (t010, 2), (g0e, 1)]),
+        ("family_level", [(t000, 2), (t100, 2)]),
+        ("with_ancestors", [(t000, 4), (anc_p, 2), (anc_f, 1), (anc_g0, 1), (anc_s, 1)]),
+        ("ancestors_only", [(anc_p, 2), (anc_f, 2)]),
+        ("ancestor_majority", [(anc_p, 6), (t000, 1), (t100, 1)]),
+        ("cross_kingdom_even", [(t000, 3), (arch, 3)]),
+        ("cross_kingdom_major", [(t000, 7), (arch, 1)]),
+        ("three_kingdoms", [(t000, 2), (arch, 2), (vir, 2)]),
+        ("empty_order_down", [(oe, 3), (t000, 3)]),
+        ("empty_order_major", [(oe, 6), (p2, 1)]),
+        ("p1_vs_p2", [(t000, 3), (p2, 1)]),
+        ("p1_vs_p2_even", [(t000, 2), (p2, 2)]),
+        ("late_group_wins", [(arch, 1), (t000, 1), (vir, 6)]),
+        ("token_prefix_a", [(L["k__Bacteria;p__P1;c__C1;o__O1;f__F1;g__G1x;s__a;t__b"], 2),
+                            (L["k__Bacteria;p__P1;c__C1;o__O1;f__F1;g__G10;s__a;t__b"], 2), (t100, 2)]),
+        ("token_prefix_b", [(L["k__Bact;p__P1"], 2), (t000, 2)]),
+        ("token_prefix_c", [(L["k__Bacteria_X;p__P1;c__C1;o__O1;f__F1;g__G1;s__q;t__r"], 3), (t000, 3), (anc_p, 1)]),
+    ]
+    for nm, picks in hand:
+        plant(nm, picks)
+    # random multisets: 2..14 hits over related / unrelated labels
+    nlab = len(labels)
+    srt_labels = sorted(range(nlab), key=lambda i: labels[i])
+    for i in range(4000):
+        npk = int(rng.integers(1, 7))
+        if rng.random() < 0.7:                                  # a lexical neighbourhood
+            c = int(rng.integers(0, nlab))
+            cand = [srt_labels[(c + d) % nlab] for d in range(-4, 5)]
+        else:
+            cand = list(range(nlab))
+        picks = [(cand[int(rng.integers(0, len(cand)))], int(rng.integers(1, 5))) for _ in range(npk)]
+        plant("rnd%d" % i, picks)
+    with tempfile.TemporaryDirectory() as td:
+        ctr = os.path.join(td, "vote.ctr")
+        ctrfile.write_ctr(ctr, 8, 2, hi[srt], lo[srt], ix[srt], labels)
+        save_db_fixture("vote", ctr, manifest)
+        fa = os.path.join(td, "reads.fa")
+        write_fasta(fa, reads)
+        gz_write(os.path.join(HERE, "vote_reads.fa.gz"), open(fa, "rb").read())
+        code, out, so, se = ref_search("xtree-searchGG", ctr, fa, 0)
+        assert code == 0
+        gz_write(os.path.join(HERE, "vote_out.txt.gz"), out)
+        manifest["vote_out_lines"] = out.count(b"\n")
+
+
+def gen_kat(manifest, seed=99):
+    """F3: lookup known-answer DB written directly, incl. the first-bin quirk layout."""
+    rng = np.random.default_rng(seed)
+    k = 32
+    labels = ["k__A;p__L%d" % i for i in range(40)]
+    words = set()
+    # bins with 1,2,3,...,40 records at scattered prefixes; min and max suffix in some bins
+    prefixes = sorted(int(x) for x in rng.choice(1 << 24, size=60, replace=False))
+    prefixes[0] = max(prefixes[0], 5)
+    sizes = list(range(1, 41)) + [1, 1, 2, 64, 100, 257] + [3] * 14
+    for pfx, sz in zip(prefixes, sizes):
+        sufs = set(int(x) for x in rng.integers(0, 1 << 40, size=sz))
+        if sz >= 2:
+            sufs.add(0)
+            sufs.add((1 << 40) - 1)
+        for s in sufs:
+            words.add((pfx << 40) | s)
+    # dense neighbours: consecutive suffixes and consecutive prefixes
+    base = (prefixes[10] << 40) | 0x1234567800
+    for d in range(6):
+        words.add(base + d)
+    words.add((0xFFFFFF << 40) | 0xFFFFFFFFFF)              # very last possible word
+    words = np.array(sorted(words), dtype=np.uint64)
+    ixs = rng.integers(0, len(labels), size=len(words)).astype(np.uint32)
+
+    def mk_reads(wlist):
+        reads = []
+        n = 0
+        for w in wlist:
+            s = ctrfile.decode_kmer(0, int(w), k)
+            reads.append(("hit%d" % n, np.frombuffer(s.encode(), dtype=np.uint8)))
+            # neighbours: +1 / -1 in the suffix (mostly misses), and a flipped prefix bit
+            for delta in (1, -1, 1 << 40, 1 << 39):
+                v = (int(w) + delta) & 0xFFFFFFFFFFFFFFFF
+                reads.append(("nbr%d_%d" % (n, delta), np.frombuffer(ctrfile.decode_kmer(0, v, k).encode(), dtype=np.uint8)))
+            n += 1
+        return reads
+
+    with tempfile.TemporaryDirectory() as td:
+        # (a) exact bin table
+        ctr = os.path.join(td, "kat.ctr")
+        ctrfile.write_ctr(ctr, 8, 2, np.zeros_like(words), words, ixs, labels)
+        save_db_fixture("kat", ctr, manifest)
+        reads = mk_reads(words)
+        fa = os.path.join(td, "reads.fa")
+        write_fasta(fa, reads)
+        gz_write(os.path.join(HERE, "kat_reads.fa.gz"), open(fa, "rb").read())
+        code, out, so, se = ref_search("xtree-searchGG", ctr, fa, 0)
+        assert code == 0
+        gz_write(os.path.join(HERE, "kat_out.txt.gz"), out)
+        manifest["kat_out_lines"] = out.count(b"\n")
+        # (b) first-bin quirk: the first non-empty bin holds exactly one record -> COMPRESS-style table
+        qw = np.concatenate([[np.uint64((3 << 40) | 0x7777777777)], words]).astype(np.uint64)
+        qw = np.array(sorted(set(int(x) for x in qw)), dtype=np.uint64)
+        qix = rng.integers(0, len(labels), size=len(qw)).astype(np.uint32)
+        ctrq = os.path.join(td, "katq.ctr")
+        ctrfile.write_ctr(ctrq, 8, 2, np.zeros_like(qw), qw, qix, labels, like_compress=True)
+        save_db_fixture("katq", ctrq, manifest)
+        # probes: every word, plus suffix-equal probes placed in the merged bin
+        extra = [np.uint64((int(qw[1]) >> 40 << 40) | 0x7777777777)]
+        readsq = mk_reads(list(qw) + extra)
+        faq = os.path.join(td, "readsq.fa")
+        write_fasta(faq, readsq)
+        gz_write(os.path.join(HERE, "katq_reads.fa.gz"), open(faq, "rb").read())
+        code, out, so, se = ref_search("xtree-searchGG", ctrq, faq, 0)
+        assert code == 0
+        gz_write(os.path.join(HERE, "katq_out.txt.gz"), out)
+        manifest["katq_out_lines"] = out.count(b"\n")
+
+
+def main():
+    if not os.path.exists(os.path.join(REF, "xtree-searchGG")):
+        sys.exit("build the reference first: make -C oracle ref")
+    manifest = {}
+    gen_toy(manifest, "toy", "", "xtree-searchGG", 1000, 1000, 10000, 100, seed=20240807)
+    gen_toy(manifest, "k64", "-k64", "xtree-searchGG-k64", 150, 1200, 3000, 150, seed=64)
+    gen_toy(manifest, "ix32", "-ix32", "xtree-searchGG-ix32", 150, 1200, 3000, 120, seed=32)
+    gen_vote(manifest)
+    gen_kat(manifest)
+    json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(manifest, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""Pin the CPU restatement (oracle/) against the genuine reference's outputs in tests/golden/.
+
+Every expected byte here was produced by itree.c -D SEARCH_GG (oracle/_ref, 1 thread) at golden time
+(tests/golden/make_golden.py).  CPU only.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from utree_amd import ctrfile
+import util
+
+
+@pytest.fixture(scope="module")
+def tmpdir_mod(tmp_path_factory):
+    return tmp_path_factory.mktemp("orc")
+
+
+def run_oracle(name, rc, tmpdir, threads=1):
+    db = orc.OracleDB.load(util.fixture_ctr(name))
+    out = os.path.join(str(tmpdir), "%s_%d.txt" % (name, rc))
+    code, nr, good, err = db.search_file(util.fixture_reads_path(name), out, threads=threads, rc=bool(rc))
+    return code, nr, good, open(out, "rb").read()
+
+
+@pytest.mark.parametrize("name,rcs", [("toy", (0, 1)), ("k64", (0, 1)), ("ix32", (0, 1)), ("vote", (0,)),
+                                      ("kat", (0,)), ("katq", (0,))])
+def test_search_file_matches_reference(name, rcs, tmpdir_mod):
+    for rc in rcs:
+        code, nr, good, got = run_oracle(name, rc, tmpdir_mod)
+        want = util.fixture_bytes("%s_out%s.txt.gz" % (name, "_rc" if rc else ""))
+        assert code == 0
+        assert got == want, "%s rc=%d: oracle output differs from the reference's" % (name, rc)
+        assert good == want.count(b"\n")
+
+
+def test_threads_do_not_change_output(tmpdir_mod):
+    _, _, _, a = run_oracle("toy", 1, tmpdir_mod, threads=1)
+    _, _, _, b = run_oracle("toy", 1, tmpdir_mod, threads=4)
+    assert a == b
+
+
+def test_edge_cases_match_reference(tmpdir_mod):
+    cases = json.load(open(os.path.join(util.GOLD, "edge_cases.json")))
+    db = orc.OracleDB.load(util.fixture_ctr("toy"))
+    assert len(cases) == util.manifest()["edge_cases"]
+    for nm, c in sorted(cases.items()):
+        fa = os.path.join(str(tmpdir_mod), "edge_%s.fa" % nm)
+        open(fa, "wb").write(bytes.fromhex(c["input_hex"]))
+        out = fa + ".out"
+        code, nr, good, err = db.search_file(fa, out, threads=1, rc=bool(c["rc"]))
+        assert code == c["exit"], (nm, code, c["exit"], err)
+        assert open(out, "rb").read() == bytes.fromhex(c["output_hex"]), nm
+
+
+def test_ctr_regenerated_by_our_writer_matches_reference_sha():
+    # fixture_ctr asserts the SHA-256 of the reference-built file
+    for name in ("toy", "k64", "ix32", "vote", "kat", "katq"):
+        p = util.fixture_ctr(name)
+        d = ctrfile.read_ctr(p)
+        assert d.n_nodes == util.manifest()[name + "_nodes"]
+        assert len(d.labels()) == util.manifest()[name + "_labels"]
+
+
+def test_compress_style_bin_table_reproduces_reference_compress():
+    # toy.ctr came out of the reference's COMPRESS: our like_compress bin table must equal its table
+    for name in ("toy", "k64", "ix32"):
+        d = util.load_db_fixture(name)
+        hi, lo = d.words()
+        pref = ctrfile.word_prefix(d.W, hi, lo)
+        # words() needs an exact table to recover prefixes; for reference-built DBs the quirk only
+        # matters when the first bin holds one record, so compare through the generic routine
+        b = ctrfile.binix_like_compress(pref, d.n_nodes)
+        assert np.array_equal(b, d.binix)
+
+
+def test_lookup_kat_direct():
+    d = util.load_db_fixture("kat")
+    db = orc.OracleDB.load(util.fixture_ctr("kat"))
+    hi, lo = d.words()
+    ix = d.ix()
+    for j in range(0, len(lo), 7):
+        assert db.lookup(0, int(lo[j])) == int(ix[j])
+        miss = int(lo[j]) ^ 1
+        if miss not in set(int(x) for x in lo[max(0, j - 2):j + 3]):
+            assert db.lookup(0, miss) == orc.BAD_IX
+
+
+def test_windows_skip_bad_bases():
+    seq = b"ACGT" * 10 + b"N" + b"ACGT" * 10
+    pos, hi, lo = orc.windows(seq, 32)
+    # windows ending at 31..39 (9 of them) then from 41+31=72 .. 80
+    assert list(pos) == list(range(31, 40)) + list(range(72, 81))
+    assert int(lo[0]) == int("".join(format("ACGT".index(c), "02b") for c in (b"ACGT" * 8).decode()), 2)
+    assert len(orc.windows(b"ACGT" * 7 + b"ACG", 32)[0]) == 0
+    # lowercase and high bytes
+    pos2, _, lo2 = orc.windows((b"acgt" * 8) + bytes([200]) + b"A" * 32, 32)
+    assert list(pos2) == [31, 64] and int(lo2[1]) == 0
