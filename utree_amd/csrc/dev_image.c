@@ -1,0 +1,426 @@
+/* dev_image.c -- device image of a database and the batch entry points (host orchestration, C).
+ *
+ * The image replaces UTree.Dump / UTree.BinIx (itree.c:140-141) as XT_getIX32 (itree.c:720) sees them.
+ * Layout in HBM (one flat allocation, offsets only -- DESIGN.md §3):
+ *
+ *   [header 4 KiB][fine prefix index: 2^(24+F)+1 offsets][records: N x {suffix, rank}, 8-byte words]
+ *   [irregular-bin bitmap 2 MiB][label offsets][labels in strcmp order][rank -> file index]
+ */
+#define _FILE_OFFSET_BITS 64
+#define _GNU_SOURCE
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "ctr_host.h"
+#include "dev_image.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { utree_dev_set_hip_error((int)e_, #x); rc = UTREE_E_HIP; goto fail; } } while (0)
+#define KCHK(x) do { int e_ = (x); if (e_ != 0) { utree_dev_set_hip_error(e_, #x); rc = UTREE_E_HIP; goto fail; } } while (0)
+
+static __thread char g_hip_msg[256];
+void utree_dev_set_hip_error(int err, const char *what) {
+    snprintf(g_hip_msg, sizeof g_hip_msg, "%s: %s", what, hipGetErrorString((hipError_t)err));
+    if (getenv("UTREE_DEBUG")) fprintf(stderr, "[utree_amd] HIP error: %s\n", g_hip_msg);
+}
+const char *utree_last_hip_error(void) { return g_hip_msg; }
+
+static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
+    const char *env = getenv("UTREE_FINE_BITS");
+    if (fine_bits == UTREE_FINE_AUTO && env && *env) fine_bits = atoi(env);
+    if (fine_bits == UTREE_FINE_AUTO) {
+        /* smallest F with at most ~1.5 records per fine bin on average */
+        int F = 0;
+        while (F < 8 && (double)ctr->info.n_nodes / (double)(1ull << (24 + F)) > 1.5) ++F;
+        return F;
+    }
+    if (fine_bits < 0) fine_bits = 0;
+    if (fine_bits > 8) fine_bits = 8;
+    return fine_bits;
+}
+
+static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
+    memset(h, 0, sizeof *h);
+    h->magic = UTREE_IMG_MAGIC; h->version = 1;
+    h->W = ctr->info.W; h->I = ctr->info.I; h->k = ctr->info.k;
+    h->fine_bits = F; h->rec_words = utree_rec_words(h->W, h->I);
+    h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
+    h->flags = ctr->info.binix_width == 8 ? UTREE_F_OFF64 : 0;
+    h->n_fine = (1ull << (24 + F)) + 1;
+    uint64_t off = UTREE_IMG_HEADER_BYTES;
+    h->off_fine = off; off = align_up(off + h->n_fine * ((h->flags & UTREE_F_OFF64) ? 8 : 4), 256);
+    h->off_recs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 256);
+    h->off_irreg = off; off = align_up(off + (1u << 24) / 8, 256);
+    h->off_label_off = off; off = align_up(off + ((uint64_t)h->n_labels + 1) * 4, 256);
+    uint64_t blob = 0;
+    for (uint32_t i = 0; i < h->n_labels; ++i) blob += (uint64_t)ctr->label_len[i] + 1;
+    h->label_blob_bytes = blob;
+    h->off_label_blob = off; off = align_up(off + blob + 64, 256);
+    h->off_rank2ix = off; off = align_up(off + (uint64_t)h->n_labels * 4, 256);
+    h->total_bytes = off;
+}
+
+size_t utree_dev_image_bytes(const utree_ctr *ctr, int fine_bits) {
+    if (!ctr) return 0;
+    utree_image_header h;
+    layout(ctr, (uint32_t)utree_pick_fine_bits(ctr, fine_bits), &h);
+    return (size_t)h.total_bytes;
+}
+
+static void bind_image(utree_dev *d) {
+    char *b = (char *)d->image;
+    d->kimg.fine = b + d->hdr.off_fine;
+    d->kimg.recs = (const uint64_t *)(b + d->hdr.off_recs);
+    d->kimg.irreg = (const uint32_t *)(b + d->hdr.off_irreg);
+    d->kimg.label_off = (const uint32_t *)(b + d->hdr.off_label_off);
+    d->kimg.label_blob = b + d->hdr.off_label_blob;
+    d->kimg.rank2ix = (const uint32_t *)(b + d->hdr.off_rank2ix);
+    d->kimg.n_nodes = d->hdr.n_nodes;
+    d->kimg.n_labels = d->hdr.n_labels;
+    d->kimg.fine_bits = d->hdr.fine_bits;
+    d->kimg.flags = d->hdr.flags;
+    d->kimg.W = d->hdr.W; d->kimg.I = d->hdr.I;
+}
+
+static int device_ok(int device, int *n_cu) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return UTREE_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return UTREE_E_HIP;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return UTREE_E_HIP;
+    if (n_cu) *n_cu = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    return UTREE_OK;
+}
+
+/* ---- build ---------------------------------------------------------------------------------- */
+typedef struct {
+    utree_dev *d;
+    const utree_ctr *ctr;
+    uint32_t *d_ix2rank;
+    uint64_t *d_coarse;
+    unsigned long long *d_counters;
+    hipStream_t stream;
+} builder;
+
+static int build_begin(builder *b, const utree_ctr *ctr, int device, int fine_bits, void *d_image, size_t image_bytes,
+                       hipStream_t stream) {
+    int rc = UTREE_OK, n_cu = 0;
+    memset(b, 0, sizeof *b);
+    if ((rc = device_ok(device, &n_cu))) return rc;
+    utree_dev *d = (utree_dev *)calloc(1, sizeof *d);
+    if (!d) return UTREE_E_NOMEM;
+    b->d = d; b->ctr = ctr; b->stream = stream;
+    d->device = device; d->n_cu = n_cu;
+    layout(ctr, (uint32_t)utree_pick_fine_bits(ctr, fine_bits), &d->hdr);
+    if (d_image) {
+        if (image_bytes < d->hdr.total_bytes) { rc = UTREE_E_ARG; goto fail; }
+        d->image = d_image; d->owns = 0;
+    } else {
+        HIPCHK(hipMalloc(&d->image, d->hdr.total_bytes));
+        d->owns = 1;
+    }
+    d->image_bytes = d->hdr.total_bytes;
+    bind_image(d);
+    char *img = (char *)d->image;
+    HIPCHK(hipMemsetAsync(img, 0, UTREE_IMG_HEADER_BYTES, stream));
+    HIPCHK(hipMemsetAsync(img + d->hdr.off_irreg, 0, (1u << 24) / 8, stream));
+    /* labels in strcmp order */
+    {
+        uint32_t n = d->hdr.n_labels;
+        uint32_t *loff = (uint32_t *)malloc(((size_t)n + 1) * 4);
+        char *blob = (char *)calloc(d->hdr.label_blob_bytes + 64, 1);
+        if (!loff || !blob) { free(loff); free(blob); rc = UTREE_E_NOMEM; goto fail; }
+        uint64_t o = 0;
+        for (uint32_t r = 0; r < n; ++r) {
+            uint32_t ix = ctr->rank2ix[r];
+            loff[r] = (uint32_t)o;
+            memcpy(blob + o, ctr->labels[ix], ctr->label_len[ix]);
+            o += (uint64_t)ctr->label_len[ix] + 1;
+        }
+        loff[n] = (uint32_t)o;
+        hipError_t e1 = hipMemcpyAsync(img + d->hdr.off_label_off, loff, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, stream);
+        hipError_t e2 = hipMemcpyAsync(img + d->hdr.off_label_blob, blob, d->hdr.label_blob_bytes + 64, hipMemcpyHostToDevice, stream);
+        hipError_t e3 = hipMemcpyAsync(img + d->hdr.off_rank2ix, ctr->rank2ix, (size_t)n * 4, hipMemcpyHostToDevice, stream);
+        hipError_t e4 = hipStreamSynchronize(stream);
+        free(loff); free(blob);
+        HIPCHK(e1); HIPCHK(e2); HIPCHK(e3); HIPCHK(e4);
+        HIPCHK(hipMalloc((void **)&b->d_ix2rank, (size_t)n * 4));
+        HIPCHK(hipMemcpyAsync(b->d_ix2rank, ctr->ix2rank, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    }
+    return UTREE_OK;
+fail:
+    if (b->d_ix2rank) hipFree(b->d_ix2rank);
+    if (d->owns && d->image) hipFree(d->image);
+    free(d);
+    b->d = NULL;
+    return rc;
+}
+
+/* records [first, first+count) given as packed on-disk bytes in HBM */
+static int build_chunk(builder *b, const void *d_raw, uint64_t first, uint64_t count) {
+    utree_dev *d = b->d;
+    uint64_t *recs = (uint64_t *)((char *)d->image + d->hdr.off_recs) + first * d->hdr.rec_words;
+    int e = utk_repack(d->hdr.W, d->hdr.I, d_raw, count, b->d_ix2rank, d->hdr.n_labels, recs, b->stream);
+    if (e) { utree_dev_set_hip_error(e, "utk_repack"); return UTREE_E_HIP; }
+    return UTREE_OK;
+}
+
+static int build_finish(builder *b, const void *d_binix_raw) {
+    int rc = UTREE_OK;
+    utree_dev *d = b->d;
+    const utree_ctr *ctr = b->ctr;
+    hipStream_t st = b->stream;
+    char *img = (char *)d->image;
+    uint64_t *recs = (uint64_t *)(img + d->hdr.off_recs);
+    unsigned long long counters[2] = {0, 0};
+    HIPCHK(hipMalloc((void **)&b->d_coarse, (size_t)UTREE_NUMBINS * 8));
+    HIPCHK(hipMalloc((void **)&b->d_counters, 16));
+    HIPCHK(hipMemsetAsync(b->d_counters, 0, 16, st));
+    KCHK(utk_fill_recs_pad(recs + d->hdr.n_nodes * d->hdr.rec_words, 8 * d->hdr.rec_words, st));
+    KCHK(utk_widen_binix(d_binix_raw, ctr->info.binix_width, b->d_coarse, st));
+    KCHK(utk_validate(d->hdr.W, d->hdr.I, b->d_coarse, recs, d->hdr.n_nodes, (uint32_t *)(img + d->hdr.off_irreg),
+                      b->d_counters, st));
+    HIPCHK(hipMemcpyAsync(counters, b->d_counters, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    d->hdr.n_irregular = counters[0];
+    if (counters[1]) {
+        /* bin table not monotone (never written by the reference's COMPRESS): trust it verbatim like the
+         * reference does, i.e. no finer index and the exact probe sequence everywhere */
+        d->hdr.flags |= UTREE_F_GENERIC;
+        d->hdr.fine_bits = 0;
+        d->hdr.n_fine = (1ull << 24) + 1;
+        HIPCHK(hipMemsetAsync(img + d->hdr.off_irreg, 0xFF, (1u << 24) / 8, st));
+    } else if (counters[0]) d->hdr.flags |= UTREE_F_IRREGULAR;
+    KCHK(utk_build_fine(d->hdr.W, d->hdr.I, (d->hdr.flags & UTREE_F_OFF64) != 0, (d->hdr.flags & UTREE_F_GENERIC) != 0,
+                        b->d_coarse, recs, d->hdr.fine_bits, img + d->hdr.off_fine, st));
+    HIPCHK(hipMemcpyAsync(img, &d->hdr, sizeof d->hdr, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    bind_image(d);
+fail:
+    if (b->d_coarse) hipFree(b->d_coarse);
+    if (b->d_counters) hipFree(b->d_counters);
+    if (b->d_ix2rank) hipFree(b->d_ix2rank);
+    b->d_coarse = NULL; b->d_counters = NULL; b->d_ix2rank = NULL;
+    if (rc) { utree_dev_free(d); b->d = NULL; }
+    return rc;
+}
+
+int utree_dev_build(const utree_ctr *ctr, int device, int fine_bits, const void *d_binix, const void *d_records,
+                    void *d_image, size_t image_bytes, void *stream, utree_dev **out) {
+    if (!ctr || !d_binix || !d_records || !out) return UTREE_E_ARG;
+    *out = NULL;
+    builder b;
+    int rc = build_begin(&b, ctr, device, fine_bits, d_image, image_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    rc = build_chunk(&b, d_records, 0, ctr->info.n_nodes);
+    if (rc) { hipFree(b.d_ix2rank); utree_dev_free(b.d); return rc; }
+    rc = build_finish(&b, d_binix);
+    if (rc) return rc;
+    *out = b.d;
+    return UTREE_OK;
+}
+
+int utree_dev_upload(const utree_ctr *ctr, int device, int fine_bits, utree_dev **out) {
+    if (!ctr || !out) return UTREE_E_ARG;
+    *out = NULL;
+    if (!ctr->path && !ctr->h_records) return UTREE_E_ARG;
+    builder b;
+    int rc = build_begin(&b, ctr, device, fine_bits, NULL, 0, NULL);
+    if (rc) return rc;
+    const size_t SZ = ctr->info.SZ;
+    const size_t chunk_recs = ((size_t)48 << 20) / SZ;
+    const size_t chunk_bytes = chunk_recs * SZ;
+    void *h_pin[2] = {NULL, NULL}, *d_raw[2] = {NULL, NULL}, *d_binix = NULL;
+    hipEvent_t ev[2] = {NULL, NULL};
+    int fd = -1;
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipHostMalloc(&h_pin[i], chunk_bytes, hipHostMallocDefault));
+        HIPCHK(hipMalloc(&d_raw[i], chunk_bytes));
+        HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    }
+    if (ctr->path) {
+        fd = open(ctr->path, O_RDONLY);
+        if (fd < 0) { rc = UTREE_E_IO; goto fail; }
+    }
+    uint64_t done = 0, N = ctr->info.n_nodes;
+    for (int slot = 0; done < N; slot ^= 1) {
+        uint64_t cnt = N - done < chunk_recs ? N - done : chunk_recs;
+        size_t bytes = (size_t)cnt * SZ;
+        HIPCHK(hipEventSynchronize(ev[slot]));                 /* the pinned buffer is free again */
+        if (fd >= 0) {
+            size_t got = 0;
+            while (got < bytes) {
+                ssize_t r = pread(fd, (char *)h_pin[slot] + got, bytes - got, (off_t)(ctr->records_file_off + done * SZ + got));
+                if (r <= 0) { rc = UTREE_E_FORMAT; goto fail; }            /* "Error in reading tree." itree.c:768 */
+                got += (size_t)r;
+            }
+        } else memcpy(h_pin[slot], ctr->h_records + done * SZ, bytes);
+        HIPCHK(hipMemcpyAsync(d_raw[slot], h_pin[slot], bytes, hipMemcpyHostToDevice, NULL));
+        rc = build_chunk(&b, d_raw[slot], done, cnt);
+        if (rc) goto fail;
+        HIPCHK(hipEventRecord(ev[slot], NULL));
+        done += cnt;
+    }
+    HIPCHK(hipMalloc(&d_binix, (size_t)UTREE_NUMBINS * ctr->info.binix_width));
+    HIPCHK(hipMemcpyAsync(d_binix, ctr->binix_raw, (size_t)UTREE_NUMBINS * ctr->info.binix_width, hipMemcpyHostToDevice, NULL));
+    rc = build_finish(&b, d_binix);
+    if (!rc) *out = b.d;
+    b.d = NULL;
+fail:
+    if (fd >= 0) close(fd);
+    hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) {
+        if (h_pin[i]) hipHostFree(h_pin[i]);
+        if (d_raw[i]) hipFree(d_raw[i]);
+        if (ev[i]) hipEventDestroy(ev[i]);
+    }
+    if (d_binix) hipFree(d_binix);
+    if (rc && b.d) { if (b.d_ix2rank) hipFree(b.d_ix2rank); utree_dev_free(b.d); }
+    return rc;
+}
+
+int utree_dev_image(const utree_dev *dev, void **d_image, size_t *bytes) {
+    if (!dev) return UTREE_E_ARG;
+    if (d_image) *d_image = dev->image;
+    if (bytes) *bytes = dev->image_bytes;
+    return UTREE_OK;
+}
+
+int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t bytes, utree_dev **out) {
+    int rc = UTREE_OK, n_cu = 0;
+    if (!d_image || !out || bytes < UTREE_IMG_HEADER_BYTES) return UTREE_E_ARG;
+    *out = NULL;
+    if ((rc = device_ok(device, &n_cu))) return rc;
+    utree_dev *d = (utree_dev *)calloc(1, sizeof *d);
+    if (!d) return UTREE_E_NOMEM;
+    d->device = device; d->n_cu = n_cu; d->image = d_image; d->owns = 0;
+    HIPCHK(hipMemcpy(&d->hdr, d_image, sizeof d->hdr, hipMemcpyDeviceToHost));
+    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 1 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
+    if (ctr && (ctr->info.W != d->hdr.W || ctr->info.I != d->hdr.I || ctr->info.n_nodes != d->hdr.n_nodes ||
+                ctr->info.n_labels != d->hdr.n_labels)) { rc = UTREE_E_ARG; goto fail; }
+    d->image_bytes = d->hdr.total_bytes;
+    bind_image(d);
+    *out = d;
+    return UTREE_OK;
+fail:
+    free(d);
+    return rc;
+}
+
+void utree_dev_free(utree_dev *d) {
+    if (!d) return;
+    hipSetDevice(d->device);
+    for (int i = 0; i < d->n_events; ++i) hipEventDestroy(d->events[i]);
+    if (d->owns && d->image) hipFree(d->image);
+    free(d);
+}
+
+int utree_dev_get_info(const utree_dev *d, utree_dev_info *info) {
+    if (!d || !info) return UTREE_E_ARG;
+    info->fine_bits = d->hdr.fine_bits;
+    info->record_bytes = d->hdr.rec_words * 8;
+    info->image_bytes = d->image_bytes;
+    info->irregular_bins = d->hdr.n_irregular;
+    info->generic_mode = (d->hdr.flags & UTREE_F_GENERIC) != 0;
+    info->device = d->device;
+    return UTREE_OK;
+}
+
+/* ---- batches --------------------------------------------------------------------------------- */
+#define LONG_BLOCKS_PER_CU 2
+
+static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc,
+                  utk_workspace *w, size_t *bytes) {
+    uint64_t off = 0;
+    char *b = (char *)ws;
+    w->cursors = (unsigned long long *)(b + off); off = align_up(off + 64, 256);
+    w->tally_cap = (do_rc ? 2 : 1) * total_bases + (uint64_t)n_reads + 64;
+    w->tally = (uint64_t *)(b + off); off = align_up(off + w->tally_cap * 8, 256);
+    w->vote_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
+    w->long_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
+    uint64_t max_total = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
+    w->long_blocks = 0; w->hist = NULL;
+    if (max_total > UTREE_SHORT_CAP) {
+        w->long_blocks = (uint32_t)d->n_cu * LONG_BLOCKS_PER_CU;
+        if (w->long_blocks > n_reads) w->long_blocks = n_reads;
+        w->hist = (uint32_t *)(b + off); off = align_up(off + (uint64_t)w->long_blocks * d->hdr.n_labels * 4, 256);
+    }
+    *bytes = (size_t)off;
+}
+
+size_t utree_classify_workspace_bytes(const utree_dev *dev, uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc) {
+    if (!dev) return 0;
+    utk_workspace w; size_t bytes;
+    carve(dev, NULL, n_reads, total_bases, max_len, do_rc, &w, &bytes);
+    return bytes;
+}
+
+int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
+                         uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc, utree_result *d_out,
+                         void *d_workspace, size_t workspace_bytes, void *stream) {
+    int rc = UTREE_OK;
+    if (!d || !d_out || (!d_workspace && n_reads)) return UTREE_E_ARG;
+    if (!n_reads) return UTREE_OK;
+    if (!d_bases || !d_off || !d_len) return UTREE_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    utk_workspace w; size_t need;
+    carve(d, d_workspace, n_reads, total_bases, max_len, do_rc, &w, &need);
+    if (workspace_bytes < need) return UTREE_E_ARG;
+    HIPCHK(hipSetDevice(d->device));
+    HIPCHK(hipMemsetAsync(w.cursors, 0, 64, st));
+    if (w.long_blocks) HIPCHK(hipMemsetAsync(w.hist, 0, (size_t)w.long_blocks * d->hdr.n_labels * 4, st));
+    /* HIP events on the launch stream bracket the dominant kernel (bench.py's roofline leg) */
+    hipEvent_t e0 = NULL, e1 = NULL;
+    if (d->timing_on && d->n_pending < UTREE_MAX_PENDING) {
+        if (d->n_events < 2 * (d->n_pending + 1)) {
+            HIPCHK(hipEventCreate((hipEvent_t *)&d->events[d->n_events])); d->n_events++;
+            HIPCHK(hipEventCreate((hipEvent_t *)&d->events[d->n_events])); d->n_events++;
+        }
+        e0 = d->events[2 * d->n_pending]; e1 = d->events[2 * d->n_pending + 1];
+        HIPCHK(hipEventRecord(e0, st));
+    }
+    KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
+    if (e0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
+    if (w.long_blocks) KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &w, d->n_cu, st));
+    KCHK(utk_vote(&d->kimg, d_out, &w, n_reads, st));
+fail:
+    return rc;
+}
+
+int utree_lookup_words(utree_dev *d, const uint64_t *d_hi, const uint64_t *d_lo, uint64_t n, uint32_t *d_ix, void *stream) {
+    int rc = UTREE_OK;
+    if (!d || !d_lo || !d_ix) return UTREE_E_ARG;
+    if (d->hdr.W == 16 && !d_hi) return UTREE_E_ARG;
+    HIPCHK(hipSetDevice(d->device));
+    KCHK(utk_lookup(&d->kimg, d_hi, d_lo, n, d_ix, (hipStream_t)stream));
+fail:
+    return rc;
+}
+
+const char *utree_classify_kernel_name(const utree_dev *d) {
+    return d ? utk_classify_short_name(d->hdr.W, d->hdr.I) : "";
+}
+
+int utree_classify_kernel_time(utree_dev *d, int reset, double *ms_total, uint64_t *launches) {
+    int rc = UTREE_OK;
+    if (!d) return UTREE_E_ARG;
+    HIPCHK(hipSetDevice(d->device));
+    for (int i = 0; i < d->n_pending; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventSynchronize(d->events[2 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, d->events[2 * i], d->events[2 * i + 1]));
+        d->ms_total += ms; d->launches++;
+    }
+    d->n_pending = 0;
+    if (ms_total) *ms_total = d->ms_total;
+    if (launches) *launches = d->launches;
+    if (reset) { d->ms_total = 0; d->launches = 0; }
+    d->timing_on = 1;
+fail:
+    return rc;
+}

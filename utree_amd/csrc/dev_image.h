@@ -1,0 +1,25 @@
+/* dev_image.h -- private definition of utree_dev. */
+#ifndef UTREE_DEV_IMAGE_H
+#define UTREE_DEV_IMAGE_H
+#include "utree_internal.h"
+
+#define UTREE_MAX_PENDING 256
+
+struct utree_dev {
+    int device, n_cu, owns;
+    void *image;
+    size_t image_bytes;
+    utree_image_header hdr;
+    utk_image kimg;
+    /* HIP-event timing of the dominant kernel (enabled by the first utree_classify_kernel_time call) */
+    int timing_on, n_pending, n_events;
+    void *events[2 * UTREE_MAX_PENDING];
+    double ms_total;
+    uint64_t launches;
+};
+
+void utree_dev_set_hip_error(int err, const char *what);
+const char *utree_last_hip_error(void);
+int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits);
+
+#endif

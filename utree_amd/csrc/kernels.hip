@@ -1,0 +1,673 @@
+// kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the SEARCH_GG path and their C launchers.
+//
+// Written for wave64 / gfx950 only.  Integer, pointer-chasing work: no MFMA.  What bounds each kernel,
+// its algorithmic bytes and the HBM layout are in DESIGN.md; the reference behaviour each kernel
+// reproduces is cited as itree.c:line.
+//
+//   repack_k        on-disk SZ-byte records -> 8-byte-aligned {suffix,rank} records   (load time)
+//   validate_k      per-bin ascending check, irregular-bin bitmap                      (load time)
+//   build_fine_k    24+F-bit prefix index by lower_bound inside each 24-bit bin        (load time)
+//   classify_short  one wavefront per read: stage through LDS, roll k-mers, look up, tally
+//   classify_long   one workgroup per read for reads that do not fit a wavefront's LDS slice
+//   vote_k          one lane per read: rank-wise LCA descent on the sorted unique label list
+//   lookup_k        XT_getIX32 alone (tests, micro-benchmarks)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "utree_internal.h"
+
+namespace {
+
+constexpr uint64_t M40 = (1ull << 40) - 1;
+constexpr uint32_t INVALID = 0xFFFFFFFFu;
+
+// ------------------------------------------------------------------------------------------------
+// keys and records
+// ------------------------------------------------------------------------------------------------
+template <int W> struct Key { uint64_t hi, lo; };   // hi is the top 40 suffix bits for W=16, else 0
+
+template <int W> __device__ __forceinline__ bool key_eq(const Key<W> &a, const Key<W> &b) {
+    if constexpr (W == 16) return a.lo == b.lo && a.hi == b.hi; else return a.lo == b.lo;
+}
+template <int W> __device__ __forceinline__ bool key_lt(const Key<W> &a, const Key<W> &b) {
+    if constexpr (W == 16) return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); else return a.lo < b.lo;
+}
+template <int W> __device__ __forceinline__ bool key_le(const Key<W> &a, const Key<W> &b) { return !key_lt<W>(b, a); }
+
+template <int W, int I> struct RecTraits { static constexpr int RW = (W == 16 ? 2 : 1) + (I == 4 ? 1 : 0); };
+
+// In-HBM record:  W=8,I=2: {suf40 | rank16<<40}          W=8,I=4: {suf40}{rank32}
+//                                 W=16,I=2: {lo64}{hi40 | rank16<<40}    W=16,I=4: {lo64}{hi40}{rank32}
+template <int W, int I> __device__ __forceinline__ Key<W> load_key(const uint64_t *recs, uint64_t i) {
+    const uint64_t *p = recs + i * RecTraits<W, I>::RW;
+    Key<W> k;
+    if constexpr (W == 16) { k.lo = p[0]; k.hi = p[1] & M40; }
+    else { k.lo = p[0] & M40; k.hi = 0; }
+    return k;
+}
+template <int W, int I> __device__ __forceinline__ uint32_t load_rank(const uint64_t *recs, uint64_t i) {
+    const uint64_t *p = recs + i * RecTraits<W, I>::RW;
+    if constexpr (I == 4) return (uint32_t)p[RecTraits<W, I>::RW - 1];
+    else {
+        uint32_t r = (uint32_t)(p[RecTraits<W, I>::RW - 1] >> 40) & 0xFFFFu;
+        return r == 0xFFFFu ? INVALID : r;
+    }
+}
+// key and rank of one record with the loads shared where they sit in the same word
+template <int W, int I> __device__ __forceinline__ void load_rec(const uint64_t *recs, uint64_t i, Key<W> &k, uint32_t &rank) {
+    if constexpr (I == 2) {
+        const uint64_t *p = recs + i * RecTraits<W, I>::RW;
+        uint64_t last = p[RecTraits<W, I>::RW - 1];
+        if constexpr (W == 16) { k.lo = p[0]; k.hi = last & M40; } else { k.lo = last & M40; k.hi = 0; }
+        uint32_t r = (uint32_t)(last >> 40) & 0xFFFFu;
+        rank = r == 0xFFFFu ? INVALID : r;
+    } else {
+        k = load_key<W, I>(recs, i);
+        rank = load_rank<W, I>(recs, i);
+    }
+}
+
+// The reference's probe sequence, verbatim in behaviour (itree.c:699-707, 728): p = first record of the
+// bin; over the remaining e-s-1 records probe record w+1 past p; "<= query" moves p there.
+template <int W, int I> __device__ uint32_t exact_probe(const uint64_t *recs, uint64_t s, uint64_t e, const Key<W> &q) {
+    uint64_t p = s, size = e - s - 1;
+    while (size) {
+        uint64_t w = size >> 1;
+        Key<W> k = load_key<W, I>(recs, p + w + 1);
+        if (key_le<W>(k, q)) { p += w + 1; size -= w + 1; }
+        else size = w;
+    }
+    Key<W> k = load_key<W, I>(recs, p);
+    return key_eq<W>(k, q) ? load_rank<W, I>(recs, p) : INVALID;
+}
+
+// XT_getIX32 (itree.c:720-730) on the device image.  khi:klo is the 2k-bit word.
+template <int W, int I, bool EXC, typename OFF>
+__device__ __forceinline__ uint32_t lookup_word(const utk_image &im, uint64_t khi, uint64_t klo) {
+    const OFF *fine = (const OFF *)im.fine;
+    const uint32_t F = im.fine_bits;
+    uint64_t top = (W == 16) ? khi : klo;         // the 64 bits holding prefix (24) + first 40 suffix bits
+    uint32_t p = (uint32_t)(top >> 40);           // itree.c:684 PREFIX_L
+    Key<W> q;
+    if constexpr (W == 16) { q.hi = khi & M40; q.lo = klo; } else { q.hi = 0; q.lo = klo & M40; }
+    uint64_t fq = top >> (40 - F);                // 24+F-bit fine prefix
+    uint64_t fs = fine[fq], fe = fine[fq + 1];
+    if constexpr (EXC) {
+        if ((im.irreg[p >> 5] >> (p & 31)) & 1u) {
+            uint64_t s = fine[(uint64_t)p << F], e = fine[((uint64_t)p + 1) << F];   // itree.c:724
+            if (s >= e || e > im.n_nodes) return INVALID;                          // itree.c:726
+            return exact_probe<W, I>(im.recs, s, e, q);
+        }
+    }
+    if (fs >= fe) return INVALID;
+    // the fine bin is strictly ascending: any exact-match search equals the reference's result
+    Key<W> k0, k1;
+    uint32_t r0, r1;
+    load_rec<W, I>(im.recs, fs, k0, r0);
+    load_rec<W, I>(im.recs, fs + 1, k1, r1);      // the record array is padded: always readable
+    if (key_eq<W>(k0, q)) return r0;
+    uint64_t n = fe - fs;
+    if (n == 1 || key_lt<W>(q, k0)) return INVALID;
+    if (key_eq<W>(k1, q)) return r1;
+    if (n == 2 || key_lt<W>(q, k1)) return INVALID;
+    uint64_t lo = fs + 2, hi = fe;
+    while (lo < hi) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        Key<W> k = load_key<W, I>(im.recs, mid);
+        if (key_lt<W>(k, q)) lo = mid + 1;
+        else if (key_eq<W>(k, q)) return load_rank<W, I>(im.recs, mid);
+        else hi = mid;
+    }
+    return INVALID;
+}
+
+// ------------------------------------------------------------------------------------------------
+// load-time kernels
+// ------------------------------------------------------------------------------------------------
+template <int W, int I>
+__global__ void repack_k(const uint8_t *__restrict__ raw, uint64_t count, const uint32_t *__restrict__ ix2rank,
+                         uint32_t n_labels, uint64_t *__restrict__ recs) {
+    constexpr int SZ = W + I - 3, SB = W - 3, RW = RecTraits<W, I>::RW;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *p = raw + i * SZ;
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            if (b < 8) lo |= (uint64_t)p[b] << (8 * b); else hi |= (uint64_t)p[b] << (8 * (b - 8));
+        }
+        uint32_t ix = 0;
+#pragma unroll
+        for (int b = 0; b < I; ++b) ix |= (uint32_t)p[SB + b] << (8 * b);
+        uint32_t rank = ix < n_labels ? ix2rank[ix] : INVALID;      // itree.c:929 `ix < maxIX`
+        uint64_t *o = recs + i * RW;
+        if constexpr (I == 2) {
+            uint64_t r16 = rank == INVALID ? 0xFFFFull : (uint64_t)rank;
+            if constexpr (W == 16) { o[0] = lo; o[1] = hi | (r16 << 40); } else { o[0] = lo | (r16 << 40); }
+        } else {
+            if constexpr (W == 16) { o[0] = lo; o[1] = hi; o[2] = rank; } else { o[0] = lo; o[1] = rank; }
+        }
+    }
+}
+
+__global__ void widen_binix_k(const void *raw, uint32_t width, uint64_t *coarse) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= UTREE_NUMBINS) return;
+    coarse[i] = width == 4 ? (uint64_t)((const uint32_t *)raw)[i] : ((const uint64_t *)raw)[i];
+}
+
+template <int W, int I>
+__global__ void validate_k(const uint64_t *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t n_nodes,
+                           uint32_t *irreg, unsigned long long *counters) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= UTREE_NUMBINS - 1) return;
+    uint64_t s = coarse[p], e = coarse[p + 1];
+    if (s > e || e > n_nodes) { counters[1] = 1; return; }
+    if (e - s < 2) return;
+    Key<W> prev = load_key<W, I>(recs, s);
+    for (uint64_t j = s + 1; j < e; ++j) {
+        Key<W> cur = load_key<W, I>(recs, j);
+        if (!key_lt<W>(prev, cur)) {
+            atomicOr(&irreg[p >> 5], 1u << (p & 31));
+            atomicAdd(&counters[0], 1ull);
+            return;
+        }
+        prev = cur;
+    }
+}
+
+template <int W, int I, typename OFF>
+__global__ void build_fine_k(const uint64_t *__restrict__ coarse, const uint64_t *__restrict__ recs, uint32_t F,
+                             int generic, OFF *__restrict__ fine) {
+    uint64_t nfine = (1ull << (24 + F)) + 1;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nfine; q += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t p = q >> F, f = q & ((1ull << F) - 1);
+        uint64_t s = coarse[p];
+        if (p == UTREE_NUMBINS - 1 || f == 0 || generic) { fine[q] = (OFF)s; continue; }
+        uint64_t e = coarse[p + 1];
+        Key<W> t;
+        if constexpr (W == 16) { t.hi = f << (40 - F); t.lo = 0; } else { t.hi = 0; t.lo = f << (40 - F); }
+        uint64_t lo = s, hi = e;                       // first record with key >= t
+        while (lo < hi) {
+            uint64_t mid = lo + ((hi - lo) >> 1);
+            if (key_lt<W>(load_key<W, I>(recs, mid), t)) lo = mid + 1; else hi = mid;
+        }
+        fine[q] = (OFF)lo;
+    }
+}
+
+__global__ void fill_pad_k(uint64_t *p, uint32_t words) {
+    if (threadIdx.x < words) p[threadIdx.x] = ~0ull;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of one wave execute in issue order; this only stops the compiler from moving a
+    // lane's LDS reads above another lane's LDS writes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// base byte -> 2-bit code and "bad" flag (itree.c:110-121).  A=0 C=1 G=2 T=3, either case.
+__device__ __forceinline__ void base_code(uint32_t b, uint32_t &code, bool &bad) {
+    uint32_t u = b & 0xDFu;
+    bad = !(u == 'A' || u == 'C' || u == 'G' || u == 'T');
+    uint32_t g = (b >> 1) & 3u;                        // A:0 C:1 G:3 T:2
+    code = g ^ (g >> 1);
+}
+
+// Byte j of the staged sequence of read (o, L): forward strand, then (RC only) a separator that breaks
+// every window, then the reverse complement (itree.c:891-898).  Positions past the end are "bad".
+__device__ __forceinline__ void staged_base(const uint8_t *__restrict__ bases, uint64_t o, uint32_t L, uint32_t total,
+                                            uint32_t j, uint32_t &code, bool &bad) {
+    code = 0; bad = true;
+    if (j < L) base_code(bases[o + j], code, bad);
+    else if (j > L && j < total) { base_code(bases[o + (2 * L - j)], code, bad); code ^= 3u; }
+}
+
+// k-mer word of the window that starts at base i, from the big-endian packed 2-bit stream in LDS
+// (word j holds bases 16j..16j+15, base 16j in the top two bits).  itree.c:924: first base most significant.
+template <int W> __device__ __forceinline__ void window_word(const uint32_t *sw, uint32_t i, uint64_t &khi, uint64_t &klo) {
+    uint32_t j = i >> 4, sh = 32u - ((i & 15u) << 1);          // sh in [2,32]
+    uint64_t a = ((uint64_t)sw[j] << 32) | sw[j + 1];
+    uint64_t b = ((uint64_t)sw[j + 1] << 32) | sw[j + 2];
+    uint32_t x0 = (uint32_t)(a >> sh), x1 = (uint32_t)(b >> sh);
+    if constexpr (W == 16) {
+        uint64_t c = ((uint64_t)sw[j + 2] << 32) | sw[j + 3];
+        uint64_t d = ((uint64_t)sw[j + 3] << 32) | sw[j + 4];
+        uint32_t x2 = (uint32_t)(c >> sh), x3 = (uint32_t)(d >> sh);
+        khi = ((uint64_t)x0 << 32) | x1; klo = ((uint64_t)x2 << 32) | x3;
+    } else { khi = 0; klo = ((uint64_t)x0 << 32) | x1; }
+}
+
+__device__ __forceinline__ void store_result(utree_result *out, uint32_t label, int32_t cut, uint32_t found,
+                                             uint32_t uix, uint32_t sl, uint32_t ol) {
+    uint32_t *o = (uint32_t *)out;
+    o[0] = label; o[1] = (uint32_t)cut; o[2] = found; o[3] = uix; o[4] = sl; o[5] = ol;
+}
+
+// ------------------------------------------------------------------------------------------------
+// classify_short: one wavefront per read (reads whose staged length fits UTREE_SHORT_CAP bases)
+// ------------------------------------------------------------------------------------------------
+constexpr int SHORT_CAP = UTREE_SHORT_CAP;
+constexpr int SHORT_NCH = SHORT_CAP / 64;
+constexpr int SHORT_WORDS = SHORT_CAP / 16 + 6;
+constexpr int WAVES_PER_BLOCK = 4;
+
+template <int W, int I, bool EXC, typename OFF>
+__global__ __launch_bounds__(256) void classify_short_k(utk_image im, const uint8_t *__restrict__ bases,
+                                                        const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+                                                        uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
+                                                        utk_workspace ws) {
+    constexpr uint32_t K = 4 * W;
+    __shared__ uint32_t s_words[WAVES_PER_BLOCK][SHORT_WORDS];
+    __shared__ uint64_t s_bad[WAVES_PER_BLOCK][SHORT_NCH + 2];
+    __shared__ uint32_t s_hits[WAVES_PER_BLOCK][SHORT_CAP];
+    const uint32_t lane = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
+    uint32_t *sw = s_words[wv];
+    uint8_t *sb = (uint8_t *)sw;
+    uint64_t *sbad = s_bad[wv];
+    uint32_t *hits = s_hits[wv];
+    const uint32_t wave_gid = blockIdx.x * WAVES_PER_BLOCK + wv, n_waves = gridDim.x * WAVES_PER_BLOCK;
+
+    for (uint32_t r = wave_gid; r < n_reads; r += n_waves) {
+        const uint32_t L = len[r];
+        const uint64_t o = off[r];
+        const uint32_t total = do_rc ? 2 * L + 1 : L;
+        if (total > SHORT_CAP) {                           // handed to classify_long
+            if (lane == 0) ws.long_list[atomicAdd(&ws.cursors[2], 1ull)] = r;
+            continue;
+        }
+        if (total < K) {                                   // no window: no hit, no output line
+            if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0);
+            continue;
+        }
+        const uint32_t nwin = total - K + 1;
+        const uint32_t nch = (total + 63) >> 6;
+        // ---- stage: bytes -> 2-bit codes packed big-endian in LDS, bad-base ballots ----
+        for (uint32_t c = 0; c < nch; ++c) {
+            uint32_t code; bool bad;
+            staged_base(bases, o, L, total, c * 64 + lane, code, bad);
+            uint64_t bm = __ballot(bad);
+            uint32_t t = (code << 2) | (uint32_t)__shfl_down((int)code, 1);
+            uint32_t u = (t << 4) | (uint32_t)__shfl_down((int)t, 2);
+            if ((lane & 3u) == 0) sb[(c * 16 + (lane >> 2)) ^ 3u] = (uint8_t)u;
+            if (lane == 0) sbad[c] = bm;
+        }
+        if (lane == 0) sbad[nch] = ~0ull;
+        wave_lds_fence();
+        // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933) ----
+        uint32_t F = 0;
+        for (uint32_t it = 0; it * 64 < nwin; ++it) {
+            const uint32_t i = it * 64 + lane;
+            uint64_t b0 = sbad[it], b1 = sbad[it + 1];
+            uint64_t x = (b0 >> lane) | (lane ? (b1 << (64 - lane)) : 0ull);     // bad flags of bases i..i+63
+            bool ok = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
+            uint32_t rank = INVALID;
+            if (ok) {
+                uint64_t khi, klo;
+                window_word<W>(sw, i, khi, klo);
+                rank = lookup_word<W, I, EXC, OFF>(im, khi, klo);
+            }
+            bool hit = rank != INVALID;                     // itree.c:929-931
+            uint64_t hm = __ballot(hit);
+            if (hit) hits[F + lanes_below(hm)] = rank;
+            F += (uint32_t)__popcll(hm);
+        }
+        wave_lds_fence();
+        // ---- tally (itree.c:1028-1040): unique labels with counts, ascending rank = strcmp order ----
+        if (F == 0) { if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); continue; }
+        const uint32_t h0 = hits[0];
+        if (F == 1) { if (lane == 0) store_result(&out[r], im.rank2ix[h0], -2, 1, 1, 0, 0); continue; }
+        // all hits equal?  (the common case for reads from one taxon)
+        uint32_t mn = INVALID, mx = 0;
+        for (uint32_t j = lane; j < F; j += 64) { uint32_t h = hits[j]; mn = h < mn ? h : mn; mx = h > mx ? h : mx; }
+        mn = wave_min_u32(mn);
+        mx = ~wave_min_u32(~mx);
+        if (mn == mx) { if (lane == 0) store_result(&out[r], im.rank2ix[h0], -2, F, 1, 0, 0); continue; }
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&ws.cursors[0], (unsigned long long)F);
+        base = __shfl(base, 0);
+        uint32_t uix = 0, cur = mn;
+        for (;;) {
+            uint32_t c = 0, nxt = INVALID;
+            for (uint32_t j = lane; j < F; j += 64) {
+                uint32_t h = hits[j];
+                c += h == cur;
+                if (h > cur && h < nxt) nxt = h;
+            }
+            c = wave_sum_u32(c);
+            nxt = wave_min_u32(nxt);
+            if (lane == 0) ws.tally[base + uix] = (uint64_t)cur | ((uint64_t)c << 32);
+            ++uix;
+            if (nxt == INVALID) break;
+            cur = nxt;
+        }
+        if (lane == 0) {
+            // vote_k finishes this read: label/cut are placeholders, sl/ol carry the tally offset
+            store_result(&out[r], im.rank2ix[h0], -2, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
+            ws.vote_list[atomicAdd(&ws.cursors[1], 1ull)] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// classify_long: one workgroup per read, any length (itree.c:836: lines up to 16 MiB).  The read is
+// walked in tiles staged through LDS; hits go to a per-workgroup label histogram in HBM (rank order),
+// which is then compacted into the same sorted (rank,count) list the short path emits.
+// ------------------------------------------------------------------------------------------------
+constexpr int LONG_TILE = 4096;                       // windows per tile
+constexpr int LONG_THREADS = 256;
+
+template <int W, int I, bool EXC, typename OFF>
+__global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, const uint8_t *__restrict__ bases,
+                                                                const uint64_t *__restrict__ off,
+                                                                const uint32_t *__restrict__ len, int do_rc,
+                                                                utree_result *__restrict__ out, utk_workspace ws) {
+    constexpr uint32_t K = 4 * W;
+    constexpr uint32_t STAGE = LONG_TILE + 64;          // bases staged per tile (tile + K-1, rounded up)
+    __shared__ uint32_t s_words[STAGE / 16 + 8];
+    __shared__ uint64_t s_bad[STAGE / 64 + 2];
+    __shared__ uint32_t s_scan[LONG_THREADS / 64 + 1];
+    __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_first;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    uint8_t *sb = (uint8_t *)s_words;
+    uint32_t *hist = ws.hist + (size_t)blockIdx.x * im.n_labels;     // all zero between reads
+    const uint32_t n_long = (uint32_t)ws.cursors[2];
+
+    for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) {
+        const uint32_t r = ws.long_list[li];
+        const uint64_t L64 = len[r];
+        const uint64_t o = off[r];
+        const uint64_t total = do_rc ? 2 * L64 + 1 : L64;
+        const uint64_t nwin = total >= K ? total - K + 1 : 0;
+        uint32_t my_hits = 0;
+        if (tid == 0) s_first = INVALID;
+        __syncthreads();
+        for (uint64_t w0 = 0; w0 < nwin; w0 += LONG_TILE) {
+            // stage bases [w0, w0+STAGE)
+            for (uint32_t c = wv; c < STAGE / 64; c += LONG_THREADS / 64) {
+                uint64_t j = w0 + (uint64_t)c * 64 + lane;
+                uint32_t code = 0; bool bad = true;
+                if (j < L64) base_code(bases[o + j], code, bad);
+                else if (j > L64 && j < total) { base_code(bases[o + (2 * L64 - j)], code, bad); code ^= 3u; }
+                uint64_t bm = __ballot(bad);
+                uint32_t t = (code << 2) | (uint32_t)__shfl_down((int)code, 1);
+                uint32_t u = (t << 4) | (uint32_t)__shfl_down((int)t, 2);
+                if ((lane & 3u) == 0) sb[(c * 16 + (lane >> 2)) ^ 3u] = (uint8_t)u;
+                if (lane == 0) s_bad[c] = bm;
+            }
+            if (tid == 0) s_bad[STAGE / 64] = ~0ull;
+            __syncthreads();
+            uint64_t tile_n = nwin - w0 < LONG_TILE ? nwin - w0 : LONG_TILE;
+            for (uint32_t i = tid; i < tile_n; i += LONG_THREADS) {
+                uint32_t ch = i >> 6, bit = i & 63u;
+                uint64_t x = (s_bad[ch] >> bit) | (bit ? (s_bad[ch + 1] << (64 - bit)) : 0ull);
+                bool ok = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
+                if (ok) {
+                    uint64_t khi, klo;
+                    window_word<W>(s_words, i, khi, klo);
+                    uint32_t rank = lookup_word<W, I, EXC, OFF>(im, khi, klo);
+                    if (rank != INVALID) { atomicAdd(&hist[rank], 1u); ++my_hits; }
+                }
+            }
+            __syncthreads();
+        }
+        // F = total hits
+        uint32_t f = wave_sum_u32(my_hits);
+        if (lane == 0) s_scan[wv] = f;
+        __syncthreads();
+        uint32_t F = 0;
+        for (uint32_t w = 0; w < LONG_THREADS / 64; ++w) F += s_scan[w];
+        __syncthreads();
+        if (F == 0) { if (tid == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); continue; }
+        // count distinct labels, then compact the histogram in rank order (and zero it again)
+        // make the other waves' global atomics visible to this workgroup's plain loads
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const uint32_t nl = im.n_labels;
+        const uint32_t per = (nl + LONG_THREADS - 1) / LONG_THREADS;
+        const uint32_t lo = tid * per, hi = (lo + per < nl) ? lo + per : nl;
+        uint32_t cnt = 0;
+        for (uint32_t x = lo; x < hi; ++x) cnt += __hip_atomic_load(&hist[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        // exclusive prefix over threads: wave scan + wave totals
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += t; }
+        if (lane == 63) s_scan[wv] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, uix = 0;
+        for (uint32_t w = 0; w < LONG_THREADS / 64; ++w) { if (w < wv) wbase += s_scan[w]; uix += s_scan[w]; }
+        uint32_t pos = wbase + inc - cnt;
+        if (tid == 0) s_base = uix > 1 ? atomicAdd(&ws.cursors[0], (unsigned long long)uix) : 0ull;
+        __syncthreads();
+        const unsigned long long base = s_base;
+        for (uint32_t x = lo; x < hi; ++x) {
+            uint32_t c = __hip_atomic_load(&hist[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c) {
+                if (uix > 1) ws.tally[base + pos] = (uint64_t)x | ((uint64_t)c << 32);
+                else s_first = x;
+                ++pos;
+                __hip_atomic_store(&hist[x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (uix == 1) store_result(&out[r], im.rank2ix[s_first], -2, F, 1, 0, 0);
+            else {
+                store_result(&out[r], 0, -2, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
+                ws.vote_list[atomicAdd(&ws.cursors[1], 1ull)] = r;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vote_k: greedy rank-wise descent with the 75 % cutoff (itree.c:1044-1088), one lane per read.
+// T is the read's distinct labels in strcmp order (= ascending rank) with their hit counts.
+// All state is 32-bit unsigned with wrap-around, like the reference's.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t cut_of(uint32_t x) {          // itree.c:1044,1046 (TAXACUT = 4)
+    uint32_t c = x - x / 4;
+    c += (x >> 1) >= c;
+    return c;
+}
+
+__global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__restrict__ out, utk_workspace ws) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = (uint32_t)ws.cursors[1];
+    if (t >= n) return;
+    const uint32_t r = ws.vote_list[t];
+    const uint32_t *res = (const uint32_t *)&out[r];
+    const uint32_t F = res[2], uix = res[3];
+    const uint64_t *T = ws.tally + ((uint64_t)res[4] | ((uint64_t)res[5] << 32));
+    const char *blob = im.label_blob;
+    const uint32_t *loff = im.label_off;
+#define T_RANK(z) ((uint32_t)T[z])
+#define T_CNT(z) ((uint32_t)(T[z] >> 32))
+    uint32_t cutoff = cut_of(F);
+    uint32_t st = 0, ed = uix, dv = 0xFFFFFFFFu, orun = F, sl, ol;
+    for (;;) {
+        uint32_t run = T_CNT(st), td = dv;
+        for (uint32_t z = st + 1; z < ed; ++z) {
+            const char *s1 = blob + loff[T_RANK(z - 1)], *s2 = blob + loff[T_RANK(z)];
+            const uint32_t nz = T_CNT(z);
+            bool aside = false;
+            if (!s1[dv + (dv == 0xFFFFFFFFu)]) aside = true;                 // itree.c:1052
+            else {
+                for (td = dv + 1; s1[td] && s1[td] == s2[td]; ++td)            // itree.c:1060-1061
+                    if (s1[td] == ';') break;
+                const char a = s1[td], b = s2[td];
+                if (a == b) { run += nz; continue; }                           // itree.c:1062
+                const char before = td ? s1[td - 1] : 0;
+                if ((!a && b == ';') || ((a == ';' || !a) && before == '_')) aside = true;   // 1063
+                else if (run >= cutoff) { ed = z; break; }                     // itree.c:1068
+                else { run = nz; st = z; continue; }                           // itree.c:1069
+            }
+            if (aside) {                                                       // 1053-1056 / 1064-1067
+                run = nz; st = z;
+                orun -= T_CNT(z - 1);
+                cutoff = cut_of(orun);
+            }
+        }
+        sl = run; ol = orun;                                                   // itree.c:1071
+        if (run < cutoff) break;                                               // itree.c:1072
+        if (st + 1 >= ed) {                                                    // itree.c:1073-1079
+            if (T_CNT(ed - 1) >= cutoff) dv = 0xFFFFFFFEu;
+            break;
+        }
+        orun = run; dv = td; cutoff = cut_of(run);                             // itree.c:1082-1085
+    }
+    const uint32_t rk = T_RANK(ed - 1);
+    int32_t cut;
+    if (dv == 0xFFFFFFFFu) cut = -1;                                           // itree.c:1087
+    else if (dv == 0xFFFFFFFEu) cut = -2;
+    else { uint32_t Ls = loff[rk + 1] - loff[rk] - 1; cut = (int32_t)(dv < Ls ? dv : Ls); }   // 1088
+    store_result(&out[r], im.rank2ix[rk], cut, F, uix, sl, ol);
+#undef T_RANK
+#undef T_CNT
+}
+
+template <int W, int I, bool EXC, typename OFF>
+__global__ void lookup_k(utk_image im, const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n,
+                         uint32_t *__restrict__ ix) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t rank = lookup_word<W, I, EXC, OFF>(im, W == 16 ? hi[i] : 0ull, lo[i]);
+        ix[i] = rank == INVALID ? INVALID : im.rank2ix[rank];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch on (W, I, EXC, OFF64)
+// ------------------------------------------------------------------------------------------------
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <typename Fn> int dispatch_wi(uint32_t W, uint32_t I, Fn &&fn) {
+    if (W == 8 && I == 2) fn(IC<8>{}, IC<2>{});
+    else if (W == 8 && I == 4) fn(IC<8>{}, IC<4>{});
+    else if (W == 16 && I == 2) fn(IC<16>{}, IC<2>{});
+    else if (W == 16 && I == 4) fn(IC<16>{}, IC<4>{});
+    else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+template <typename Fn> int dispatch_img(const utk_image *im, Fn &&fn) {
+    const bool exc = (im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC)) != 0;
+    const bool o64 = (im->flags & UTREE_F_OFF64) != 0;
+    return dispatch_wi(im->W, im->I, [&](auto w, auto i) {
+        if (exc && o64) fn(w, i, std::true_type{}, uint64_t{});
+        else if (exc) fn(w, i, std::true_type{}, uint32_t{});
+        else if (o64) fn(w, i, std::false_type{}, uint64_t{});
+        else fn(w, i, std::false_type{}, uint32_t{});
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+int utk_repack(uint32_t W_, uint32_t I_, const void *d_raw, uint64_t count, const uint32_t *d_ix2rank,
+               uint32_t n_labels, uint64_t *d_recs, void *stream) {
+    if (!count) return 0;
+    uint64_t blocks = (count + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    return dispatch_wi(W_, I_, [&](auto w, auto i) {
+        repack_k<decltype(w)::value, decltype(i)::value><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
+            (const uint8_t *)d_raw, count, d_ix2rank, n_labels, d_recs);
+    });
+}
+
+int utk_widen_binix(const void *d_raw_binix, uint32_t width, uint64_t *d_coarse, void *stream) {
+    widen_binix_k<<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(d_raw_binix, width, d_coarse);
+    return (int)hipGetLastError();
+}
+
+int utk_validate(uint32_t W_, uint32_t I_, const uint64_t *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
+                 uint32_t *d_irreg, unsigned long long *d_counters, void *stream) {
+    return dispatch_wi(W_, I_, [&](auto w, auto i) {
+        validate_k<decltype(w)::value, decltype(i)::value><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+            d_coarse, d_recs, n_nodes, d_irreg, d_counters);
+    });
+}
+
+int utk_build_fine(uint32_t W_, uint32_t I_, int off64, int generic, const uint64_t *d_coarse, const uint64_t *d_recs,
+                   uint32_t fine_bits, void *d_fine, void *stream) {
+    uint64_t nfine = (1ull << (24 + fine_bits)) + 1;
+    uint64_t blocks = (nfine + 255) / 256;
+    if (blocks > (1u << 20)) blocks = 1u << 20;
+    return dispatch_wi(W_, I_, [&](auto w, auto i) {
+        constexpr int W = decltype(w)::value, I = decltype(i)::value;
+        if (off64) build_fine_k<W, I, uint64_t><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
+            d_coarse, d_recs, fine_bits, generic, (uint64_t *)d_fine);
+        else build_fine_k<W, I, uint32_t><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
+            d_coarse, d_recs, fine_bits, generic, (uint32_t *)d_fine);
+    });
+}
+
+int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream) {
+    fill_pad_k<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(d_recs_end, words);
+    return (int)hipGetLastError();
+}
+
+int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
+                       uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+    if (!n_reads) return 0;
+    uint32_t blocks = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    uint32_t cap = (uint32_t)n_cu * 8u;
+    if (blocks > cap) blocks = cap;
+    return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
+        classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt)>
+            <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+    });
+}
+
+int utk_classify_long(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
+                      int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+    (void)n_cu;
+    if (!ws->long_blocks) return 0;
+    return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
+        classify_long_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt)>
+            <<<dim3(ws->long_blocks), dim3(LONG_THREADS), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, do_rc, d_out, *ws);
+    });
+}
+
+int utk_vote(const utk_image *im, utree_result *d_out, const utk_workspace *ws, uint32_t n_reads, void *stream) {
+    if (!n_reads) return 0;
+    vote_k<<<dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(*im, d_out, *ws);
+    return (int)hipGetLastError();
+}
+
+int utk_lookup(const utk_image *im, const uint64_t *d_hi, const uint64_t *d_lo, uint64_t n, uint32_t *d_ix, void *stream) {
+    if (!n) return 0;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
+        lookup_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt)>
+            <<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_hi, d_lo, n, d_ix);
+    });
+}
+
+const char *utk_classify_short_name(uint32_t W, uint32_t I) {
+    (void)W; (void)I;
+    return "classify_short_k";
+}
+
+}  // extern "C"

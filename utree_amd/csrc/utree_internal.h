@@ -1,0 +1,85 @@
+/* utree_internal.h -- shared between the C host files and kernels.hip (not part of the public ABI). */
+#ifndef UTREE_INTERNAL_H
+#define UTREE_INTERNAL_H
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/utree_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UTREE_NUMBINS ((1u << 24) + 1u)          /* itree.c:693 */
+#define UTREE_INVALID 0xFFFFFFFFu
+#define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
+#define UTREE_IMG_HEADER_BYTES 4096u
+#define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds */
+
+/* image flags */
+#define UTREE_F_IRREGULAR 1u   /* some bins are not strictly ascending: bitmap present, exact probe path   */
+#define UTREE_F_GENERIC   2u   /* bin table not monotone: fine_bits = 0, every lookup takes the exact path  */
+#define UTREE_F_OFF64     4u   /* fine offsets are 64-bit (n_nodes >= UINT32_MAX)                            */
+
+/* At offset 0 of the flat device image (position independent: offsets, never pointers). */
+typedef struct {
+    uint64_t magic;
+    uint32_t version, W, I, k;
+    uint32_t fine_bits, rec_words, n_labels, flags;
+    uint64_t n_nodes;
+    uint64_t n_fine;                 /* 2^(24+fine_bits) + 1 entries                                        */
+    uint64_t off_fine, off_recs, off_irreg, off_label_off, off_label_blob, off_rank2ix;
+    uint64_t label_blob_bytes;
+    uint64_t n_irregular;
+    uint64_t total_bytes;
+} utree_image_header;
+
+/* What kernels take by value. */
+typedef struct {
+    const void *fine;                /* uint32_t* or uint64_t* (UTREE_F_OFF64)                               */
+    const uint64_t *recs;
+    const uint32_t *irreg;           /* 2^24-bit bitmap                                                      */
+    const uint32_t *label_off;       /* [n_labels+1], rank order                                             */
+    const char *label_blob;          /* NUL-terminated labels in strcmp order                                */
+    const uint32_t *rank2ix;
+    uint64_t n_nodes;
+    uint32_t n_labels, fine_bits, flags, W, I;
+} utk_image;
+
+static inline uint32_t utree_rec_words(uint32_t W, uint32_t I) { return (W == 16 ? 2u : 1u) + (I == 4 ? 1u : 0u); }
+
+/* ---- launchers implemented in kernels.hip (all asynchronous on `stream`, return hipError_t as int) ---- */
+int utk_repack(uint32_t W, uint32_t I, const void *d_raw, uint64_t count, const uint32_t *d_ix2rank,
+               uint32_t n_labels, uint64_t *d_recs_at_first, void *stream);
+int utk_widen_binix(const void *d_raw_binix, uint32_t width, uint64_t *d_coarse, void *stream);
+/* counters[0] += irregular bins, counters[1] = 1 if the table is not monotone / exceeds n_nodes */
+int utk_validate(uint32_t W, uint32_t I, const uint64_t *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
+                 uint32_t *d_irreg, unsigned long long *d_counters, void *stream);
+int utk_build_fine(uint32_t W, uint32_t I, int off64, int generic, const uint64_t *d_coarse, const uint64_t *d_recs,
+                   uint32_t fine_bits, void *d_fine, void *stream);
+int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream);
+
+/* workspace layout for one batch */
+typedef struct {
+    unsigned long long *cursors;     /* [0] tally bump, [1] vote count, [2] long count (zeroed per batch)    */
+    uint64_t *tally;                 /* (rank, count) pairs packed as rank | count<<32                        */
+    uint64_t tally_cap;
+    uint32_t *vote_list;             /* [n_reads]                                                             */
+    uint32_t *long_list;             /* [n_reads]                                                             */
+    uint32_t *hist;                  /* long path: [long_blocks][n_labels]                                    */
+    uint32_t long_blocks;
+} utk_workspace;
+
+int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
+                       uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu,
+                       void *stream);
+int utk_classify_long(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
+                      int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
+int utk_vote(const utk_image *im, utree_result *d_out, const utk_workspace *ws, uint32_t n_reads, void *stream);
+int utk_lookup(const utk_image *im, const uint64_t *d_hi, const uint64_t *d_lo, uint64_t n, uint32_t *d_ix,
+               void *stream);
+const char *utk_classify_short_name(uint32_t W, uint32_t I);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
