@@ -269,6 +269,8 @@ constexpr int SHORT_CAP = UTREE_SHORT_CAP;
 constexpr int SHORT_NCH = SHORT_CAP / 64;
 constexpr int SHORT_WORDS = SHORT_CAP / 16 + 6;
 constexpr int WAVES_PER_BLOCK = 4;
+constexpr uint32_t TALLY_CHUNK = UTREE_TALLY_CHUNK;
+constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read waits for vote_k
 
 template <int W, int I, bool EXC, typename OFF>
 __global__ __launch_bounds__(256) void classify_short_k(utk_image im, const uint8_t *__restrict__ bases,
@@ -286,13 +288,15 @@ __global__ __launch_bounds__(256) void classify_short_k(utk_image im, const uint
     uint64_t *sbad = s_bad[wv];
     uint32_t *hits = s_hits[wv];
     const uint32_t wave_gid = blockIdx.x * WAVES_PER_BLOCK + wv, n_waves = gridDim.x * WAVES_PER_BLOCK;
+    unsigned long long chunk_base = 0;
+    uint32_t chunk_left = 0;
 
     for (uint32_t r = wave_gid; r < n_reads; r += n_waves) {
         const uint32_t L = len[r];
         const uint64_t o = off[r];
         const uint32_t total = do_rc ? 2 * L + 1 : L;
         if (total > SHORT_CAP) {                           // handed to classify_long
-            if (lane == 0) ws.long_list[atomicAdd(&ws.cursors[2], 1ull)] = r;
+            if (lane == 0) ws.long_list[atomicAdd(&ws.cursors[UTREE_CUR_LONG], 1ull)] = r;
             continue;
         }
         if (total < K) {                                   // no window: no hit, no output line
@@ -342,9 +346,16 @@ __global__ __launch_bounds__(256) void classify_short_k(utk_image im, const uint
         mn = wave_min_u32(mn);
         mx = ~wave_min_u32(~mx);
         if (mn == mx) { if (lane == 0) store_result(&out[r], im.rank2ix[h0], -2, F, 1, 0, 0); continue; }
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&ws.cursors[0], (unsigned long long)F);
-        base = __shfl(base, 0);
+        // (rank,count) list space: every wave sub-allocates from chunks it reserves with ONE atomic per
+        // TALLY_CHUNK entries (a per-read atomic on one address serialises the whole chip)
+        if (F > chunk_left) {
+            unsigned long long nb = 0;
+            const uint32_t need = F > TALLY_CHUNK ? F : TALLY_CHUNK;
+            if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)need);
+            chunk_base = __shfl(nb, 0);
+            chunk_left = need;
+        }
+        const unsigned long long base = chunk_base;
         uint32_t uix = 0, cur = mn;
         for (;;) {
             uint32_t c = 0, nxt = INVALID;
@@ -360,11 +371,9 @@ __global__ __launch_bounds__(256) void classify_short_k(utk_image im, const uint
             if (nxt == INVALID) break;
             cur = nxt;
         }
-        if (lane == 0) {
-            // vote_k finishes this read: label/cut are placeholders, sl/ol carry the tally offset
-            store_result(&out[r], im.rank2ix[h0], -2, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
-            ws.vote_list[atomicAdd(&ws.cursors[1], 1ull)] = r;
-        }
+        chunk_base += uix; chunk_left -= uix;
+        // vote_k finishes this read: cut = CUT_PENDING marks it, sl/ol carry the tally offset
+        if (lane == 0) store_result(&out[r], im.rank2ix[h0], CUT_PENDING, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
     }
 }
 
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     uint8_t *sb = (uint8_t *)s_words;
     uint32_t *hist = ws.hist + (size_t)blockIdx.x * im.n_labels;     // all zero between reads
-    const uint32_t n_long = (uint32_t)ws.cursors[2];
+    const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
 
     for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) {
         const uint32_t r = ws.long_list[li];
@@ -471,10 +480,7 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
         __syncthreads();
         if (tid == 0) {
             if (uix == 1) store_result(&out[r], im.rank2ix[s_first], -2, F, 1, 0, 0);
-            else {
-                store_result(&out[r], 0, -2, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
-                ws.vote_list[atomicAdd(&ws.cursors[1], 1ull)] = r;
-            }
+            else store_result(&out[r], 0, CUT_PENDING, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
         }
         __syncthreads();
     }
@@ -491,12 +497,11 @@ __device__ __forceinline__ uint32_t cut_of(uint32_t x) {          // itree.c:104
     return c;
 }
 
-__global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__restrict__ out, utk_workspace ws) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n = (uint32_t)ws.cursors[1];
-    if (t >= n) return;
-    const uint32_t r = ws.vote_list[t];
+__global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__restrict__ out, utk_workspace ws, uint32_t n_reads) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
     const uint32_t *res = (const uint32_t *)&out[r];
+    if ((int32_t)res[1] != CUT_PENDING) return;            // finished by the classify kernel (0 or 1 distinct label)
     const uint32_t F = res[2], uix = res[3];
     const uint64_t *T = ws.tally + ((uint64_t)res[4] | ((uint64_t)res[5] << 32));
     const char *blob = im.label_blob;
@@ -651,7 +656,7 @@ int utk_classify_long(const utk_image *im, const uint8_t *d_bases, const uint64_
 
 int utk_vote(const utk_image *im, utree_result *d_out, const utk_workspace *ws, uint32_t n_reads, void *stream) {
     if (!n_reads) return 0;
-    vote_k<<<dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(*im, d_out, *ws);
+    vote_k<<<dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(*im, d_out, *ws, n_reads);
     return (int)hipGetLastError();
 }
 

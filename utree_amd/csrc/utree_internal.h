@@ -13,6 +13,8 @@ extern "C" {
 #define UTREE_INVALID 0xFFFFFFFFu
 #define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
 #define UTREE_IMG_HEADER_BYTES 4096u
+#define UTREE_TALLY_CHUNK 4096u                  /* tally entries a wave reserves with one atomic              */
+#define UTREE_CUR_LONG 32                        /* cursors[] index of the long-read counter (own 256-B line)   */
 #define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds */
 
 /* image flags */
@@ -60,10 +62,9 @@ int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream);
 
 /* workspace layout for one batch */
 typedef struct {
-    unsigned long long *cursors;     /* [0] tally bump, [1] vote count, [2] long count (zeroed per batch)    */
+    unsigned long long *cursors;     /* [0] tally bump, [UTREE_CUR_LONG] long-read count; 512 B, zeroed per batch */
     uint64_t *tally;                 /* (rank, count) pairs packed as rank | count<<32                        */
     uint64_t tally_cap;
-    uint32_t *vote_list;             /* [n_reads]                                                             */
     uint32_t *long_list;             /* [n_reads]                                                             */
     uint32_t *hist;                  /* long path: [long_blocks][n_labels]                                    */
     uint32_t long_blocks;
