@@ -48,7 +48,7 @@ def test_golden_outputs_bit_exact(torch_cuda, name, rc):
     assert got == want
 
 
-@pytest.mark.parametrize("fine_bits", [0, 1, 3, 6, 8])
+@pytest.mark.parametrize("fine_bits", [0, 1, 3, 6])
 @pytest.mark.parametrize("name", ["toy", "k64", "ix32", "katq"])
 def test_fine_index_width_does_not_change_results(torch_cuda, name, fine_bits):
     db, tree = tree_for(name, fine_bits)

@@ -3,8 +3,8 @@
  * The image replaces UTree.Dump / UTree.BinIx (itree.c:140-141) as XT_getIX32 (itree.c:720) sees them.
  * Layout in HBM (one flat allocation, offsets only -- DESIGN.md §3):
  *
- *   [header 4 KiB][fine prefix index: 2^(24+F)+1 offsets][records: N x {suffix, rank}, 8-byte words]
- *   [irregular-bin bitmap 2 MiB][label offsets][labels in strcmp order][rank -> file index]
+ *   [header 4 KiB][direct-mapped prefix table: 2^(24+F) slots][records: N x {suffix, rank}, sorted as in the file]
+ *   [bin table 2^24+1][irregular-bin bitmap 2 MiB][label offsets][labels in strcmp order][rank -> file index]
  */
 #define _FILE_OFFSET_BITS 64
 #define _GNU_SOURCE
@@ -34,27 +34,33 @@ int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
     const char *env = getenv("UTREE_FINE_BITS");
     if (fine_bits == UTREE_FINE_AUTO && env && *env) fine_bits = atoi(env);
     if (fine_bits == UTREE_FINE_AUTO) {
-        /* smallest F with at most ~1.5 records per fine bin on average */
+        /* smallest F that leaves <= 0.35 records per table slot on average (then ~97 % of lookups end in the
+         * one line that holds their slot), within a memory cap for the table */
+        const char *cap_env = getenv("UTREE_TABLE_MAX_GB");
+        double cap = (cap_env && atof(cap_env) > 0 ? atof(cap_env) : 48.0) * 1073741824.0;
+        double slot_bytes = 8.0 * utree_rec_words(ctr->info.W, ctr->info.I);
         int F = 0;
-        while (F < 8 && (double)ctr->info.n_nodes / (double)(1ull << (24 + F)) > 1.5) ++F;
+        while (F < 12 && (double)ctr->info.n_nodes / (double)(1ull << (24 + F)) > 0.35 &&
+               (double)(1ull << (24 + F + 1)) * slot_bytes <= cap) ++F;
         return F;
     }
     if (fine_bits < 0) fine_bits = 0;
-    if (fine_bits > 8) fine_bits = 8;
+    if (fine_bits > 12) fine_bits = 12;
     return fine_bits;
 }
 
 static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     memset(h, 0, sizeof *h);
-    h->magic = UTREE_IMG_MAGIC; h->version = 1;
+    h->magic = UTREE_IMG_MAGIC; h->version = 2;
     h->W = ctr->info.W; h->I = ctr->info.I; h->k = ctr->info.k;
     h->fine_bits = F; h->rec_words = utree_rec_words(h->W, h->I);
     h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
     h->flags = ctr->info.binix_width == 8 ? UTREE_F_OFF64 : 0;
-    h->n_fine = (1ull << (24 + F)) + 1;
+    h->n_slots = 1ull << (24 + F);
     uint64_t off = UTREE_IMG_HEADER_BYTES;
-    h->off_fine = off; off = align_up(off + h->n_fine * ((h->flags & UTREE_F_OFF64) ? 8 : 4), 256);
-    h->off_recs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 256);
+    h->off_table = off; off = align_up(off + h->n_slots * h->rec_words * 8, 4096);
+    h->off_recs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 4096);
+    h->off_coarse = off; off = align_up(off + (uint64_t)UTREE_NUMBINS * ((h->flags & UTREE_F_OFF64) ? 8 : 4), 256);
     h->off_irreg = off; off = align_up(off + (1u << 24) / 8, 256);
     h->off_label_off = off; off = align_up(off + ((uint64_t)h->n_labels + 1) * 4, 256);
     uint64_t blob = 0;
@@ -74,8 +80,9 @@ size_t utree_dev_image_bytes(const utree_ctr *ctr, int fine_bits) {
 
 static void bind_image(utree_dev *d) {
     char *b = (char *)d->image;
-    d->kimg.fine = b + d->hdr.off_fine;
+    d->kimg.table = (const uint64_t *)(b + d->hdr.off_table);
     d->kimg.recs = (const uint64_t *)(b + d->hdr.off_recs);
+    d->kimg.coarse = b + d->hdr.off_coarse;
     d->kimg.irreg = (const uint32_t *)(b + d->hdr.off_irreg);
     d->kimg.label_off = (const uint32_t *)(b + d->hdr.off_label_off);
     d->kimg.label_blob = b + d->hdr.off_label_blob;
@@ -102,7 +109,6 @@ typedef struct {
     utree_dev *d;
     const utree_ctr *ctr;
     uint32_t *d_ix2rank;
-    uint64_t *d_coarse;
     unsigned long long *d_counters;
     hipStream_t stream;
 } builder;
@@ -177,35 +183,38 @@ static int build_finish(builder *b, const void *d_binix_raw) {
     hipStream_t st = b->stream;
     char *img = (char *)d->image;
     uint64_t *recs = (uint64_t *)(img + d->hdr.off_recs);
+    void *coarse = img + d->hdr.off_coarse;
+    const int off64 = (d->hdr.flags & UTREE_F_OFF64) != 0;
     unsigned long long counters[2] = {0, 0};
-    HIPCHK(hipMalloc((void **)&b->d_coarse, (size_t)UTREE_NUMBINS * 8));
     HIPCHK(hipMalloc((void **)&b->d_counters, 16));
     HIPCHK(hipMemsetAsync(b->d_counters, 0, 16, st));
     KCHK(utk_fill_recs_pad(recs + d->hdr.n_nodes * d->hdr.rec_words, 8 * d->hdr.rec_words, st));
-    KCHK(utk_widen_binix(d_binix_raw, ctr->info.binix_width, b->d_coarse, st));
-    KCHK(utk_validate(d->hdr.W, d->hdr.I, b->d_coarse, recs, d->hdr.n_nodes, (uint32_t *)(img + d->hdr.off_irreg),
+    KCHK(utk_widen_binix(d_binix_raw, ctr->info.binix_width, off64, coarse, st));
+    KCHK(utk_validate(d->hdr.W, d->hdr.I, off64, coarse, recs, d->hdr.n_nodes, (uint32_t *)(img + d->hdr.off_irreg),
                       b->d_counters, st));
     HIPCHK(hipMemcpyAsync(counters, b->d_counters, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     d->hdr.n_irregular = counters[0];
     if (counters[1]) {
         /* bin table not monotone (never written by the reference's COMPRESS): trust it verbatim like the
-         * reference does, i.e. no finer index and the exact probe sequence everywhere */
+         * reference does -- every bin takes the exact probe path over [BinIx[p], BinIx[p+1]) */
         d->hdr.flags |= UTREE_F_GENERIC;
         d->hdr.fine_bits = 0;
-        d->hdr.n_fine = (1ull << 24) + 1;
+        d->hdr.n_slots = 1ull << 24;
         HIPCHK(hipMemsetAsync(img + d->hdr.off_irreg, 0xFF, (1u << 24) / 8, st));
-    } else if (counters[0]) d->hdr.flags |= UTREE_F_IRREGULAR;
-    KCHK(utk_build_fine(d->hdr.W, d->hdr.I, (d->hdr.flags & UTREE_F_OFF64) != 0, (d->hdr.flags & UTREE_F_GENERIC) != 0,
-                        b->d_coarse, recs, d->hdr.fine_bits, img + d->hdr.off_fine, st));
+        HIPCHK(hipMemsetAsync(img + d->hdr.off_table, 0, d->hdr.n_slots * d->hdr.rec_words * 8, st));
+    } else {
+        if (counters[0]) d->hdr.flags |= UTREE_F_IRREGULAR;
+        KCHK(utk_build_table(d->hdr.W, d->hdr.I, off64, coarse, recs, d->hdr.fine_bits,
+                             (uint64_t *)(img + d->hdr.off_table), st));
+    }
     HIPCHK(hipMemcpyAsync(img, &d->hdr, sizeof d->hdr, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     bind_image(d);
 fail:
-    if (b->d_coarse) hipFree(b->d_coarse);
     if (b->d_counters) hipFree(b->d_counters);
     if (b->d_ix2rank) hipFree(b->d_ix2rank);
-    b->d_coarse = NULL; b->d_counters = NULL; b->d_ix2rank = NULL;
+    b->d_counters = NULL; b->d_ix2rank = NULL;
     if (rc) { utree_dev_free(d); b->d = NULL; }
     return rc;
 }
@@ -300,7 +309,7 @@ int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t byt
     if (!d) return UTREE_E_NOMEM;
     d->device = device; d->n_cu = n_cu; d->image = d_image; d->owns = 0;
     HIPCHK(hipMemcpy(&d->hdr, d_image, sizeof d->hdr, hipMemcpyDeviceToHost));
-    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 1 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
+    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 2 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
     if (ctr && (ctr->info.W != d->hdr.W || ctr->info.I != d->hdr.I || ctr->info.n_nodes != d->hdr.n_nodes ||
                 ctr->info.n_labels != d->hdr.n_labels)) { rc = UTREE_E_ARG; goto fail; }
     d->image_bytes = d->hdr.total_bytes;

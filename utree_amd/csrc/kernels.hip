@@ -22,9 +22,17 @@ constexpr uint64_t M40 = (1ull << 40) - 1;
 constexpr uint32_t INVALID = 0xFFFFFFFFu;
 
 // ------------------------------------------------------------------------------------------------
-// keys and records
+// keys, records, table entries
 // ------------------------------------------------------------------------------------------------
-template <int W> struct Key { uint64_t hi, lo; };   // hi is the top 40 suffix bits for W=16, else 0
+// One format serves both the sorted record array and the direct-mapped prefix table.
+// EW 8-byte words per record (a power of two, so an entry never straddles a 128-B line):
+//   W=8, I=2 (EW 1): {flag8 | rank16 | suffix40}
+//   W=8, I=4 (EW 2): {flag8 | 0 | suffix40} {rank32}
+//   W=16,I=2 (EW 2): {suffix lo64} {flag8 | rank16 | suffix hi40}
+//   W=16,I=4 (EW 4): {suffix lo64} {flag8 | 0 | suffix hi40} {rank32} {0}
+// flag (top byte of the word holding the top suffix bits): 0 = a record, 1 = empty table slot,
+// 2 = table slot that points at a run of >= 2 records: {2 | count16 | start40}.
+template <int W> struct Key { uint64_t hi, lo; };   // hi = top 40 suffix bits for W=16, else 0
 
 template <int W> __device__ __forceinline__ bool key_eq(const Key<W> &a, const Key<W> &b) {
     if constexpr (W == 16) return a.lo == b.lo && a.hi == b.hi; else return a.lo == b.lo;
@@ -34,37 +42,51 @@ template <int W> __device__ __forceinline__ bool key_lt(const Key<W> &a, const K
 }
 template <int W> __device__ __forceinline__ bool key_le(const Key<W> &a, const Key<W> &b) { return !key_lt<W>(b, a); }
 
-template <int W, int I> struct RecTraits { static constexpr int RW = (W == 16 ? 2 : 1) + (I == 4 ? 1 : 0); };
+template <int W, int I> struct RecTraits {
+    static constexpr int EW = (W == 16 ? 2 : 1) * (I == 4 ? 2 : 1);
+    static constexpr int KW = (W == 16 ? 1 : 0);            // word with the top suffix bits and the flag
+};
+constexpr uint64_t FLAG_EMPTY = 1ull << 56, FLAG_RUN = 2ull << 56;
 
-// In-HBM record:  W=8,I=2: {suf40 | rank16<<40}          W=8,I=4: {suf40}{rank32}
-//                                 W=16,I=2: {lo64}{hi40 | rank16<<40}    W=16,I=4: {lo64}{hi40}{rank32}
-template <int W, int I> __device__ __forceinline__ Key<W> load_key(const uint64_t *recs, uint64_t i) {
-    const uint64_t *p = recs + i * RecTraits<W, I>::RW;
+template <int W, int I> struct Entry { uint64_t w[RecTraits<W, I>::EW]; };
+
+template <int W, int I> __device__ __forceinline__ Entry<W, I> load_entry(const uint64_t *base, uint64_t i) {
+    constexpr int EW = RecTraits<W, I>::EW;
+    Entry<W, I> e;
+    if constexpr (EW == 1) e.w[0] = base[i];
+    else if constexpr (EW == 2) {
+        const ulonglong2 v = *(const ulonglong2 *)(base + i * 2);
+        e.w[0] = v.x; e.w[1] = v.y;
+    } else {
+        const ulonglong2 v0 = *(const ulonglong2 *)(base + i * 4), v1 = *(const ulonglong2 *)(base + i * 4 + 2);
+        e.w[0] = v0.x; e.w[1] = v0.y; e.w[2] = v1.x; e.w[3] = v1.y;
+    }
+    return e;
+}
+template <int W, int I> __device__ __forceinline__ Key<W> entry_key(const Entry<W, I> &e) {
     Key<W> k;
-    if constexpr (W == 16) { k.lo = p[0]; k.hi = p[1] & M40; }
-    else { k.lo = p[0] & M40; k.hi = 0; }
+    if constexpr (W == 16) { k.lo = e.w[0]; k.hi = e.w[1] & M40; } else { k.lo = e.w[0] & M40; k.hi = 0; }
     return k;
 }
-template <int W, int I> __device__ __forceinline__ uint32_t load_rank(const uint64_t *recs, uint64_t i) {
-    const uint64_t *p = recs + i * RecTraits<W, I>::RW;
-    if constexpr (I == 4) return (uint32_t)p[RecTraits<W, I>::RW - 1];
+template <int W, int I> __device__ __forceinline__ uint32_t entry_rank(const Entry<W, I> &e) {
+    if constexpr (I == 4) return (uint32_t)e.w[RecTraits<W, I>::KW + 1];
     else {
-        uint32_t r = (uint32_t)(p[RecTraits<W, I>::RW - 1] >> 40) & 0xFFFFu;
+        uint32_t r = (uint32_t)(e.w[RecTraits<W, I>::KW] >> 40) & 0xFFFFu;
         return r == 0xFFFFu ? INVALID : r;
     }
 }
-// key and rank of one record with the loads shared where they sit in the same word
-template <int W, int I> __device__ __forceinline__ void load_rec(const uint64_t *recs, uint64_t i, Key<W> &k, uint32_t &rank) {
-    if constexpr (I == 2) {
-        const uint64_t *p = recs + i * RecTraits<W, I>::RW;
-        uint64_t last = p[RecTraits<W, I>::RW - 1];
-        if constexpr (W == 16) { k.lo = p[0]; k.hi = last & M40; } else { k.lo = last & M40; k.hi = 0; }
-        uint32_t r = (uint32_t)(last >> 40) & 0xFFFFu;
-        rank = r == 0xFFFFu ? INVALID : r;
-    } else {
-        k = load_key<W, I>(recs, i);
-        rank = load_rank<W, I>(recs, i);
-    }
+template <int W, int I> __device__ __forceinline__ uint32_t entry_flag(const Entry<W, I> &e) {
+    return (uint32_t)(e.w[RecTraits<W, I>::KW] >> 56);
+}
+template <int W, int I> __device__ __forceinline__ Key<W> load_key(const uint64_t *recs, uint64_t i) {
+    constexpr int EW = RecTraits<W, I>::EW;
+    Key<W> k;
+    if constexpr (W == 16) { const ulonglong2 v = *(const ulonglong2 *)(recs + i * EW); k.lo = v.x; k.hi = v.y & M40; }
+    else { k.lo = recs[i * EW] & M40; k.hi = 0; }
+    return k;
+}
+template <int W, int I> __device__ __forceinline__ uint32_t load_rank(const uint64_t *recs, uint64_t i) {
+    return entry_rank<W, I>(load_entry<W, I>(recs, i));
 }
 
 // The reference's probe sequence, verbatim in behaviour (itree.c:699-707, 728): p = first record of the
@@ -81,44 +103,67 @@ template <int W, int I> __device__ uint32_t exact_probe(const uint64_t *recs, ui
     return key_eq<W>(k, q) ? load_rank<W, I>(recs, p) : INVALID;
 }
 
-// XT_getIX32 (itree.c:720-730) on the device image.  khi:klo is the 2k-bit word.
-template <int W, int I, bool EXC, typename OFF>
-__device__ __forceinline__ uint32_t lookup_word(const utk_image &im, uint64_t khi, uint64_t klo) {
-    const OFF *fine = (const OFF *)im.fine;
-    const uint32_t F = im.fine_bits;
-    uint64_t top = (W == 16) ? khi : klo;         // the 64 bits holding prefix (24) + first 40 suffix bits
-    uint32_t p = (uint32_t)(top >> 40);           // itree.c:684 PREFIX_L
-    Key<W> q;
-    if constexpr (W == 16) { q.hi = khi & M40; q.lo = klo; } else { q.hi = 0; q.lo = klo & M40; }
-    uint64_t fq = top >> (40 - F);                // 24+F-bit fine prefix
-    uint64_t fs = fine[fq], fe = fine[fq + 1];
-    if constexpr (EXC) {
-        if ((im.irreg[p >> 5] >> (p & 31)) & 1u) {
-            uint64_t s = fine[(uint64_t)p << F], e = fine[((uint64_t)p + 1) << F];   // itree.c:724
-            if (s >= e || e > im.n_nodes) return INVALID;                          // itree.c:726
-            return exact_probe<W, I>(im.recs, s, e, q);
-        }
-    }
-    if (fs >= fe) return INVALID;
-    // the fine bin is strictly ascending: any exact-match search equals the reference's result
-    Key<W> k0, k1;
-    uint32_t r0, r1;
-    load_rec<W, I>(im.recs, fs, k0, r0);
-    load_rec<W, I>(im.recs, fs + 1, k1, r1);      // the record array is padded: always readable
-    if (key_eq<W>(k0, q)) return r0;
-    uint64_t n = fe - fs;
-    if (n == 1 || key_lt<W>(q, k0)) return INVALID;
-    if (key_eq<W>(k1, q)) return r1;
-    if (n == 2 || key_lt<W>(q, k1)) return INVALID;
-    uint64_t lo = fs + 2, hi = fe;
+// exact-match search in a strictly ascending run [lo, hi): equals the reference's result there
+template <int W, int I> __device__ uint32_t sorted_find(const uint64_t *recs, uint64_t lo, uint64_t hi, const Key<W> &q) {
     while (lo < hi) {
         uint64_t mid = lo + ((hi - lo) >> 1);
-        Key<W> k = load_key<W, I>(im.recs, mid);
+        Key<W> k = load_key<W, I>(recs, mid);
         if (key_lt<W>(k, q)) lo = mid + 1;
-        else if (key_eq<W>(k, q)) return load_rank<W, I>(im.recs, mid);
+        else if (key_eq<W>(k, q)) return load_rank<W, I>(recs, mid);
         else hi = mid;
     }
     return INVALID;
+}
+
+template <typename OFF> __device__ __forceinline__ void coarse_bin(const utk_image &im, uint32_t p, uint64_t &s, uint64_t &e) {
+    const OFF *c = (const OFF *)im.coarse;
+    s = c[p]; e = c[p + 1];                                      // itree.c:724
+}
+
+// Second half of a lookup, given the table entry of the word's (24+F)-bit prefix.
+template <int W, int I, bool EXC, typename OFF>
+__device__ __forceinline__ uint32_t resolve_entry(const utk_image &im, const Entry<W, I> &t, uint32_t p, const Key<W> &q) {
+    if constexpr (EXC) {
+        if ((im.irreg[p >> 5] >> (p & 31)) & 1u) {               // bin not strictly ascending (or generic mode)
+            uint64_t s, e;
+            coarse_bin<OFF>(im, p, s, e);
+            if (s >= e || e > im.n_nodes) return INVALID;        // itree.c:726
+            return exact_probe<W, I>(im.recs, s, e, q);
+        }
+    }
+    const uint32_t flag = entry_flag<W, I>(t);
+    if (flag == 0) return key_eq<W>(entry_key<W, I>(t), q) ? entry_rank<W, I>(t) : INVALID;   // the bin's only record
+    if (flag == 1) return INVALID;                                                            // empty fine bin
+    // a run of >= 2 records in the sorted array
+    const uint64_t d = t.w[RecTraits<W, I>::KW];
+    uint64_t start = d & M40, cnt = (d >> 40) & 0xFFFFu, end = start + cnt;
+    if (cnt == 0xFFFFu) { uint64_t s; coarse_bin<OFF>(im, p, s, end); if (start < s) start = s; }   // saturated: search to the bin end
+    const Entry<W, I> r0 = load_entry<W, I>(im.recs, start), r1 = load_entry<W, I>(im.recs, start + 1);
+    const Key<W> k0 = entry_key<W, I>(r0), k1 = entry_key<W, I>(r1);
+    if (key_eq<W>(k0, q)) return entry_rank<W, I>(r0);
+    if (key_lt<W>(q, k0)) return INVALID;
+    if (key_eq<W>(k1, q)) return entry_rank<W, I>(r1);
+    if (end - start == 2 || key_lt<W>(q, k1)) return INVALID;
+    return sorted_find<W, I>(im.recs, start + 2, end, q);
+}
+
+// split of the 2k-bit word khi:klo into 24-bit prefix (itree.c:684), suffix key and table slot
+template <int W> __device__ __forceinline__ void split_word(const utk_image &im, uint64_t khi, uint64_t klo, uint32_t &p,
+                                                            Key<W> &q, uint64_t &slot) {
+    const uint64_t top = (W == 16) ? khi : klo;           // the 64 bits holding prefix (24) + first 40 suffix bits
+    p = (uint32_t)(top >> 40);
+    if constexpr (W == 16) { q.hi = khi & M40; q.lo = klo; } else { q.hi = 0; q.lo = klo & M40; }
+    slot = top >> (40 - im.fine_bits);
+}
+
+// XT_getIX32 (itree.c:720-730) on the device image: ONE 128-B line for all but the few percent of words
+// whose fine bin holds two or more records.
+template <int W, int I, bool EXC, typename OFF>
+__device__ __forceinline__ uint32_t lookup_word(const utk_image &im, uint64_t khi, uint64_t klo) {
+    uint32_t p; Key<W> q; uint64_t slot;
+    split_word<W>(im, khi, klo, p, q, slot);
+    const Entry<W, I> t = load_entry<W, I>(im.table, slot);
+    return resolve_entry<W, I, EXC, OFF>(im, t, p, q);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -127,7 +172,7 @@ __device__ __forceinline__ uint32_t lookup_word(const utk_image &im, uint64_t kh
 template <int W, int I>
 __global__ void repack_k(const uint8_t *__restrict__ raw, uint64_t count, const uint32_t *__restrict__ ix2rank,
                          uint32_t n_labels, uint64_t *__restrict__ recs) {
-    constexpr int SZ = W + I - 3, SB = W - 3, RW = RecTraits<W, I>::RW;
+    constexpr int SZ = W + I - 3, SB = W - 3, EW = RecTraits<W, I>::EW;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint8_t *p = raw + i * SZ;
         uint64_t lo = 0, hi = 0;
@@ -139,24 +184,24 @@ __global__ void repack_k(const uint8_t *__restrict__ raw, uint64_t count, const 
 #pragma unroll
         for (int b = 0; b < I; ++b) ix |= (uint32_t)p[SB + b] << (8 * b);
         uint32_t rank = ix < n_labels ? ix2rank[ix] : INVALID;      // itree.c:929 `ix < maxIX`
-        uint64_t *o = recs + i * RW;
-        if constexpr (I == 2) {
-            uint64_t r16 = rank == INVALID ? 0xFFFFull : (uint64_t)rank;
-            if constexpr (W == 16) { o[0] = lo; o[1] = hi | (r16 << 40); } else { o[0] = lo | (r16 << 40); }
-        } else {
-            if constexpr (W == 16) { o[0] = lo; o[1] = hi; o[2] = rank; } else { o[0] = lo; o[1] = rank; }
-        }
+        uint64_t *o = recs + i * EW;
+        const uint64_t r16 = rank == INVALID ? 0xFFFFull : (uint64_t)rank;
+        if constexpr (W == 8 && I == 2) { o[0] = lo | (r16 << 40); }
+        else if constexpr (W == 8 && I == 4) { o[0] = lo; o[1] = rank; }
+        else if constexpr (W == 16 && I == 2) { o[0] = lo; o[1] = hi | (r16 << 40); }
+        else { o[0] = lo; o[1] = hi; o[2] = rank; o[3] = 0; }
     }
 }
 
-__global__ void widen_binix_k(const void *raw, uint32_t width, uint64_t *coarse) {
+// bin table: on-disk width -> the image's OFF width (zero-extended, itree.c:756-759)
+template <typename OFF> __global__ void widen_binix_k(const void *raw, uint32_t width, OFF *coarse) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= UTREE_NUMBINS) return;
-    coarse[i] = width == 4 ? (uint64_t)((const uint32_t *)raw)[i] : ((const uint64_t *)raw)[i];
+    coarse[i] = (OFF)(width == 4 ? (uint64_t)((const uint32_t *)raw)[i] : ((const uint64_t *)raw)[i]);
 }
 
-template <int W, int I>
-__global__ void validate_k(const uint64_t *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t n_nodes,
+template <int W, int I, typename OFF>
+__global__ void validate_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t n_nodes,
                            uint32_t *irreg, unsigned long long *counters) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= UTREE_NUMBINS - 1) return;
@@ -175,23 +220,42 @@ __global__ void validate_k(const uint64_t *__restrict__ coarse, const uint64_t *
     }
 }
 
+// Direct-mapped table over (24+F)-bit prefixes: slot q describes the records of 24-bit bin q>>F whose next
+// F suffix bits equal q & (2^F-1): none, exactly one (stored inline) or a run in the sorted array.
 template <int W, int I, typename OFF>
-__global__ void build_fine_k(const uint64_t *__restrict__ coarse, const uint64_t *__restrict__ recs, uint32_t F,
-                             int generic, OFF *__restrict__ fine) {
-    uint64_t nfine = (1ull << (24 + F)) + 1;
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nfine; q += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t p = q >> F, f = q & ((1ull << F) - 1);
-        uint64_t s = coarse[p];
-        if (p == UTREE_NUMBINS - 1 || f == 0 || generic) { fine[q] = (OFF)s; continue; }
-        uint64_t e = coarse[p + 1];
-        Key<W> t;
-        if constexpr (W == 16) { t.hi = f << (40 - F); t.lo = 0; } else { t.hi = 0; t.lo = f << (40 - F); }
-        uint64_t lo = s, hi = e;                       // first record with key >= t
-        while (lo < hi) {
-            uint64_t mid = lo + ((hi - lo) >> 1);
-            if (key_lt<W>(load_key<W, I>(recs, mid), t)) lo = mid + 1; else hi = mid;
-        }
-        fine[q] = (OFF)lo;
+__global__ void build_table_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint32_t F,
+                              uint64_t *__restrict__ table) {
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+    const uint64_t nslots = 1ull << (24 + F);
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nslots; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = q >> F, f = q & ((1ull << F) - 1);
+        const uint64_t s = coarse[p], e = coarse[p + 1];
+        uint64_t fs = s, fe = e;
+        if (s < e) {
+            // first record with (suffix >> (SUF-F)) >= f, and >= f+1
+            auto lower = [&](uint64_t ff) {
+                if (ff >> F) return e;
+                Key<W> t;
+                if constexpr (W == 16) { t.hi = ff << (40 - F); t.lo = 0; } else { t.hi = 0; t.lo = ff << (40 - F); }
+                uint64_t lo = s, hi = e;
+                while (lo < hi) {
+                    uint64_t mid = lo + ((hi - lo) >> 1);
+                    if (key_lt<W>(load_key<W, I>(recs, mid), t)) lo = mid + 1; else hi = mid;
+                }
+                return lo;
+            };
+            fs = f ? lower(f) : s;
+            fe = lower(f + 1);
+        } else fe = fs;
+        uint64_t *o = table + q * EW;
+        const uint64_t n = fe > fs ? fe - fs : 0;
+#pragma unroll
+        for (int j = 0; j < EW; ++j) o[j] = 0;
+        if (n == 0) o[KW] = FLAG_EMPTY;
+        else if (n == 1) {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) o[j] = recs[fs * EW + j];       // flag byte of a record is 0
+        } else o[KW] = FLAG_RUN | ((n < 0xFFFFu ? n : 0xFFFFull) << 40) | (fs & M40);
     }
 }
 
@@ -306,34 +370,59 @@ __global__ __launch_bounds__(256) void classify_short_k(utk_image im, const uint
         const uint32_t nwin = total - K + 1;
         const uint32_t nch = (total + 63) >> 6;
         // ---- stage: bytes -> 2-bit codes packed big-endian in LDS, bad-base ballots ----
-        for (uint32_t c = 0; c < nch; ++c) {
-            uint32_t code; bool bad;
-            staged_base(bases, o, L, total, c * 64 + lane, code, bad);
-            uint64_t bm = __ballot(bad);
-            uint32_t t = (code << 2) | (uint32_t)__shfl_down((int)code, 1);
-            uint32_t u = (t << 4) | (uint32_t)__shfl_down((int)t, 2);
-            if ((lane & 3u) == 0) sb[(c * 16 + (lane >> 2)) ^ 3u] = (uint8_t)u;
-            if (lane == 0) sbad[c] = bm;
+        // all byte loads of the read are issued before the first one is consumed
+        uint32_t raw[SHORT_NCH];
+#pragma unroll
+        for (int c = 0; c < SHORT_NCH; ++c) {
+            const uint32_t j = c * 64 + lane;
+            raw[c] = 0;
+            if (j < L) raw[c] = bases[o + j];
+            else if (j > L && j < total) raw[c] = 0x100u | bases[o + (2 * L - j)];      // reverse strand: complement
+        }
+#pragma unroll
+        for (int c = 0; c < SHORT_NCH; ++c) {
+            if ((uint32_t)c < nch) {
+                uint32_t code; bool bad;
+                base_code(raw[c] & 0xFFu, code, bad);
+                code ^= (raw[c] >> 8) * 3u;
+                uint64_t bm = __ballot(bad);
+                uint32_t t = (code << 2) | (uint32_t)__shfl_down((int)code, 1);
+                uint32_t u = (t << 4) | (uint32_t)__shfl_down((int)t, 2);
+                if ((lane & 3u) == 0) sb[(c * 16 + (lane >> 2)) ^ 3u] = (uint8_t)u;
+                if (lane == 0) sbad[c] = bm;
+            }
         }
         if (lane == 0) sbad[nch] = ~0ull;
         wave_lds_fence();
-        // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933) ----
+        // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933); two rounds of table loads in flight ----
         uint32_t F = 0;
-        for (uint32_t it = 0; it * 64 < nwin; ++it) {
-            const uint32_t i = it * 64 + lane;
-            uint64_t b0 = sbad[it], b1 = sbad[it + 1];
-            uint64_t x = (b0 >> lane) | (lane ? (b1 << (64 - lane)) : 0ull);     // bad flags of bases i..i+63
-            bool ok = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
-            uint32_t rank = INVALID;
-            if (ok) {
-                uint64_t khi, klo;
-                window_word<W>(sw, i, khi, klo);
-                rank = lookup_word<W, I, EXC, OFF>(im, khi, klo);
+        for (uint32_t it = 0; it * 64 < nwin; it += 2) {
+            bool ok[2]; uint32_t p[2]; Key<W> q[2]; uint64_t slot[2]; Entry<W, I> t[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t i = (it + h) * 64 + lane;
+                ok[h] = false;
+                if ((it + h) * 64 < nwin) {
+                    uint64_t b0 = sbad[it + h], b1 = sbad[it + h + 1];
+                    uint64_t x = (b0 >> lane) | (lane ? (b1 << (64 - lane)) : 0ull);     // bad flags of bases i..i+63
+                    ok[h] = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
+                }
+                if (ok[h]) {
+                    uint64_t khi, klo;
+                    window_word<W>(sw, i, khi, klo);
+                    split_word<W>(im, khi, klo, p[h], q[h], slot[h]);
+                    t[h] = load_entry<W, I>(im.table, slot[h]);
+                }
             }
-            bool hit = rank != INVALID;                     // itree.c:929-931
-            uint64_t hm = __ballot(hit);
-            if (hit) hits[F + lanes_below(hm)] = rank;
-            F += (uint32_t)__popcll(hm);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t rank = INVALID;
+                if (ok[h]) rank = resolve_entry<W, I, EXC, OFF>(im, t[h], p[h], q[h]);
+                bool hit = rank != INVALID;                     // itree.c:929-931
+                uint64_t hm = __ballot(hit);
+                if (hit) hits[F + lanes_below(hm)] = rank;
+                F += (uint32_t)__popcll(hm);
+            }
         }
         wave_lds_fence();
         // ---- tally (itree.c:1028-1040): unique labels with counts, ascending rank = strcmp order ----
@@ -600,30 +689,34 @@ int utk_repack(uint32_t W_, uint32_t I_, const void *d_raw, uint64_t count, cons
     });
 }
 
-int utk_widen_binix(const void *d_raw_binix, uint32_t width, uint64_t *d_coarse, void *stream) {
-    widen_binix_k<<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(d_raw_binix, width, d_coarse);
+int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_coarse, void *stream) {
+    if (off64) widen_binix_k<uint64_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(d_raw_binix, width, (uint64_t *)d_coarse);
+    else widen_binix_k<uint32_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(d_raw_binix, width, (uint32_t *)d_coarse);
     return (int)hipGetLastError();
 }
 
-int utk_validate(uint32_t W_, uint32_t I_, const uint64_t *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
+int utk_validate(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
                  uint32_t *d_irreg, unsigned long long *d_counters, void *stream) {
     return dispatch_wi(W_, I_, [&](auto w, auto i) {
-        validate_k<decltype(w)::value, decltype(i)::value><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
-            d_coarse, d_recs, n_nodes, d_irreg, d_counters);
+        constexpr int W = decltype(w)::value, I = decltype(i)::value;
+        if (off64) validate_k<W, I, uint64_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+            (const uint64_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
+        else validate_k<W, I, uint32_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+            (const uint32_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
     });
 }
 
-int utk_build_fine(uint32_t W_, uint32_t I_, int off64, int generic, const uint64_t *d_coarse, const uint64_t *d_recs,
-                   uint32_t fine_bits, void *d_fine, void *stream) {
-    uint64_t nfine = (1ull << (24 + fine_bits)) + 1;
-    uint64_t blocks = (nfine + 255) / 256;
+int utk_build_table(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs,
+                    uint32_t fine_bits, uint64_t *d_table, void *stream) {
+    uint64_t nslots = 1ull << (24 + fine_bits);
+    uint64_t blocks = (nslots + 255) / 256;
     if (blocks > (1u << 20)) blocks = 1u << 20;
     return dispatch_wi(W_, I_, [&](auto w, auto i) {
         constexpr int W = decltype(w)::value, I = decltype(i)::value;
-        if (off64) build_fine_k<W, I, uint64_t><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
-            d_coarse, d_recs, fine_bits, generic, (uint64_t *)d_fine);
-        else build_fine_k<W, I, uint32_t><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
-            d_coarse, d_recs, fine_bits, generic, (uint32_t *)d_fine);
+        if (off64) build_table_k<W, I, uint64_t><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
+            (const uint64_t *)d_coarse, d_recs, fine_bits, d_table);
+        else build_table_k<W, I, uint32_t><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
+            (const uint32_t *)d_coarse, d_recs, fine_bits, d_table);
     });
 }
 

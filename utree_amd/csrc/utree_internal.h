@@ -20,7 +20,7 @@ extern "C" {
 /* image flags */
 #define UTREE_F_IRREGULAR 1u   /* some bins are not strictly ascending: bitmap present, exact probe path   */
 #define UTREE_F_GENERIC   2u   /* bin table not monotone: fine_bits = 0, every lookup takes the exact path  */
-#define UTREE_F_OFF64     4u   /* fine offsets are 64-bit (n_nodes >= UINT32_MAX)                            */
+#define UTREE_F_OFF64     4u   /* bin-table offsets are 64-bit (n_nodes >= UINT32_MAX)                       */
 
 /* At offset 0 of the flat device image (position independent: offsets, never pointers). */
 typedef struct {
@@ -28,8 +28,8 @@ typedef struct {
     uint32_t version, W, I, k;
     uint32_t fine_bits, rec_words, n_labels, flags;
     uint64_t n_nodes;
-    uint64_t n_fine;                 /* 2^(24+fine_bits) + 1 entries                                        */
-    uint64_t off_fine, off_recs, off_irreg, off_label_off, off_label_blob, off_rank2ix;
+    uint64_t n_slots;                /* 2^(24+fine_bits) table slots                                        */
+    uint64_t off_table, off_recs, off_coarse, off_irreg, off_label_off, off_label_blob, off_rank2ix;
     uint64_t label_blob_bytes;
     uint64_t n_irregular;
     uint64_t total_bytes;
@@ -37,8 +37,9 @@ typedef struct {
 
 /* What kernels take by value. */
 typedef struct {
-    const void *fine;                /* uint32_t* or uint64_t* (UTREE_F_OFF64)                               */
-    const uint64_t *recs;
+    const uint64_t *table;           /* direct-mapped prefix table, rec_words words per slot                 */
+    const uint64_t *recs;            /* all records, sorted as in the file, rec_words words each             */
+    const void *coarse;              /* the file's bin table: uint32_t* or uint64_t* (UTREE_F_OFF64)         */
     const uint32_t *irreg;           /* 2^24-bit bitmap                                                      */
     const uint32_t *label_off;       /* [n_labels+1], rank order                                             */
     const char *label_blob;          /* NUL-terminated labels in strcmp order                                */
@@ -47,17 +48,17 @@ typedef struct {
     uint32_t n_labels, fine_bits, flags, W, I;
 } utk_image;
 
-static inline uint32_t utree_rec_words(uint32_t W, uint32_t I) { return (W == 16 ? 2u : 1u) + (I == 4 ? 1u : 0u); }
+static inline uint32_t utree_rec_words(uint32_t W, uint32_t I) { return (W == 16 ? 2u : 1u) * (I == 4 ? 2u : 1u); }
 
 /* ---- launchers implemented in kernels.hip (all asynchronous on `stream`, return hipError_t as int) ---- */
 int utk_repack(uint32_t W, uint32_t I, const void *d_raw, uint64_t count, const uint32_t *d_ix2rank,
                uint32_t n_labels, uint64_t *d_recs_at_first, void *stream);
-int utk_widen_binix(const void *d_raw_binix, uint32_t width, uint64_t *d_coarse, void *stream);
+int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_coarse, void *stream);
 /* counters[0] += irregular bins, counters[1] = 1 if the table is not monotone / exceeds n_nodes */
-int utk_validate(uint32_t W, uint32_t I, const uint64_t *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
+int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
                  uint32_t *d_irreg, unsigned long long *d_counters, void *stream);
-int utk_build_fine(uint32_t W, uint32_t I, int off64, int generic, const uint64_t *d_coarse, const uint64_t *d_recs,
-                   uint32_t fine_bits, void *d_fine, void *stream);
+int utk_build_table(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs,
+                    uint32_t fine_bits, uint64_t *d_table, void *stream);
 int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream);
 
 /* workspace layout for one batch */
