@@ -55,11 +55,17 @@ def main():
     ap.add_argument("--rc", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-baseline", action="store_true", help="cpu_baseline from the oracle port only")
+    ap.add_argument("--reference-threads", type=int, default=16, help="threads for the genuine reference (its best on a 256-core box)")
+    ap.add_argument("--reference-reads", type=int, default=1_000_000)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse on one GPU")
+    ap.add_argument("--share-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
+    from utree_amd import dist as udist
     from utree_amd import synth
     from utree_amd.search import CtrDB, DeviceTree
 
@@ -68,10 +74,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.share_gpu0:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     W = args.kmer // 4
     want_cpu = (world == 1 and not args.no_cpu_baseline)
 
@@ -82,18 +93,10 @@ def main():
         sdb = synth.make_db(dev, args.nodes, W=W, fine_bits=args.fine_bits, keep_raw=want_cpu)
         tree, ctr = sdb.tree, sdb.ctr
     if world > 1:
-        meta = [None]
+        meta = None
         if rank == 0:
-            meta = [dict(label_text=sdb.label_text, image_bytes=tree.image_tensor().numel(), W=W, n_nodes=args.nodes)]
-        dist.broadcast_object_list(meta, src=0)
-        m = meta[0]
-        image = tree.image_tensor() if rank == 0 else torch.empty(m["image_bytes"], dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-        dist.barrier()
-        tb = time.time()
-        dist.broadcast(image, src=0)
-        torch.cuda.synchronize()
-        bcast_s = time.time() - tb
+            meta = dict(label_text=sdb.label_text, image_bytes=tree.image_tensor().numel(), W=W, n_nodes=args.nodes)
+        image, m, bcast_s = udist.broadcast_image(tree.image_tensor() if rank == 0 else None, meta, 0, dev)
         if rank != 0:
             dummy_bins = np.zeros((1 << 24) + 1, dtype=np.uint64)
             dummy_bins[-1] = m["n_nodes"]
@@ -132,9 +135,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.time() - t1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = udist.max_over_ranks(elapsed, dev)
     k_ms, k_launches = tree.kernel_time(reset=True)
 
     if rank == 0:
@@ -181,27 +182,38 @@ def main():
 
 
 def cpu_baseline(args, sdb, batch, outs, tree, total_bases):
-    """The reference path's CPU restatement (oracle/, OpenMP over reads) on this box's host cores, on a bounded
-    sample of batch 0, plus a record-by-record parity check of the GPU results on that sample."""
+    """CPU baselines on this box's host cores, rank 0, N=1 only, on a bounded sample of batch 0:
+
+    kind "reference": the GENUINE reference binary (oracle/_ref/xtree-searchGG, compiled from /root/reference by
+        `make -C oracle ref` in the build container; only the binary travels) run as a subprocess on the same
+        database written out as a real `.ctr` file and the sample written as FASTA, at the thread count where
+        it is fastest on this class of box (its `omp critical` input section makes it SLOWER beyond ~16
+        threads: profiles/r01/reference_thread_sweep.txt); database load time taken out with an empty-FASTA run.
+    kind "port": the CPU oracle (oracle/, OpenMP parallel-for over reads, no input critical section) on all cores.
+    Both also serve as parity checks of the GPU results on the sample."""
+    import hashlib
+    import shutil
+    import subprocess
+    import tempfile
     import numpy as np
     import torch
     from oracle import orc
     cores = os.cpu_count() or 1
-    try:
-        binix = sdb.binix.cpu().numpy().view(np.uint32).astype(np.uint64)
-        records = sdb.records.cpu().numpy()
-        o = orc.OracleDB.from_memory(sdb.W, 2, binix, records, sdb.label_text)
-        del records
-    except (MemoryError, RuntimeError) as e:
-        return {"value": None, "unit": "reads/s", "cores": cores, "kind": "port", "sample": "skipped: %s" % e}
     L = batch.read_len
-    # GPU results of batch 0 for the parity check
-    res = tree.classify(batch.bases, batch.off, batch.length, rc=bool(args.rc), total_bases=total_bases, max_len=L).cpu().numpy()
-    probe = 20000
     cap = min(batch.n, 2_000_000)
+    res = tree.classify(batch.bases, batch.off, batch.length, rc=bool(args.rc), total_bases=total_bases, max_len=L).cpu().numpy()
     host = batch.bases[: cap * L].cpu().numpy()
-    off = np.arange(batch.n, dtype=np.uint64) * L
-    ln = np.full(batch.n, L, dtype=np.uint32)
+    off = np.arange(cap, dtype=np.uint64) * L
+    ln = np.full(cap, L, dtype=np.uint32)
+    out = {"value": None, "unit": "reads/s", "cores": cores, "kind": "port", "sample": ""}
+    try:
+        binix_u32 = sdb.binix.cpu().numpy().view(np.uint32)
+        records = sdb.records.cpu().numpy()
+        o = orc.OracleDB.from_memory(sdb.W, 2, binix_u32.astype(np.uint64), records, sdb.label_text)
+    except (MemoryError, RuntimeError) as e:
+        out["sample"] = "skipped: %s" % e
+        return out
+    probe = 20000
     t0 = time.time()
     o.classify_batch(host, off[:probe], ln[:probe], rc=bool(args.rc), threads=cores)
     rate0 = probe / max(1e-6, time.time() - t0)
@@ -215,10 +227,63 @@ def cpu_baseline(args, sdb, batch, outs, tree, total_bases):
     ok = (np.array_equal(got[:, 2], want["found"]) and np.array_equal(got[hit, 3], want["uix"][hit]) and
           np.array_equal(got[hit, 0], want["label"][hit]) and np.array_equal(res[:n][hit, 1], want["cut"][hit]) and
           np.array_equal(got[multi, 4], want["sl"][multi]) and np.array_equal(got[multi, 5], want["ol"][multi]))
-    return {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+    port = {"value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port", "parity_ok": bool(ok),
             "sample": "first %d reads of batch 0 (same DB, same reads), %.1f s on %d OpenMP threads; GPU results on the "
-                      "sample bit-identical to the CPU oracle: %s" % (n, dt, cores, bool(ok)),
-            "parity_ok": bool(ok)}
+                      "sample bit-identical to the CPU oracle: %s" % (n, dt, cores, bool(ok))}
+    out = dict(port)
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "xtree-searchGG" + ("-k64" if sdb.W == 16 else ""))
+    if not os.path.exists(ref_bin) or args.no_reference_baseline:
+        return out
+    tmp = None
+    try:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 3 * records.nbytes else None
+        tmp = tempfile.mkdtemp(prefix="utree_bench_", dir=base)
+        ctr_path, fa, empty = os.path.join(tmp, "db.ctr"), os.path.join(tmp, "sample.fa"), os.path.join(tmp, "empty.fa")
+        with open(ctr_path, "wb") as f:
+            f.write(np.array([sdb.W, 0, 2, sdb.n_nodes], dtype="<u8").tobytes())
+            f.write(binix_u32.tobytes())
+            for lo in range(0, records.size, 1 << 30):
+                f.write(records[lo:lo + (1 << 30)].tobytes())
+            f.write(sdb.label_text)
+        T = args.reference_threads
+        nref = int(min(cap, max(50_000, args.reference_reads)))
+        seq = host[: nref * L].reshape(nref, L)
+        with open(fa, "wb") as f:
+            for i in range(nref):
+                f.write(b">r%d\n" % i)
+                f.write(seq[i].tobytes())
+                f.write(b"\n")
+        open(empty, "wb").close()
+        rcarg = ["RC"] if args.rc else []
+
+        def run(fasta, outp):
+            t = time.time()
+            subprocess.run([ref_bin, ctr_path, fasta, outp, str(T)] + rcarg, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           check=True, timeout=900)
+            return time.time() - t
+        t_load = run(empty, os.path.join(tmp, "e.txt"))
+        t_all = run(fa, os.path.join(tmp, "ref.txt"))
+        search = max(1e-6, t_all - t_load)
+        # parity: GPU results formatted by the product's formatter == the reference's lines (as a multiset:
+        # the reference writes in thread-completion order)
+        names_off = np.zeros(nref, dtype=np.uint64)
+        names = b"".join(b"r%d" % i for i in range(nref))
+        lens = np.array([len(b"r%d" % i) for i in range(nref)], dtype=np.uint32)
+        names_off[1:] = np.cumsum(lens[:-1])
+        ours = sdb.ctr.format(np.frombuffer(names, dtype=np.uint8), names_off, lens, res[:nref])
+        ref_lines = sorted(open(os.path.join(tmp, "ref.txt"), "rb").read().split(b"\n"))
+        same = sorted(ours.split(b"\n")) == ref_lines
+        out = {"value": nref / search, "unit": "reads/s", "cores": T, "kind": "reference", "parity_ok": bool(same and ok),
+               "sample": "genuine reference binary (itree.c -D SEARCH_GG), %d threads, first %d reads of batch 0 on the same "
+                         "database written as a .ctr file: %.1f s total - %.1f s load-only run = %.2f s search; its output "
+                         "lines == GPU results formatted by the product (multiset): %s" % (T, nref, t_all, t_load, search, same),
+               "port": port}
+    except Exception as e:  # the baseline must never take the benchmark line down
+        out["reference_error"] = repr(e)
+    finally:
+        if tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -1,0 +1,77 @@
+"""N>1 path on CPU: world_size-2 `gloo` processes exercise the sharding / image-replication / ordered-concat
+plumbing of utree_amd.dist (the part of the multi-GPU path that is not a kernel).  The per-shard "classify"
+stand-in here is the CPU oracle, so the test also shows that contiguous sharding + rank-order concatenation
+reproduces the single-process output byte for byte."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from utree_amd import dist as udist
+import util
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ctr_path, fasta_path, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import orc
+        from utree_amd.search import CtrDB, frame_fasta
+        # (1) image replication: rank 0 owns a fake flat image, everybody must end up with the same bytes
+        img = None
+        meta = None
+        if rank == 0:
+            g = torch.Generator().manual_seed(7)
+            img = torch.randint(0, 256, (3_000_001,), dtype=torch.uint8, generator=g)
+            meta = {"image_bytes": img.numel(), "label_text": b"a\t1\n", "n_nodes": 5}
+        img, meta, secs = udist.broadcast_image(img, meta, 0, torch.device("cpu"))
+        g = torch.Generator().manual_seed(7)
+        want = torch.randint(0, 256, (3_000_001,), dtype=torch.uint8, generator=g)
+        assert torch.equal(img, want) and meta["n_nodes"] == 5 and secs >= 0
+        # (2) contiguous read shards, classified independently, concatenated in rank order
+        data = open(fasta_path, "rb").read()
+        fr = frame_fasta(data)
+        n = len(fr["seq_off"])
+        lo, hi = udist.shard_range(n, rank, world)
+        o = orc.OracleDB.load(ctr_path)
+        db = CtrDB.open(ctr_path)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        res = o.classify_batch(buf, fr["seq_off"][lo:hi], fr["seq_len"][lo:hi], rc=True, threads=2)
+        text = db.format(buf, fr["name_off"][lo:hi], fr["name_len"][lo:hi], res)
+        full = udist.gather_outputs_in_order(text, dst=0)
+        # (3) the bench's timing reduction
+        m = udist.max_over_ranks(float(rank + 1), torch.device("cpu"))
+        assert m == float(world)
+        if rank == 0:
+            open(os.path.join(out_dir, "out.txt"), "wb").write(full)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_ranges_partition_exactly():
+    for n in (0, 1, 7, 10_000, 40_000_001):
+        for world in (1, 2, 3, 8):
+            r = [udist.shard_range(n, g, world) for g in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_two_rank_gloo_shard_and_concat(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, util.fixture_ctr("toy"), util.fixture_reads_path("toy"), str(tmp_path)), nprocs=2,
+             join=True)
+    assert (tmp_path / "out.txt").read_bytes() == util.fixture_bytes("toy_out_rc.txt.gz")
