@@ -145,3 +145,45 @@ def test_synthetic_ctr_roundtrip(tmp_path):
     o = orc.OracleDB.load(p)
     for j in range(0, len(lo), 97):
         assert o.lookup(0, int(lo[j])) == int(ix[j])
+
+
+def _frame_both(data, final):
+    """parallel (default) and serial (UTREE_FRAME_SERIAL) framing of the same bytes"""
+    os.environ.pop("UTREE_FRAME_SERIAL", None)
+    a = frame_fasta(data, final=final)
+    os.environ["UTREE_FRAME_SERIAL"] = "1"
+    try:
+        b = frame_fasta(data, final=final)
+    finally:
+        os.environ.pop("UTREE_FRAME_SERIAL", None)
+    return a, b
+
+
+def test_parallel_framing_equals_serial_framing():
+    rng = np.random.default_rng(11)
+    parts = []
+    for i in range(150_000):
+        L = int(rng.integers(1, 400)) if rng.random() < 0.98 else int(rng.integers(2000, 60000))
+        seq = bytes(rng.integers(65, 85, L, dtype=np.uint8))
+        nl = b"\r\n" if rng.random() < 0.05 else b"\n"
+        hdr = b">r%d" % i + (b" desc with spaces" if rng.random() < 0.1 else b"") + (b"\tx" if rng.random() < 0.02 else b"")
+        if rng.random() < 0.002:
+            seq = b""                                   # blank sequence line: framed with length 0, no error
+        parts.append(hdr + nl + seq + nl)
+    data = b"".join(parts)
+    assert len(data) > (32 << 20)
+    for final, blob in ((True, data), (True, data[:-1]), (False, data[:-777]), (False, data)):
+        a, b = _frame_both(blob, final)
+        for k in ("seq_off", "seq_len", "name_off", "name_len"):
+            assert np.array_equal(a[k], b[k]), (k, final)
+        assert a["consumed"] == b["consumed"] and a["error_code"] == b["error_code"] == 0
+    # injected errors: the earliest one wins, reads before it are framed identically
+    for where, junk in ((len(data) // 3, b"\n"), (len(data) // 2, b">oops\n"), (len(data) * 3 // 4, b"xx\n")):
+        cut = data.index(b"\n>", where) + 1
+        blob = data[:cut] + junk + data[cut:]
+        a, b = _frame_both(blob, True)
+        assert a["error_code"] == b["error_code"] != 0 and a["error_read"] == b["error_read"]
+        assert len(a["seq_off"]) == len(b["seq_off"]) and np.array_equal(a["seq_off"], b["seq_off"])
+    # odd number of lines at the end: "can't read sequence"
+    a, b = _frame_both(data + b">last\n", True)
+    assert a["error_code"] == b["error_code"] == 1 and len(a["seq_off"]) == len(b["seq_off"]) == 150_000

@@ -1,14 +1,19 @@
 /* search.c -- whole-file search: XT_doSearch32's GG branch (itree.c:833-1108) over one or more device
- * images.  Host orchestration in C: read the FASTA in large chunks into pinned memory, frame the reads
- * (fasta.c), shard them contiguously over the GPUs, copy each shard's byte span to HBM as it stands,
- * run the batch kernels, copy the 24-byte results back, format and write the lines in input order
- * (= what the reference writes with one thread; with more threads it writes a permutation).
+ * images.  Host orchestration in C, three overlapped stages connected by a ring of chunk slots:
+ *
+ *   reader   : parallel pread of the next ~96 MiB of FASTA into pinned memory, frame the reads (fasta.c;
+ *              the reference does this under `omp critical`, itree.c:867-874 -- its scaling limit)
+ *   gpu      : shard the framed reads contiguously over the GPUs; per GPU copy the shard's byte span to HBM
+ *              as it stands, run the batch kernels, copy the 24-byte results back
+ *   writer   : format the lines with a thread team and write them in input order (= what the reference
+ *              writes with one thread; with more threads it writes a permutation)
  */
 #define _FILE_OFFSET_BITS 64
 #define _GNU_SOURCE
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -21,8 +26,10 @@
 #include "dev_image.h"
 
 #define CHUNK_BYTES ((size_t)96 << 20)        /* must hold two maximal (16 MiB) lines                    */
-#define MAX_READS_PER_BATCH ((size_t)4 << 20)
+#define MAX_READS_PER_BATCH ((size_t)2 << 20)  /* more reads in a chunk (tiny reads) simply take another batch */
 #define LINELEN_MAX 16777216u                 /* itree.c:836 */
+#define NSLOTS 3
+#define READ_THREADS 4
 
 static double now_s(void) {
     struct timespec ts;
@@ -30,13 +37,247 @@ static double now_s(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+enum { S_EMPTY = 0, S_FRAMED, S_DONE };
+
+typedef struct {
+    uint8_t *h_buf;                            /* pinned: the chunk as read from the file                   */
+    size_t have;                               /* valid bytes                                               */
+    size_t nr, used;                           /* framed reads, bytes they cover                            */
+    uint64_t *seq_off, *name_off, *rel_off;
+    uint32_t *seq_len, *name_len;
+    utree_result *h_res;                       /* pinned                                                    */
+    int frame_rc, last;
+    utree_fasta_error ferr;
+    int state;
+} slot_t;
+
+static int slot_alloc(slot_t *s) {
+    if (s->h_buf) return UTREE_OK;
+    if (hipHostMalloc((void **)&s->h_buf, CHUNK_BYTES + 64, hipHostMallocDefault) != hipSuccess) return UTREE_E_NOMEM;
+    if (hipHostMalloc((void **)&s->h_res, MAX_READS_PER_BATCH * sizeof(utree_result), hipHostMallocDefault) != hipSuccess) return UTREE_E_NOMEM;
+    if (hipHostMalloc((void **)&s->rel_off, MAX_READS_PER_BATCH * 8, hipHostMallocDefault) != hipSuccess) return UTREE_E_NOMEM;
+    if (hipHostMalloc((void **)&s->seq_len, MAX_READS_PER_BATCH * 4, hipHostMallocDefault) != hipSuccess) return UTREE_E_NOMEM;
+    s->seq_off = (uint64_t *)malloc(MAX_READS_PER_BATCH * 8); s->name_off = (uint64_t *)malloc(MAX_READS_PER_BATCH * 8);
+    s->name_len = (uint32_t *)malloc(MAX_READS_PER_BATCH * 4);
+    return (s->seq_off && s->name_off && s->name_len) ? UTREE_OK : UTREE_E_NOMEM;
+}
+
 typedef struct {
     utree_dev *dev;
     hipStream_t stream;
     uint8_t *d_buf; uint64_t *d_off; uint32_t *d_len; utree_result *d_out; void *d_ws; size_t ws_bytes;
-    hipEvent_t k0, k1;
-    size_t first, count;                       /* shard of the current batch                              */
 } gpu_ctx;
+
+typedef struct {
+    const utree_ctr *ctr;
+    gpu_ctx *G; int n_dev;
+    int fd, fo;                                 /* input, output                                            */
+    off_t out_pos;
+    int do_rc, host_threads;
+    slot_t slot[NSLOTS];
+    pthread_mutex_t mu; pthread_cond_t cv;
+    int rc;                                     /* first error of any stage                                  */
+    int stop;
+    utree_search_stats st;
+    double t_read, t_frame, t_gpu, t_format, t_write;
+    uint32_t max_label;
+} pipe_t;
+
+static void set_error(pipe_t *P, int rc) {
+    pthread_mutex_lock(&P->mu);
+    if (!P->rc) P->rc = rc;
+    P->stop = 1;
+    pthread_cond_broadcast(&P->cv);
+    pthread_mutex_unlock(&P->mu);
+}
+/* wait until slot reaches `state` (or the pipeline stops); returns 0 if stopped */
+static int wait_state(pipe_t *P, slot_t *s, int state) {
+    pthread_mutex_lock(&P->mu);
+    while (s->state != state && !P->stop) pthread_cond_wait(&P->cv, &P->mu);
+    int ok = s->state == state;
+    pthread_mutex_unlock(&P->mu);
+    return ok;
+}
+static void set_state(pipe_t *P, slot_t *s, int state) {
+    pthread_mutex_lock(&P->mu);
+    s->state = state;
+    pthread_cond_broadcast(&P->cv);
+    pthread_mutex_unlock(&P->mu);
+}
+
+/* ---- stage 1: read + frame ------------------------------------------------------------------- */
+static void *reader_main(void *arg) {
+    pipe_t *P = (pipe_t *)arg;
+    off_t file_pos = 0;
+    size_t carry = 0;                           /* bytes of an incomplete read carried into the next chunk */
+    const uint8_t *carry_src = NULL;
+    int eof = 0;
+    for (int i = 0; !eof || carry; ++i) {
+        slot_t *s = &P->slot[i % NSLOTS];
+        if (!wait_state(P, s, S_EMPTY)) return NULL;
+        if (i < NSLOTS) {                       /* pinned memory is slow to allocate: do it while earlier chunks are in flight */
+            int arc = slot_alloc(s);
+            if (arc) { set_error(P, arc); return NULL; }
+        }
+        if (carry) memmove(s->h_buf, carry_src, carry);
+        size_t have = carry;
+        double t0 = now_s();
+        if (!eof) {
+            /* parallel pread: the page-cache copy is the cost; several threads stream it */
+            size_t want = CHUNK_BYTES - have;
+            ssize_t got[READ_THREADS];
+            int T = READ_THREADS;
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+            for (int t = 0; t < T; ++t) {
+                size_t a = want * (size_t)t / (size_t)T, b = want * (size_t)(t + 1) / (size_t)T, done = 0;
+                got[t] = 0;
+                while (done < b - a) {
+                    ssize_t r = pread(P->fd, s->h_buf + have + a + done, b - a - done, file_pos + (off_t)(a + done));
+                    if (r < 0) { got[t] = -1; break; }
+                    if (r == 0) break;
+                    done += (size_t)r; got[t] = (ssize_t)done;
+                }
+            }
+            size_t total = 0;
+            for (int t = 0; t < T; ++t) {
+                if (got[t] < 0) { set_error(P, UTREE_E_IO); return NULL; }
+                size_t seg = want * (size_t)(t + 1) / (size_t)T - want * (size_t)t / (size_t)T;
+                total += (size_t)got[t];
+                if ((size_t)got[t] < seg) { eof = 1; break; }       /* short segment: end of file inside it */
+            }
+            have += total; file_pos += (off_t)total;
+        }
+        double t1 = now_s();
+        s->have = have;
+        s->nr = 0; s->used = 0; s->frame_rc = UTREE_OK; s->last = 0;
+        if (have) {
+            s->frame_rc = utree_fasta_frame(s->h_buf, have, eof, MAX_READS_PER_BATCH, s->seq_off, s->seq_len, s->name_off,
+                                            s->name_len, &s->nr, &s->used, &s->ferr);
+            if (s->frame_rc != UTREE_OK && s->frame_rc != UTREE_E_FASTA) { set_error(P, s->frame_rc); return NULL; }
+            if (s->frame_rc == UTREE_OK && !s->nr && !s->used && !eof) {
+                s->frame_rc = UTREE_E_FASTA; s->ferr.code = 5; s->ferr.read_index = 0;   /* a line pair larger than a chunk */
+            }
+        }
+        P->t_read += t1 - t0; P->t_frame += now_s() - t1;
+        carry = have - s->used; carry_src = s->h_buf + s->used;
+        if (s->frame_rc == UTREE_E_FASTA) { carry = 0; eof = 1; }
+        if (eof && !carry) s->last = 1;
+        if (eof && carry && s->frame_rc == UTREE_OK && s->used == 0 && s->nr == 0) { s->last = 1; carry = 0; }
+        set_state(P, s, S_FRAMED);
+        if (s->last) break;
+    }
+    return NULL;
+}
+
+/* ---- stage 2: GPU ---------------------------------------------------------------------------- */
+#define HIPOK(x) do { if ((x) != hipSuccess) { set_error(P, UTREE_E_HIP); return NULL; } } while (0)
+
+static void *gpu_main(void *arg) {
+    pipe_t *P = (pipe_t *)arg;
+    for (int i = 0;; ++i) {
+        slot_t *s = &P->slot[i % NSLOTS];
+        if (!wait_state(P, s, S_FRAMED)) return NULL;
+        double t0 = now_s();
+        size_t nr = s->nr, n_dev = (size_t)P->n_dev;
+        size_t per = (nr + n_dev - 1) / n_dev;
+        for (size_t g = 0; g < n_dev && nr; ++g) {
+            gpu_ctx *c = &P->G[g];
+            size_t first = g * per; if (first > nr) first = nr;
+            size_t count = first + per <= nr ? per : nr - first;
+            if (!count) continue;
+            size_t last = first + count - 1;
+            size_t lo = (size_t)s->seq_off[first], hi = (size_t)s->seq_off[last] + s->seq_len[last];
+            uint64_t total = 0; uint32_t mx = 0;
+            for (size_t r = first; r <= last; ++r) {
+                s->rel_off[r] = s->seq_off[r] - lo; total += s->seq_len[r];
+                if (s->seq_len[r] > mx) mx = s->seq_len[r];
+            }
+            HIPOK(hipSetDevice(c->dev->device));
+            HIPOK(hipMemcpyAsync(c->d_buf, s->h_buf + lo, hi - lo, hipMemcpyHostToDevice, c->stream));
+            HIPOK(hipMemcpyAsync(c->d_off, s->rel_off + first, count * 8, hipMemcpyHostToDevice, c->stream));
+            HIPOK(hipMemcpyAsync(c->d_len, s->seq_len + first, count * 4, hipMemcpyHostToDevice, c->stream));
+            int e = utree_classify_batch(c->dev, c->d_buf, c->d_off, c->d_len, (uint32_t)count, total, mx, P->do_rc, c->d_out,
+                                         c->d_ws, c->ws_bytes, c->stream);
+            if (e) { set_error(P, e); return NULL; }
+            HIPOK(hipMemcpyAsync(s->h_res + first, c->d_out, count * sizeof(utree_result), hipMemcpyDeviceToHost, c->stream));
+        }
+        for (size_t g = 0; g < n_dev && nr; ++g) {
+            HIPOK(hipSetDevice(P->G[g].dev->device));
+            HIPOK(hipStreamSynchronize(P->G[g].stream));
+        }
+        P->t_gpu += now_s() - t0;
+        int last = s->last;
+        set_state(P, s, S_DONE);
+        if (last) return NULL;
+    }
+}
+
+/* ---- stage 3: format + write ------------------------------------------------------------------ */
+static void *writer_main(void *arg) {
+    pipe_t *P = (pipe_t *)arg;
+    int T0 = P->host_threads;
+    char **fmt_buf = (char **)calloc((size_t)T0, sizeof(char *));
+    size_t *fmt_cap = (size_t *)calloc((size_t)T0, sizeof(size_t)), *fmt_len = (size_t *)calloc((size_t)T0, sizeof(size_t));
+    uint64_t next_progress = 1048576;
+    if (!fmt_buf || !fmt_cap || !fmt_len) { set_error(P, UTREE_E_NOMEM); goto out; }
+    for (int i = 0;; ++i) {
+        slot_t *s = &P->slot[i % NSLOTS];
+        if (!wait_state(P, s, S_DONE)) break;
+        double t0 = now_s();
+        size_t nr = s->nr;
+        int T = T0;
+        if ((size_t)T > nr / 4096 + 1) T = (int)(nr / 4096 + 1);
+        int fail = 0;
+        uint64_t good_total = 0;
+#pragma omp parallel for num_threads(T) schedule(static, 1) reduction(+ : good_total) reduction(| : fail)
+        for (int t = 0; t < T; ++t) {
+            size_t a = nr * (size_t)t / (size_t)T, b = nr * (size_t)(t + 1) / (size_t)T, need = 64;
+            for (size_t r = a; r < b; ++r) {
+                const utree_result *q = &s->h_res[r];
+                if (!q->found) continue;
+                uint32_t ll = q->label < P->ctr->info.n_labels ? P->ctr->label_len[q->label] : 0;
+                need += (size_t)s->name_len[r] + ll + 48;
+            }
+            if (need > fmt_cap[t]) { free(fmt_buf[t]); fmt_buf[t] = (char *)malloc(need + need / 4); fmt_cap[t] = fmt_buf[t] ? need + need / 4 : 0; }
+            uint64_t good = 0;
+            size_t L = fmt_buf[t] ? utree_format_records(P->ctr, s->h_buf, s->name_off + a, s->name_len + a, s->h_res + a, b - a,
+                                                        fmt_buf[t], fmt_cap[t], &good) : (size_t)-1;
+            if (L == (size_t)-1) { fail |= 1; fmt_len[t] = 0; } else { fmt_len[t] = L; good_total += good; }
+        }
+        double t1 = now_s();
+        if (fail) { set_error(P, UTREE_E_NOMEM); break; }
+        /* pieces in input order; writes to one file serialise in the kernel anyway, so one thread issues them */
+        for (int t = 0; t < T; ++t) {
+            size_t done = 0;
+            while (done < fmt_len[t]) {
+                ssize_t w = write(P->fo, fmt_buf[t] + done, fmt_len[t] - done);
+                if (w <= 0) { set_error(P, UTREE_E_IO); goto out; }
+                done += (size_t)w;
+            }
+        }
+        for (int t = 0; t < T; ++t) P->out_pos += (off_t)fmt_len[t];
+        P->t_format += t1 - t0; P->t_write += now_s() - t1;
+        P->st.good_finds += good_total;
+        P->st.n_reads += nr;
+        while (P->st.n_reads >= next_progress) {                                  /* itree.c:878 */
+            printf("Searched %llu queries...\n", (unsigned long long)next_progress);
+            next_progress += 1048576;
+        }
+        int last = s->last;
+        if (s->frame_rc == UTREE_E_FASTA) {                                       /* reads before the bad one are written */
+            P->st.fasta_error = s->ferr;
+            P->st.fasta_error.read_index += P->st.n_reads - nr;
+            set_error(P, UTREE_E_FASTA);
+            break;
+        }
+        set_state(P, s, S_EMPTY);
+        if (last) break;
+    }
+out:
+    if (fmt_buf) for (int t = 0; t < T0; ++t) free(fmt_buf[t]);
+    free(fmt_buf); free(fmt_cap); free(fmt_len);
+    return NULL;
+}
 
 static void free_ctx(gpu_ctx *g) {
     if (!g->dev) return;
@@ -46,147 +287,83 @@ static void free_ctx(gpu_ctx *g) {
     if (g->d_len) hipFree(g->d_len);
     if (g->d_out) hipFree(g->d_out);
     if (g->d_ws) hipFree(g->d_ws);
-    if (g->k0) hipEventDestroy(g->k0);
-    if (g->k1) hipEventDestroy(g->k1);
     if (g->stream) hipStreamDestroy(g->stream);
 }
 
-#define HIPOK(x) do { if ((x) != hipSuccess) { rc = UTREE_E_HIP; goto done; } } while (0)
+#define HIPM(x) do { if ((x) != hipSuccess) { rc = UTREE_E_HIP; goto done; } } while (0)
 
 int utree_search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
                       int do_rc, int host_threads, utree_search_stats *stats) {
     if (!ctr || !devs || n_dev < 1 || !fasta_path || !out_path) return UTREE_E_ARG;
     int rc = UTREE_OK;
-    double t_start = now_s(), t_kernels = 0;
-    utree_search_stats st;
-    memset(&st, 0, sizeof st);
-    int fd = open(fasta_path, O_RDONLY);
-    FILE *fo = fopen(out_path, "wb");
-    if (fd < 0 || !fo) { if (fd >= 0) close(fd); if (fo) fclose(fo); return UTREE_E_IO; }   /* itree.c:835 */
+    double t_start = now_s();
+    pipe_t *P = (pipe_t *)calloc(1, sizeof *P);
+    if (!P) return UTREE_E_NOMEM;
+    P->ctr = ctr; P->n_dev = n_dev; P->do_rc = do_rc;
+    P->fd = open(fasta_path, O_RDONLY);
+    P->fo = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);                   /* fopen(outfile, "wb"), itree.c:834 */
+    if (P->fd < 0 || P->fo < 0) {                                                 /* itree.c:835 */
+        if (P->fd >= 0) close(P->fd);
+        if (P->fo >= 0) close(P->fo);
+        free(P);
+        return UTREE_E_IO;
+    }
 #ifdef _OPENMP
     if (host_threads <= 0) host_threads = omp_get_max_threads();
 #else
     host_threads = 1;
 #endif
-    uint8_t *h_buf = NULL;
-    uint64_t *seq_off = NULL, *name_off = NULL, *rel_off = NULL;
-    uint32_t *seq_len = NULL, *name_len = NULL;
-    utree_result *h_res = NULL;
-    char **fmt_buf = NULL; size_t *fmt_cap = NULL, *fmt_len = NULL;
-    gpu_ctx *G = (gpu_ctx *)calloc((size_t)n_dev, sizeof(gpu_ctx));
-    if (!G) { rc = UTREE_E_NOMEM; goto done; }
-    HIPOK(hipHostMalloc((void **)&h_buf, CHUNK_BYTES + 64, hipHostMallocDefault));
-    seq_off = (uint64_t *)malloc(MAX_READS_PER_BATCH * 8); name_off = (uint64_t *)malloc(MAX_READS_PER_BATCH * 8);
-    rel_off = (uint64_t *)malloc(MAX_READS_PER_BATCH * 8);
-    seq_len = (uint32_t *)malloc(MAX_READS_PER_BATCH * 4); name_len = (uint32_t *)malloc(MAX_READS_PER_BATCH * 4);
-    HIPOK(hipHostMalloc((void **)&h_res, MAX_READS_PER_BATCH * sizeof(utree_result), hipHostMallocDefault));
-    fmt_buf = (char **)calloc((size_t)host_threads, sizeof(char *));
-    fmt_cap = (size_t *)calloc((size_t)host_threads, sizeof(size_t));
-    fmt_len = (size_t *)calloc((size_t)host_threads, sizeof(size_t));
-    if (!seq_off || !name_off || !rel_off || !seq_len || !name_len || !fmt_buf || !fmt_cap || !fmt_len) { rc = UTREE_E_NOMEM; goto done; }
+    if (host_threads > 16) host_threads = 16;                                     /* formatting saturates well before that */
+    P->host_threads = host_threads;
+    pthread_mutex_init(&P->mu, NULL);
+    pthread_cond_init(&P->cv, NULL);
+    for (uint32_t i = 0; i < ctr->info.n_labels; ++i) if (ctr->label_len[i] > P->max_label) P->max_label = ctr->label_len[i];
+    P->G = (gpu_ctx *)calloc((size_t)n_dev, sizeof(gpu_ctx));
+    if (!P->G) { rc = UTREE_E_NOMEM; goto done; }
     for (int g = 0; g < n_dev; ++g) {
-        G[g].dev = devs[g];
-        HIPOK(hipSetDevice(devs[g]->device));
-        HIPOK(hipStreamCreateWithFlags(&G[g].stream, hipStreamNonBlocking));
-        HIPOK(hipEventCreate(&G[g].k0)); HIPOK(hipEventCreate(&G[g].k1));
-        HIPOK(hipMalloc((void **)&G[g].d_buf, CHUNK_BYTES + 64));
-        HIPOK(hipMalloc((void **)&G[g].d_off, MAX_READS_PER_BATCH * 8));
-        HIPOK(hipMalloc((void **)&G[g].d_len, MAX_READS_PER_BATCH * 4));
-        HIPOK(hipMalloc((void **)&G[g].d_out, MAX_READS_PER_BATCH * sizeof(utree_result)));
-        G[g].ws_bytes = utree_classify_workspace_bytes(devs[g], (uint32_t)MAX_READS_PER_BATCH, CHUNK_BYTES, LINELEN_MAX, do_rc);
-        HIPOK(hipMalloc(&G[g].d_ws, G[g].ws_bytes));
+        gpu_ctx *c = &P->G[g];
+        c->dev = devs[g];
+        HIPM(hipSetDevice(devs[g]->device));
+        HIPM(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPM(hipMalloc((void **)&c->d_buf, CHUNK_BYTES + 64));
+        HIPM(hipMalloc((void **)&c->d_off, MAX_READS_PER_BATCH * 8));
+        HIPM(hipMalloc((void **)&c->d_len, MAX_READS_PER_BATCH * 4));
+        HIPM(hipMalloc((void **)&c->d_out, MAX_READS_PER_BATCH * sizeof(utree_result)));
+        c->ws_bytes = utree_classify_workspace_bytes(devs[g], (uint32_t)MAX_READS_PER_BATCH, CHUNK_BYTES, LINELEN_MAX, do_rc);
+        HIPM(hipMalloc(&c->d_ws, c->ws_bytes));
     }
-    uint32_t max_label = 0;
-    for (uint32_t i = 0; i < ctr->info.n_labels; ++i) if (ctr->label_len[i] > max_label) max_label = ctr->label_len[i];
-
-    size_t have = 0;               /* bytes in h_buf */
-    int eof = 0;
-    uint64_t next_progress = 1048576;
-    while (!eof || have) {
-        while (!eof && have < CHUNK_BYTES) {
-            ssize_t r = read(fd, h_buf + have, CHUNK_BYTES - have);
-            if (r < 0) { rc = UTREE_E_IO; goto done; }
-            if (r == 0) { eof = 1; break; }
-            have += (size_t)r;
-        }
-        if (!have) break;
-        size_t nr = 0, used = 0;
-        utree_fasta_error ferr;
-        int frc = utree_fasta_frame(h_buf, have, eof, MAX_READS_PER_BATCH, seq_off, seq_len, name_off, name_len, &nr, &used, &ferr);
-        if (frc != UTREE_OK && frc != UTREE_E_FASTA) { rc = frc; goto done; }
-        if (!nr && frc == UTREE_OK && used == 0) {
-            if (eof) break;
-            rc = UTREE_E_FASTA; ferr.code = 5; st.fasta_error = ferr; goto done;   /* a line pair larger than the chunk */
-        }
-        /* shard contiguously over the devices and launch */
-        double tk0 = now_s();
-        size_t per = (nr + (size_t)n_dev - 1) / (size_t)n_dev;
-        for (int g = 0; g < n_dev && nr; ++g) {
-            gpu_ctx *c = &G[g];
-            c->first = (size_t)g * per; if (c->first > nr) c->first = nr;
-            c->count = c->first + per <= nr ? per : nr - c->first;
-            if (!c->count) continue;
-            size_t lo = (size_t)seq_off[c->first], last = c->first + c->count - 1;
-            size_t hi = (size_t)seq_off[last] + seq_len[last];
-            uint64_t total = 0; uint32_t mx = 0;
-            for (size_t i = c->first; i <= last; ++i) { rel_off[i] = seq_off[i] - lo; total += seq_len[i]; if (seq_len[i] > mx) mx = seq_len[i]; }
-            HIPOK(hipSetDevice(c->dev->device));
-            HIPOK(hipMemcpyAsync(c->d_buf, h_buf + lo, hi - lo, hipMemcpyHostToDevice, c->stream));
-            HIPOK(hipMemcpyAsync(c->d_off, rel_off + c->first, c->count * 8, hipMemcpyHostToDevice, c->stream));
-            HIPOK(hipMemcpyAsync(c->d_len, seq_len + c->first, c->count * 4, hipMemcpyHostToDevice, c->stream));
-            int e = utree_classify_batch(c->dev, c->d_buf, c->d_off, c->d_len, (uint32_t)c->count, total, mx, do_rc, c->d_out,
-                                         c->d_ws, c->ws_bytes, c->stream);
-            if (e) { rc = e; goto done; }
-            HIPOK(hipMemcpyAsync(h_res + c->first, c->d_out, c->count * sizeof(utree_result), hipMemcpyDeviceToHost, c->stream));
-        }
-        for (int g = 0; g < n_dev && nr; ++g) {
-            if (!G[g].count) continue;
-            HIPOK(hipSetDevice(G[g].dev->device));
-            HIPOK(hipStreamSynchronize(G[g].stream));
-        }
-        t_kernels += now_s() - tk0;
-        /* format in parallel, write in input order (itree.c:1032, 1040, 1096) */
-        int T = host_threads;
-        if ((size_t)T > nr) T = nr ? (int)nr : 1;
-        int fmt_fail = 0;
-#pragma omp parallel for num_threads(T) schedule(static, 1)
-        for (int t = 0; t < T; ++t) {
-            size_t a = nr * (size_t)t / (size_t)T, b = nr * (size_t)(t + 1) / (size_t)T;
-            size_t need = 0;
-            for (size_t i = a; i < b; ++i) need += (size_t)name_len[i] + max_label + 48;
-            if (need > fmt_cap[t]) { free(fmt_buf[t]); fmt_buf[t] = (char *)malloc(need + 64); fmt_cap[t] = fmt_buf[t] ? need + 64 : 0; }
-            uint64_t good = 0;
-            size_t L = fmt_buf[t] ? utree_format_records(ctr, h_buf, name_off + a, name_len + a, h_res + a, b - a, fmt_buf[t], fmt_cap[t], &good) : (size_t)-1;
-            fmt_len[t] = L == (size_t)-1 ? 0 : L;
-#pragma omp critical(utree_fmt)
-            {
-                if (L == (size_t)-1) fmt_fail = 1;
-                else st.good_finds += good;
-            }
-        }
-        if (fmt_fail) { rc = UTREE_E_NOMEM; goto done; }
-        for (int t = 0; t < T; ++t) if (fmt_len[t] && fwrite(fmt_buf[t], 1, fmt_len[t], fo) != fmt_len[t]) { rc = UTREE_E_IO; goto done; }
-        st.n_reads += nr;
-        while (st.n_reads >= next_progress) {                          /* itree.c:878 */
-            printf("Searched %llu queries...\n", (unsigned long long)next_progress);
-            next_progress += 1048576;
-        }
-        if (frc == UTREE_E_FASTA) { st.fasta_error = ferr; st.fasta_error.read_index += st.n_reads - nr; rc = UTREE_E_FASTA; goto done; }
-        memmove(h_buf, h_buf + used, have - used);
-        have -= used;
-        if (eof && !have) break;
+    {
+        pthread_t tr, tg, tw;
+        pthread_create(&tr, NULL, reader_main, P);
+        pthread_create(&tg, NULL, gpu_main, P);
+        pthread_create(&tw, NULL, writer_main, P);
+        pthread_join(tw, NULL);
+        /* the writer ends last on success; on error make sure the others leave their waits */
+        pthread_mutex_lock(&P->mu); P->stop = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
+        pthread_join(tr, NULL);
+        pthread_join(tg, NULL);
+        rc = P->rc;
     }
 done:
-    if (fd >= 0) close(fd);
-    if (fo) fclose(fo);
-    if (G) { for (int g = 0; g < n_dev; ++g) free_ctx(&G[g]); free(G); }
-    if (h_buf) hipHostFree(h_buf);
-    if (h_res) hipHostFree(h_res);
-    free(seq_off); free(name_off); free(rel_off); free(seq_len); free(name_len);
-    if (fmt_buf) for (int t = 0; t < host_threads; ++t) free(fmt_buf[t]);
-    free(fmt_buf); free(fmt_cap); free(fmt_len);
-    st.seconds_total = now_s() - t_start;
-    st.seconds_kernels = t_kernels;
-    if (stats) *stats = st;
+    if (P->fd >= 0) close(P->fd);
+    if (P->fo >= 0) close(P->fo);
+    if (P->G) { for (int g = 0; g < n_dev; ++g) free_ctx(&P->G[g]); free(P->G); }
+    for (int i = 0; i < NSLOTS; ++i) {
+        slot_t *s = &P->slot[i];
+        if (s->h_buf) hipHostFree(s->h_buf);
+        if (s->h_res) hipHostFree(s->h_res);
+        if (s->rel_off) hipHostFree(s->rel_off);
+        if (s->seq_len) hipHostFree(s->seq_len);
+        free(s->seq_off); free(s->name_off); free(s->name_len);
+    }
+    P->st.seconds_total = now_s() - t_start;
+    P->st.seconds_kernels = P->t_gpu;
+    if (getenv("UTREE_DEBUG") || getenv("UTREE_TIMING"))
+        fprintf(stderr, "[utree_amd] stages: read %.3f s, frame %.3f s | gpu %.3f s | format %.3f s, write %.3f s (overlapped)\n",
+                P->t_read, P->t_frame, P->t_gpu, P->t_format, P->t_write);
+    if (stats) *stats = P->st;
+    pthread_mutex_destroy(&P->mu);
+    pthread_cond_destroy(&P->cv);
+    free(P);
     return rc;
 }
