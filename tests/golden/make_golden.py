@@ -439,15 +439,89 @@ def gen_kat(manifest, seed=99):
         manifest["katq_out_lines"] = out.count(b"\n")
 
 
+def gen_irregular(manifest, seed=123):
+    """F3 extras: (a) `katq2` -- COMPRESS' first-bin quirk where the stray record is LARGER than the records it is
+    merged in front of (a bin that is not ascending: only the reference's exact probe order gives its answers);
+    (b) `generic` -- a bin table that is not monotone (never written by COMPRESS, but the reference trusts the
+    table verbatim, itree.c:724-728)."""
+    rng = np.random.default_rng(seed)
+    k = 32
+    labels = ["k__A;p__L%d" % i for i in range(25)]
+
+    def probes(wlist, extra=()):
+        reads = []
+        for n, w in enumerate(list(wlist) + list(extra)):
+            for tag, delta in (("w", 0), ("p", 1), ("m", -1)):
+                v = (int(w) + delta) & 0xFFFFFFFFFFFFFFFF
+                reads.append(("%s%d" % (tag, n), np.frombuffer(ctrfile.decode_kmer(0, v, k).encode(), dtype=np.uint8)))
+        return reads
+
+    with tempfile.TemporaryDirectory() as td:
+        # (a) first bin = one record with a huge suffix; next bin = 9 records with small suffixes
+        P = 0x123456
+        words = [(3 << 40) | 0xFFFFFFFFFF] + [(P << 40) | (0x10 * (j + 1)) for j in range(9)]
+        words += [((P + 5) << 40) | int(x) for x in sorted(set(int(v) for v in rng.integers(0, 1 << 40, 40)))]
+        words = np.array(sorted(words), dtype=np.uint64)
+        ixs = rng.integers(0, len(labels), size=len(words)).astype(np.uint32)
+        ctr = os.path.join(td, "katq2.ctr")
+        ctrfile.write_ctr(ctr, 8, 2, np.zeros_like(words), words, ixs, labels, like_compress=True)
+        d = save_db_fixture("katq2", ctr, manifest)
+        assert int(d.binix[P]) == 0 and int(d.binix[P + 1]) == 10       # the stray record sits in front of bin P
+        extra = [(P << 40) | 0xFFFFFFFFFF, (P << 40) | 0x5, (P << 40) | 0x95, (3 << 40) | 0x10]
+        reads = probes(words, extra)
+        fa = os.path.join(td, "r.fa")
+        write_fasta(fa, reads)
+        gz_write(os.path.join(HERE, "katq2_reads.fa.gz"), open(fa, "rb").read())
+        code, out, so, se = ref_search("xtree-searchGG", ctr, fa, 0)
+        assert code == 0
+        gz_write(os.path.join(HERE, "katq2_out.txt.gz"), out)
+        manifest["katq2_out_lines"] = out.count(b"\n")
+        # (b) non-monotone table: take the kat DB and pull some interior bin starts back / push them forward
+        dk = ctrfile.read_ctr(os.path.join(td, "katq2.ctr"))
+        kat = np.load(os.path.join(HERE, "kat_db.npz"))
+        lo = kat["suf_lo"]
+        # rebuild kat exactly, then damage its table
+        idx = kat["bin_chg_idx"].astype(np.int64); val = kat["bin_chg_val"].astype(np.uint64)
+        starts = np.concatenate([[0], idx]); vals = np.concatenate([[np.uint64(kat["bin0"])], val]).astype(np.uint64)
+        lens = np.diff(np.concatenate([starts, [ctrfile.NUMBINS]]))
+        b = np.repeat(vals, lens).copy()
+        nz = np.flatnonzero(np.diff(b.astype(np.int64)) > 0)
+        for j in (5, 11, 17, 23, 31):                 # bin nz[j]: start pulled back by 3 records (overlaps its predecessors)
+            b[nz[j]] = np.uint64(max(0, int(b[nz[j]]) - 3))
+        for j in (8, 20):                             # bin nz[j]: start pushed past its end (s > e: empty)
+            b[nz[j]] = b[nz[j] + 1] + np.uint64(2)
+        rec = ctrfile.pack_records(8, 2, np.zeros_like(lo), lo, kat["ix"])
+        g = os.path.join(td, "generic.ctr")
+        with open(g, "wb") as f:
+            f.write(np.array([8, 0, 2, len(lo)], dtype="<u8").tobytes())
+            f.write(b.astype("<u4").tobytes())
+            f.write(rec.tobytes())
+            f.write(kat["label_text"].tobytes())
+        save_db_fixture("generic", g, manifest)
+        gz = gzip.open(os.path.join(HERE, "kat_reads.fa.gz"), "rb").read()
+        fa2 = os.path.join(td, "r2.fa")
+        open(fa2, "wb").write(gz)
+        code, out, so, se = ref_search("xtree-searchGG", g, fa2, 0)
+        assert code == 0, (code, se[-300:])
+        gz_write(os.path.join(HERE, "generic_out.txt.gz"), out)
+        manifest["generic_out_lines"] = out.count(b"\n")
+
+
 def main():
     if not os.path.exists(os.path.join(REF, "xtree-searchGG")):
         sys.exit("build the reference first: make -C oracle ref")
+    if len(sys.argv) > 1 and sys.argv[1] == "irregular":      # add the irregular-bin fixtures to an existing golden set
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+        gen_irregular(manifest)
+        json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+        return
     manifest = {}
     gen_toy(manifest, "toy", "", "xtree-searchGG", 1000, 1000, 10000, 100, seed=20240807)
     gen_toy(manifest, "k64", "-k64", "xtree-searchGG-k64", 150, 1200, 3000, 150, seed=64)
     gen_toy(manifest, "ix32", "-ix32", "xtree-searchGG-ix32", 150, 1200, 3000, 120, seed=32)
     gen_vote(manifest)
     gen_kat(manifest)
+    gen_irregular(manifest)
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(manifest, indent=1, sort_keys=True))
 

@@ -37,19 +37,20 @@ def tree_for(name, fine_bits=lib.FINE_AUTO):
     return _TREES[key]
 
 
-GOLDEN = [("toy", 0), ("toy", 1), ("k64", 0), ("k64", 1), ("ix32", 0), ("ix32", 1), ("vote", 0), ("kat", 0), ("katq", 0)]
+GOLDEN = [("toy", 0), ("toy", 1), ("k64", 0), ("k64", 1), ("ix32", 0), ("ix32", 1), ("vote", 0), ("kat", 0), ("katq", 0),
+          ("katq2", 0), ("generic", 0)]
 
 
 @pytest.mark.parametrize("name,rc", GOLDEN)
 def test_golden_outputs_bit_exact(torch_cuda, name, rc):
     db, tree = tree_for(name)
-    got = classify_fasta_bytes(db, tree, util.fixture_bytes(name + "_reads.fa.gz"), rc=bool(rc))
+    got = classify_fasta_bytes(db, tree, util.fixture_bytes(util.READS_OF.get(name, name) + "_reads.fa.gz"), rc=bool(rc))
     want = util.fixture_bytes("%s_out%s.txt.gz" % (name, "_rc" if rc else ""))
     assert got == want
 
 
 @pytest.mark.parametrize("fine_bits", [0, 1, 3, 6])
-@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "katq"])
+@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "katq", "katq2"])
 def test_fine_index_width_does_not_change_results(torch_cuda, name, fine_bits):
     db, tree = tree_for(name, fine_bits)
     assert tree.info.fine_bits == fine_bits
@@ -57,10 +58,15 @@ def test_fine_index_width_does_not_change_results(torch_cuda, name, fine_bits):
     assert got == util.fixture_bytes(name + "_out.txt.gz")
 
 
-def test_first_bin_quirk_is_flagged_and_searched_exactly(torch_cuda):
-    _, tq = tree_for("katq")
+def test_irregular_bins_and_generic_mode_are_detected(torch_cuda):
+    """katq2: the first-bin quirk put a LARGER record in front of a bin -> that bin is flagged and searched with the
+    reference's probe order; generic: non-monotone bin table -> every bin takes that path.  Both golden-checked above."""
     _, tk = tree_for("kat")
-    assert tq.info.irregular_bins >= 0 and tk.info.irregular_bins == 0 and tk.info.generic_mode == 0
+    _, tq2 = tree_for("katq2")
+    _, tg = tree_for("generic")
+    assert tk.info.irregular_bins == 0 and tk.info.generic_mode == 0
+    assert tq2.info.irregular_bins >= 1 and tq2.info.generic_mode == 0
+    assert tg.info.generic_mode == 1 and tg.info.fine_bits == 0
 
 
 def test_lookup_operator_matches_oracle(torch_cuda):

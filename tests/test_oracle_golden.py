@@ -22,12 +22,12 @@ def tmpdir_mod(tmp_path_factory):
 def run_oracle(name, rc, tmpdir, threads=1):
     db = orc.OracleDB.load(util.fixture_ctr(name))
     out = os.path.join(str(tmpdir), "%s_%d.txt" % (name, rc))
-    code, nr, good, err = db.search_file(util.fixture_reads_path(name), out, threads=threads, rc=bool(rc))
+    code, nr, good, err = db.search_file(util.fixture_reads_path(util.READS_OF.get(name, name)), out, threads=threads, rc=bool(rc))
     return code, nr, good, open(out, "rb").read()
 
 
 @pytest.mark.parametrize("name,rcs", [("toy", (0, 1)), ("k64", (0, 1)), ("ix32", (0, 1)), ("vote", (0,)),
-                                      ("kat", (0,)), ("katq", (0,))])
+                                      ("kat", (0,)), ("katq", (0,)), ("katq2", (0,)), ("generic", (0,))])
 def test_search_file_matches_reference(name, rcs, tmpdir_mod):
     for rc in rcs:
         code, nr, good, got = run_oracle(name, rc, tmpdir_mod)
@@ -58,7 +58,7 @@ def test_edge_cases_match_reference(tmpdir_mod):
 
 def test_ctr_regenerated_by_our_writer_matches_reference_sha():
     # fixture_ctr asserts the SHA-256 of the reference-built file
-    for name in ("toy", "k64", "ix32", "vote", "kat", "katq"):
+    for name in ("toy", "k64", "ix32", "vote", "kat", "katq", "katq2", "generic"):
         p = util.fixture_ctr(name)
         d = ctrfile.read_ctr(p)
         assert d.n_nodes == util.manifest()[name + "_nodes"]

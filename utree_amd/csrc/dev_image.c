@@ -391,11 +391,17 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
             HIPCHK(hipEventCreate((hipEvent_t *)&d->events[d->n_events])); d->n_events++;
         }
         e0 = d->events[2 * d->n_pending]; e1 = d->events[2 * d->n_pending + 1];
-        HIPCHK(hipEventRecord(e0, st));
     }
+    /* the bracket goes around the batch's dominant kernel: the long-read kernel when the batch has long reads */
+    d->last_long = w.long_blocks != 0;
+    if (e0 && !w.long_blocks) HIPCHK(hipEventRecord(e0, st));
     KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
-    if (e0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
-    if (w.long_blocks) KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &w, d->n_cu, st));
+    if (e0 && !w.long_blocks) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
+    if (w.long_blocks) {
+        if (e0) HIPCHK(hipEventRecord(e0, st));
+        KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &w, d->n_cu, st));
+        if (e0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
+    }
     KCHK(utk_vote(&d->kimg, d_out, &w, n_reads, st));
 fail:
     return rc;
@@ -412,7 +418,8 @@ fail:
 }
 
 const char *utree_classify_kernel_name(const utree_dev *d) {
-    return d ? utk_classify_short_name(d->hdr.W, d->hdr.I) : "";
+    if (!d) return "";
+    return d->last_long ? utk_classify_long_name() : utk_classify_short_name(d->hdr.W, d->hdr.I);
 }
 
 int utree_classify_kernel_time(utree_dev *d, int reset, double *ms_total, uint64_t *launches) {

@@ -12,7 +12,7 @@ struct utree_dev {
     utree_image_header hdr;
     utk_image kimg;
     /* HIP-event timing of the dominant kernel (enabled by the first utree_classify_kernel_time call) */
-    int timing_on, n_pending, n_events;
+    int timing_on, n_pending, n_events, last_long;   /* last_long: the last batch's dominant kernel was classify_long_k */
     void *events[2 * UTREE_MAX_PENDING];
     double ms_total;
     uint64_t launches;

@@ -313,15 +313,6 @@ __device__ __forceinline__ void base_code(uint32_t b, uint32_t &code, bool &bad)
     code = g ^ (g >> 1);
 }
 
-// Byte j of the staged sequence of read (o, L): forward strand, then (RC only) a separator that breaks
-// every window, then the reverse complement (itree.c:891-898).  Positions past the end are "bad".
-__device__ __forceinline__ void staged_base(const uint8_t *__restrict__ bases, uint64_t o, uint32_t L, uint32_t total,
-                                            uint32_t j, uint32_t &code, bool &bad) {
-    code = 0; bad = true;
-    if (j < L) base_code(bases[o + j], code, bad);
-    else if (j > L && j < total) { base_code(bases[o + (2 * L - j)], code, bad); code ^= 3u; }
-}
-
 // k-mer word of the window that starts at base i, from the big-endian packed 2-bit stream in LDS
 // (word j holds bases 16j..16j+15, base 16j in the top two bits).  itree.c:924: first base most significant.
 template <int W> __device__ __forceinline__ void window_word(const uint32_t *sw, uint32_t i, uint64_t &khi, uint64_t &klo) {
@@ -354,7 +345,8 @@ constexpr uint32_t TALLY_CHUNK = UTREE_TALLY_CHUNK;
 constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read waits for vote_k
 
 // 8 waves/SIMD for the default record format measured 4 % faster than 5 (r01: 325 vs 313 M reads/s) even with a
-// few spilled dwords; the wider formats keep their registers.
+// few spilled dwords; the wider formats keep their registers.  (Voting inside this kernel, 64 parked reads per
+// wave, was tried and measured slower at every occupancy: 295-331 vs 343 M reads/s with the separate vote_k.)
 template <int W, int I, bool EXC, typename OFF>
 __global__ __launch_bounds__(256, (W == 8 && I == 2) ? 8 : 5) void classify_short_k(utk_image im, const uint8_t *__restrict__ bases,
                                                         const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
@@ -800,5 +792,6 @@ const char *utk_classify_short_name(uint32_t W, uint32_t I) {
     (void)W; (void)I;
     return "classify_short_k";
 }
+const char *utk_classify_long_name(void) { return "classify_long_k"; }
 
 }  // extern "C"

@@ -80,6 +80,7 @@ int utk_vote(const utk_image *im, utree_result *d_out, const utk_workspace *ws, 
 int utk_lookup(const utk_image *im, const uint64_t *d_hi, const uint64_t *d_lo, uint64_t n, uint32_t *d_ix,
                void *stream);
 const char *utk_classify_short_name(uint32_t W, uint32_t I);
+const char *utk_classify_long_name(void);
 
 #ifdef __cplusplus
 }
