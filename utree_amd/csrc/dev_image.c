@@ -341,7 +341,7 @@ int utree_dev_get_info(const utree_dev *d, utree_dev_info *info) {
 }
 
 /* ---- batches --------------------------------------------------------------------------------- */
-#define LONG_BLOCKS_PER_CU 2
+#define LONG_BLOCKS_PER_CU 8
 
 static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc,
                   utk_workspace *w, size_t *bytes) {
@@ -352,12 +352,15 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
     w->tally_cap = ((do_rc ? 2 : 1) * total_bases + (uint64_t)n_reads) * 9 / 8 + (uint64_t)d->n_cu * 32 * UTREE_TALLY_CHUNK + 4096;
     w->tally = (uint64_t *)(b + off); off = align_up(off + w->tally_cap * 8, 256);
     w->long_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
+    w->mid_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
     uint64_t max_total = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
-    w->long_blocks = 0; w->hist = NULL;
-    if (max_total > UTREE_SHORT_CAP) {
+    w->long_blocks = 0; w->hist = NULL; w->touch = NULL;
+    w->mid_reads = max_total > UTREE_SHORT_CAP;
+    if (max_total > UTREE_MID_CAP) {
         w->long_blocks = (uint32_t)d->n_cu * LONG_BLOCKS_PER_CU;
         if (w->long_blocks > n_reads) w->long_blocks = n_reads;
         w->hist = (uint32_t *)(b + off); off = align_up(off + (uint64_t)w->long_blocks * d->hdr.n_labels * 4, 256);
+        w->touch = (uint32_t *)(b + off); off = align_up(off + (uint64_t)w->long_blocks * ((d->hdr.n_labels + 31) / 32) * 4, 256);
     }
     *bytes = (size_t)off;
 }
@@ -382,7 +385,10 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     if (workspace_bytes < need) return UTREE_E_ARG;
     HIPCHK(hipSetDevice(d->device));
     HIPCHK(hipMemsetAsync(w.cursors, 0, 512, st));
-    if (w.long_blocks) HIPCHK(hipMemsetAsync(w.hist, 0, (size_t)w.long_blocks * d->hdr.n_labels * 4, st));
+    if (w.long_blocks) {
+        HIPCHK(hipMemsetAsync(w.hist, 0, (size_t)w.long_blocks * d->hdr.n_labels * 4, st));
+        HIPCHK(hipMemsetAsync(w.touch, 0, (size_t)w.long_blocks * ((d->hdr.n_labels + 31) / 32) * 4, st));
+    }
     /* HIP events on the launch stream bracket the dominant kernel (bench.py's roofline leg) */
     hipEvent_t e0 = NULL, e1 = NULL;
     if (d->timing_on && d->n_pending < UTREE_MAX_PENDING) {
@@ -392,11 +398,19 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
         }
         e0 = d->events[2 * d->n_pending]; e1 = d->events[2 * d->n_pending + 1];
     }
-    /* the bracket goes around the batch's dominant kernel: the long-read kernel when the batch has long reads */
-    d->last_long = w.long_blocks != 0;
-    if (e0 && !w.long_blocks) HIPCHK(hipEventRecord(e0, st));
+    /* the bracket goes around the batch's dominant kernel: the long-read kernel when the batch has long reads,
+     * else the mid-length pass when it has mid-length reads, else the 150-bp-class kernel */
+    const int dominant = w.long_blocks ? 2 : (w.mid_reads ? 1 : 0);
+    d->last_long = dominant == 2;
+    if (w.mid_reads) KCHK(utk_route(d_len, n_reads, do_rc, &w, st));
+    if (e0 && dominant == 0) HIPCHK(hipEventRecord(e0, st));
     KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
-    if (e0 && !w.long_blocks) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
+    if (e0 && dominant == 0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
+    if (w.mid_reads) {
+        if (e0 && dominant == 1) HIPCHK(hipEventRecord(e0, st));
+        KCHK(utk_classify_mid(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
+        if (e0 && dominant == 1) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
+    }
     if (w.long_blocks) {
         if (e0) HIPCHK(hipEventRecord(e0, st));
         KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &w, d->n_cu, st));

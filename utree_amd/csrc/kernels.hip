@@ -335,11 +335,35 @@ __device__ __forceinline__ void store_result(utree_result *out, uint32_t label, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// route_k: only launched when a batch may hold reads beyond SHORT_CAP.  Lists them for the mid-length pass
+// (<= MID_CAP staged bases) or for classify_long_k, with one atomic per wavefront of 64 reads.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void route_k(const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utk_workspace ws) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t total = 0;
+    if (r < n_reads) total = do_rc ? 2 * (uint64_t)len[r] + 1 : len[r];
+    const bool mid = total > UTREE_SHORT_CAP && total <= UTREE_MID_CAP, lng = total > UTREE_MID_CAP;
+    const uint64_t mm = __ballot(mid), ml = __ballot(lng);
+    const uint32_t lane = lane_id();
+    if (mm) {
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&ws.cursors[UTREE_CUR_MID], (unsigned long long)__popcll(mm));
+        b = __shfl(b, 0);
+        if (mid) ws.mid_list[b + lanes_below(mm)] = r;
+    }
+    if (ml) {
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&ws.cursors[UTREE_CUR_LONG], (unsigned long long)__popcll(ml));
+        b = __shfl(b, 0);
+        if (lng) ws.long_list[b + lanes_below(ml)] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // classify_short: one wavefront per read (reads whose staged length fits UTREE_SHORT_CAP bases)
 // ------------------------------------------------------------------------------------------------
-constexpr int SHORT_CAP = UTREE_SHORT_CAP;
-constexpr int SHORT_NCH = SHORT_CAP / 64;
-constexpr int SHORT_WORDS = SHORT_CAP / 16 + 6;
+constexpr int SHORT_CAP = UTREE_SHORT_CAP;          // 150 bp + reverse strand fits
+constexpr int MID_CAP = UTREE_MID_CAP;              // 1 kb + reverse strand fits; longer reads take classify_long_k
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr uint32_t TALLY_CHUNK = UTREE_TALLY_CHUNK;
 constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read waits for vote_k
@@ -347,15 +371,19 @@ constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read w
 // 8 waves/SIMD for the default record format measured 4 % faster than 5 (r01: 325 vs 313 M reads/s) even with a
 // few spilled dwords; the wider formats keep their registers.  (Voting inside this kernel, 64 parked reads per
 // wave, was tried and measured slower at every occupancy: 295-331 vs 343 M reads/s with the separate vote_k.)
-template <int W, int I, bool EXC, typename OFF>
-__global__ __launch_bounds__(256, (W == 8 && I == 2) ? 8 : 5) void classify_short_k(utk_image im, const uint8_t *__restrict__ bases,
-                                                        const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
-                                                        uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
-                                                        utk_workspace ws) {
+// CAP = staged bases a wavefront's LDS slice holds.  CAP = SHORT_CAP walks all reads of the batch and routes the
+// longer ones to the mid / long lists; CAP = MID_CAP (LISTED) walks the mid list.  Its 37 KB of LDS per
+// workgroup allow 4 workgroups per CU, so it may use 128 VGPRs.
+template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED>
+__global__ __launch_bounds__(256, CAP > SHORT_CAP ? 4 : ((W == 8 && I == 2) ? 8 : 5))
+void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
+                      const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
+                      utk_workspace ws) {
     constexpr uint32_t K = 4 * W;
-    __shared__ uint32_t s_words[WAVES_PER_BLOCK][SHORT_WORDS];
-    __shared__ uint64_t s_bad[WAVES_PER_BLOCK][SHORT_NCH + 2];
-    __shared__ uint32_t s_hits[WAVES_PER_BLOCK][SHORT_CAP];
+    constexpr int NCH = CAP / 64, NWORDS = CAP / 16 + 6;
+    __shared__ uint32_t s_words[WAVES_PER_BLOCK][NWORDS];
+    __shared__ uint64_t s_bad[WAVES_PER_BLOCK][NCH + 2];
+    __shared__ uint32_t s_hits[WAVES_PER_BLOCK][CAP];
     const uint32_t lane = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
     uint32_t *sw = s_words[wv];
@@ -366,14 +394,16 @@ __global__ __launch_bounds__(256, (W == 8 && I == 2) ? 8 : 5) void classify_shor
     unsigned long long chunk_base = 0;
     uint32_t chunk_left = 0;
 
-    for (uint32_t r = wave_gid; r < n_reads; r += n_waves) {
+    const uint32_t n_items = LISTED ? (uint32_t)ws.cursors[UTREE_CUR_MID] : n_reads;
+    for (uint32_t item = wave_gid; item < n_items; item += n_waves) {
+        const uint32_t r = LISTED ? ws.mid_list[item] : item;
         const uint32_t L = len[r];
         const uint64_t o = off[r];
-        const uint32_t total = do_rc ? 2 * L + 1 : L;
-        if (total > SHORT_CAP) {                           // handed to classify_long
-            if (lane == 0) ws.long_list[atomicAdd(&ws.cursors[UTREE_CUR_LONG], 1ull)] = r;
+        const uint64_t total64 = do_rc ? 2 * (uint64_t)L + 1 : L;
+        if (total64 > (uint64_t)CAP) {                     // route_k listed it for the mid-length pass or classify_long_k
             continue;
         }
+        const uint32_t total = (uint32_t)total64;
         if (total < K) {                                   // no window: no hit, no output line
             if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0);
             continue;
@@ -381,26 +411,30 @@ __global__ __launch_bounds__(256, (W == 8 && I == 2) ? 8 : 5) void classify_shor
         const uint32_t nwin = total - K + 1;
         const uint32_t nch = (total + 63) >> 6;
         // ---- stage: bytes -> 2-bit codes packed big-endian in LDS, bad-base ballots ----
-        // all byte loads of the read are issued before the first one is consumed
-        uint32_t raw[SHORT_NCH];
+        // byte loads are issued in groups (the whole read for CAP = SHORT_CAP) before the first one is consumed
+        constexpr int G = NCH <= 5 ? NCH : 4;
+        for (uint32_t c0 = 0; c0 < nch; c0 += G) {
+            uint32_t raw[G];
 #pragma unroll
-        for (int c = 0; c < SHORT_NCH; ++c) {
-            const uint32_t j = c * 64 + lane;
-            raw[c] = 0;
-            if (j < L) raw[c] = bases[o + j];
-            else if (j > L && j < total) raw[c] = 0x100u | bases[o + (2 * L - j)];      // reverse strand: complement
-        }
+            for (int g = 0; g < G; ++g) {
+                const uint32_t j = (c0 + g) * 64 + lane;
+                raw[g] = 0;
+                if (j < L) raw[g] = bases[o + j];
+                else if (j > L && j < total) raw[g] = 0x100u | bases[o + (2 * L - j)];      // reverse strand: complement
+            }
 #pragma unroll
-        for (int c = 0; c < SHORT_NCH; ++c) {
-            if ((uint32_t)c < nch) {
-                uint32_t code; bool bad;
-                base_code(raw[c] & 0xFFu, code, bad);
-                code ^= (raw[c] >> 8) * 3u;
-                uint64_t bm = __ballot(bad);
-                uint32_t t = (code << 2) | (uint32_t)__shfl_down((int)code, 1);
-                uint32_t u = (t << 4) | (uint32_t)__shfl_down((int)t, 2);
-                if ((lane & 3u) == 0) sb[(c * 16 + (lane >> 2)) ^ 3u] = (uint8_t)u;
-                if (lane == 0) sbad[c] = bm;
+            for (int g = 0; g < G; ++g) {
+                const uint32_t c = c0 + g;
+                if (c < nch) {
+                    uint32_t code; bool bad;
+                    base_code(raw[g] & 0xFFu, code, bad);
+                    code ^= (raw[g] >> 8) * 3u;
+                    uint64_t bm = __ballot(bad);
+                    uint32_t t = (code << 2) | (uint32_t)__shfl_down((int)code, 1);
+                    uint32_t u = (t << 4) | (uint32_t)__shfl_down((int)t, 2);
+                    if ((lane & 3u) == 0) sb[(c * 16 + (lane >> 2)) ^ 3u] = (uint8_t)u;
+                    if (lane == 0) sbad[c] = bm;
+                }
             }
         }
         if (lane == 0) sbad[nch] = ~0ull;
@@ -478,12 +512,14 @@ __global__ __launch_bounds__(256, (W == 8 && I == 2) ? 8 : 5) void classify_shor
 }
 
 // ------------------------------------------------------------------------------------------------
-// classify_long: one workgroup per read, any length (itree.c:836: lines up to 16 MiB).  The read is
-// walked in tiles staged through LDS; hits go to a per-workgroup label histogram in HBM (rank order),
-// which is then compacted into the same sorted (rank,count) list the short path emits.
+// classify_long: one workgroup per read, any length (itree.c:836: lines up to 16 MiB).  The read is walked in
+// tiles staged through LDS (two table slots in flight per lane); hits go to a per-workgroup label histogram in
+// HBM and set a bit in a touched-label bitmap; the bitmap is then swept in rank order, which yields the same
+// sorted (rank,count) list the wave kernel emits, and only touched histogram entries are read and cleared.
 // ------------------------------------------------------------------------------------------------
 constexpr int LONG_TILE = 4096;                       // windows per tile
 constexpr int LONG_THREADS = 256;
+constexpr uint32_t LONG_LDS_BITWORDS = 2048;          // labels whose bitmap fits LDS (65 536); else a bitmap in HBM
 
 template <int W, int I, bool EXC, typename OFF>
 __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, const uint8_t *__restrict__ bases,
@@ -495,12 +531,17 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
     __shared__ uint32_t s_words[STAGE / 16 + 8];
     __shared__ uint64_t s_bad[STAGE / 64 + 2];
     __shared__ uint32_t s_scan[LONG_THREADS / 64 + 1];
+    __shared__ uint32_t s_touch[LONG_LDS_BITWORDS];
     __shared__ unsigned long long s_base;
     __shared__ uint32_t s_first;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     uint8_t *sb = (uint8_t *)s_words;
-    uint32_t *hist = ws.hist + (size_t)blockIdx.x * im.n_labels;     // all zero between reads
+    const uint32_t nl = im.n_labels, nbw = (nl + 31) >> 5;
+    uint32_t *hist = ws.hist + (size_t)blockIdx.x * nl;                       // all zero between reads
+    uint32_t *touch = nbw <= LONG_LDS_BITWORDS ? s_touch : ws.touch + (size_t)blockIdx.x * nbw;   // all zero between reads
     const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
+    if (nbw <= LONG_LDS_BITWORDS) for (uint32_t x = tid; x < nbw; x += LONG_THREADS) s_touch[x] = 0;
+    __syncthreads();
 
     for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) {
         const uint32_t r = ws.long_list[li];
@@ -510,7 +551,6 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
         const uint64_t nwin = total >= K ? total - K + 1 : 0;
         uint32_t my_hits = 0;
         if (tid == 0) s_first = INVALID;
-        __syncthreads();
         for (uint64_t w0 = 0; w0 < nwin; w0 += LONG_TILE) {
             // stage bases [w0, w0+STAGE)
             for (uint32_t c = wv; c < STAGE / 64; c += LONG_THREADS / 64) {
@@ -526,16 +566,34 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
             }
             if (tid == 0) s_bad[STAGE / 64] = ~0ull;
             __syncthreads();
-            uint64_t tile_n = nwin - w0 < LONG_TILE ? nwin - w0 : LONG_TILE;
-            for (uint32_t i = tid; i < tile_n; i += LONG_THREADS) {
-                uint32_t ch = i >> 6, bit = i & 63u;
-                uint64_t x = (s_bad[ch] >> bit) | (bit ? (s_bad[ch + 1] << (64 - bit)) : 0ull);
-                bool ok = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
-                if (ok) {
-                    uint64_t khi, klo;
-                    window_word<W>(s_words, i, khi, klo);
-                    uint32_t rank = lookup_word<W, I, EXC, OFF>(im, khi, klo);
-                    if (rank != INVALID) { atomicAdd(&hist[rank], 1u); ++my_hits; }
+            const uint32_t tile_n = (uint32_t)(nwin - w0 < LONG_TILE ? nwin - w0 : LONG_TILE);
+            for (uint32_t i0 = tid; i0 < tile_n; i0 += 2 * LONG_THREADS) {
+                bool ok[2]; uint32_t p[2]; Key<W> q[2]; uint64_t slot[2]; Entry<W, I> t[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t i = i0 + h * LONG_THREADS;
+                    ok[h] = false;
+                    if (i < tile_n) {
+                        const uint32_t ch = i >> 6, bit = i & 63u;
+                        uint64_t x = (s_bad[ch] >> bit) | (bit ? (s_bad[ch + 1] << (64 - bit)) : 0ull);
+                        ok[h] = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
+                    }
+                    if (ok[h]) {
+                        uint64_t khi, klo;
+                        window_word<W>(s_words, i, khi, klo);
+                        split_word<W>(im, khi, klo, p[h], q[h], slot[h]);
+                        t[h] = load_slot<W, I>(im.table, slot[h]);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (!ok[h]) continue;
+                    const uint32_t rank = resolve_entry<W, I, EXC, OFF>(im, t[h], p[h], q[h]);
+                    if (rank != INVALID) {                              // itree.c:929-931
+                        atomicAdd(&hist[rank], 1u);
+                        atomicOr(&touch[rank >> 5], 1u << (rank & 31u));
+                        ++my_hits;
+                    }
                 }
             }
             __syncthreads();
@@ -548,16 +606,12 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
         for (uint32_t w = 0; w < LONG_THREADS / 64; ++w) F += s_scan[w];
         __syncthreads();
         if (F == 0) { if (tid == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); continue; }
-        // count distinct labels, then compact the histogram in rank order (and zero it again)
-        // make the other waves' global atomics visible to this workgroup's plain loads
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const uint32_t nl = im.n_labels;
-        const uint32_t per = (nl + LONG_THREADS - 1) / LONG_THREADS;
-        const uint32_t lo = tid * per, hi = (lo + per < nl) ? lo + per : nl;
+        // the other waves' global atomics are complete (barrier above waits vmcnt) and live in L2: read them there
+        const uint32_t per = (nbw + LONG_THREADS - 1) / LONG_THREADS;
+        const uint32_t lo = tid * per < nbw ? tid * per : nbw, hi = lo + per < nbw ? lo + per : nbw;
         uint32_t cnt = 0;
-        for (uint32_t x = lo; x < hi; ++x) cnt += __hip_atomic_load(&hist[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        // exclusive prefix over threads: wave scan + wave totals
-        uint32_t inc = cnt;
+        for (uint32_t x = lo; x < hi; ++x) cnt += (uint32_t)__popc(__hip_atomic_load(&touch[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        uint32_t inc = cnt;                               // inclusive prefix over threads: wave scan + wave totals
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d); if (lane >= (uint32_t)d) inc += t; }
         if (lane == 63) s_scan[wv] = inc;
@@ -569,12 +623,17 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
         __syncthreads();
         const unsigned long long base = s_base;
         for (uint32_t x = lo; x < hi; ++x) {
-            uint32_t c = __hip_atomic_load(&hist[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c) {
-                if (uix > 1) ws.tally[base + pos] = (uint64_t)x | ((uint64_t)c << 32);
-                else s_first = x;
+            uint32_t bits = __hip_atomic_load(&touch[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!bits) continue;
+            __hip_atomic_store(&touch[x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (bits) {
+                const uint32_t rk = x * 32 + (uint32_t)__builtin_ctz(bits);
+                bits &= bits - 1;
+                const uint32_t c = __hip_atomic_load(&hist[rk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&hist[rk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (uix > 1) ws.tally[base + pos] = (uint64_t)rk | ((uint64_t)c << 32);
+                else s_first = rk;
                 ++pos;
-                __hip_atomic_store(&hist[x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -757,7 +816,26 @@ int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64
     uint32_t cap = (uint32_t)n_cu * 8u;
     if (blocks > cap) blocks = cap;
     return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
-        classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt)>
+        classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT_CAP, false>
+            <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+    });
+}
+
+int utk_route(const uint32_t *d_len, uint32_t n_reads, int do_rc, const utk_workspace *ws, void *stream) {
+    if (!n_reads) return 0;
+    route_k<<<dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(d_len, n_reads, do_rc, *ws);
+    return (int)hipGetLastError();
+}
+
+// reads of 321..2112 staged bases, listed by route_k
+int utk_classify_mid(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
+                     uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+    if (!n_reads) return 0;
+    uint32_t blocks = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    uint32_t cap = (uint32_t)n_cu * 4u;
+    if (blocks > cap) blocks = cap;
+    return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
+        classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), MID_CAP, true>
             <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
     });
 }

@@ -15,7 +15,9 @@ extern "C" {
 #define UTREE_IMG_HEADER_BYTES 4096u
 #define UTREE_TALLY_CHUNK 4096u                  /* tally entries a wave reserves with one atomic              */
 #define UTREE_CUR_LONG 32                        /* cursors[] index of the long-read counter (own 256-B line)   */
-#define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds */
+#define UTREE_CUR_MID 16                         /* ... of the mid-length-read counter                           */
+#define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds      */
+#define UTREE_MID_CAP 2112u                      /* ... and its mid-length instantiation; longer: classify_long */
 
 /* image flags */
 #define UTREE_F_IRREGULAR 1u   /* some bins are not strictly ascending: bitmap present, exact probe path   */
@@ -67,13 +69,18 @@ typedef struct {
     uint64_t *tally;                 /* (rank, count) pairs packed as rank | count<<32                        */
     uint64_t tally_cap;
     uint32_t *long_list;             /* [n_reads]                                                             */
+    uint32_t *mid_list;              /* [n_reads]                                                             */
     uint32_t *hist;                  /* long path: [long_blocks][n_labels]                                    */
-    uint32_t long_blocks;
+    uint32_t *touch;                 /* long path: touched-label bitmap when it does not fit LDS              */
+    uint32_t long_blocks, mid_reads; /* mid_reads != 0: the batch may hold mid-length reads                   */
 } utk_workspace;
 
 int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                        uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu,
                        void *stream);
+int utk_route(const uint32_t *d_len, uint32_t n_reads, int do_rc, const utk_workspace *ws, void *stream);
+int utk_classify_mid(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
+                     uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_classify_long(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                       int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_vote(const utk_image *im, utree_result *d_out, const utk_workspace *ws, uint32_t n_reads, void *stream);
