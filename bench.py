@@ -96,8 +96,9 @@ def main():
     if world > 1:
         meta = None
         if rank == 0:
-            meta = dict(label_text=sdb.label_text, image_bytes=tree.image_tensor().numel(), W=W, n_nodes=args.nodes)
-        image, m, bcast_s = udist.broadcast_image(tree.image_tensor() if rank == 0 else None, meta, 0, dev)
+            used = tree.image_ptr()[1]                      # the built image may be smaller than its allocation
+            meta = dict(label_text=sdb.label_text, image_bytes=used, W=W, n_nodes=args.nodes)
+        image, m, bcast_s = udist.broadcast_image(tree.image_tensor()[:used] if rank == 0 else None, meta, 0, dev)
         if rank != 0:
             dummy_bins = np.zeros((1 << 24) + 1, dtype=np.uint64)
             dummy_bins[-1] = m["n_nodes"]

@@ -3,8 +3,9 @@
  * The image replaces UTree.Dump / UTree.BinIx (itree.c:140-141) as XT_getIX32 (itree.c:720) sees them.
  * Layout in HBM (one flat allocation, offsets only -- DESIGN.md §3):
  *
- *   [header 4 KiB][direct-mapped prefix table: 2^(24+F) slots][records: N x {suffix, rank}, sorted as in the file]
+ *   [header 4 KiB][table over 24+F minimizer-hash bits][MIN records: nodes by (minimizer hash, position, rest)]
  *   [bin table 2^24+1][irregular-bin bitmap 2 MiB][label offsets][labels in strcmp order][rank -> file index]
+ *   [FILE records: nodes as the file orders them -- kept in the image only when some bin needs the exact probe path]
  */
 #define _FILE_OFFSET_BITS 64
 #define _GNU_SOURCE
@@ -51,7 +52,7 @@ int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
 
 static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     memset(h, 0, sizeof *h);
-    h->magic = UTREE_IMG_MAGIC; h->version = 2;
+    h->magic = UTREE_IMG_MAGIC; h->version = 3;
     h->W = ctr->info.W; h->I = ctr->info.I; h->k = ctr->info.k;
     h->fine_bits = F; h->rec_words = utree_rec_words(h->W, h->I);
     h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
@@ -59,7 +60,7 @@ static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     h->n_slots = 1ull << (24 + F);
     uint64_t off = UTREE_IMG_HEADER_BYTES;
     h->off_table = off; off = align_up(off + h->n_slots * h->rec_words * 8, 4096);
-    h->off_recs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 4096);
+    h->off_mrecs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 4096);
     h->off_coarse = off; off = align_up(off + (uint64_t)UTREE_NUMBINS * ((h->flags & UTREE_F_OFF64) ? 8 : 4), 256);
     h->off_irreg = off; off = align_up(off + (1u << 24) / 8, 256);
     h->off_label_off = off; off = align_up(off + ((uint64_t)h->n_labels + 1) * 4, 256);
@@ -67,7 +68,9 @@ static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     for (uint32_t i = 0; i < h->n_labels; ++i) blob += (uint64_t)ctr->label_len[i] + 1;
     h->label_blob_bytes = blob;
     h->off_label_blob = off; off = align_up(off + blob + 64, 256);
-    h->off_rank2ix = off; off = align_up(off + (uint64_t)h->n_labels * 4, 256);
+    h->off_rank2ix = off; off = align_up(off + (uint64_t)h->n_labels * 4, 4096);
+    /* last, so that an image without irregular bins can leave it out of what is broadcast */
+    h->off_recs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 4096);
     h->total_bytes = off;
 }
 
@@ -81,6 +84,7 @@ size_t utree_dev_image_bytes(const utree_ctr *ctr, int fine_bits) {
 static void bind_image(utree_dev *d) {
     char *b = (char *)d->image;
     d->kimg.table = (const uint64_t *)(b + d->hdr.off_table);
+    d->kimg.mrecs = (const uint64_t *)(b + d->hdr.off_mrecs);
     d->kimg.recs = (const uint64_t *)(b + d->hdr.off_recs);
     d->kimg.coarse = b + d->hdr.off_coarse;
     d->kimg.irreg = (const uint32_t *)(b + d->hdr.off_irreg);
@@ -195,19 +199,35 @@ static int build_finish(builder *b, const void *d_binix_raw) {
     HIPCHK(hipMemcpyAsync(counters, b->d_counters, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     d->hdr.n_irregular = counters[0];
+    uint64_t full_bytes = d->hdr.total_bytes;
     if (counters[1]) {
         /* bin table not monotone (never written by the reference's COMPRESS): trust it verbatim like the
          * reference does -- every bin takes the exact probe path over [BinIx[p], BinIx[p+1]) */
         d->hdr.flags |= UTREE_F_GENERIC;
         d->hdr.fine_bits = 0;
         d->hdr.n_slots = 1ull << 24;
+        d->hdr.n_min = 0;
         HIPCHK(hipMemsetAsync(img + d->hdr.off_irreg, 0xFF, (1u << 24) / 8, st));
         HIPCHK(hipMemsetAsync(img + d->hdr.off_table, 0, d->hdr.n_slots * d->hdr.rec_words * 8, st));
     } else {
         if (counters[0]) d->hdr.flags |= UTREE_F_IRREGULAR;
-        KCHK(utk_build_table(d->hdr.W, d->hdr.I, off64, coarse, recs, d->hdr.fine_bits,
-                             (uint64_t *)(img + d->hdr.off_table), st));
+        /* a monotone table reaches the contiguous node range [BinIx[0], BinIx[2^24]) */
+        uint64_t c0, cN;
+        if (ctr->info.binix_width == 4) { uint32_t a, z; memcpy(&a, ctr->binix_raw, 4); memcpy(&z, (const char *)ctr->binix_raw + 4 * (size_t)(UTREE_NUMBINS - 1), 4); c0 = a; cN = z; }
+        else { memcpy(&c0, ctr->binix_raw, 8); memcpy(&cN, (const char *)ctr->binix_raw + 8 * (size_t)(UTREE_NUMBINS - 1), 8); }
+        d->hdr.n_min = cN - c0;
+        HIPCHK(hipMemsetAsync(b->d_counters, 0, 16, st));
+        KCHK(utk_build_min(d->hdr.W, d->hdr.I, off64, coarse, recs, c0, d->hdr.n_min, 24 + d->hdr.fine_bits,
+                           (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs), b->d_counters, st));
+        KCHK(utk_fill_recs_pad((uint64_t *)(img + d->hdr.off_mrecs) + d->hdr.n_min * d->hdr.rec_words, 8 * d->hdr.rec_words, st));
+        HIPCHK(hipMemcpyAsync(counters, b->d_counters, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (counters[0]) { rc = UTREE_E_UNSUPPORTED; goto fail; }       /* >= 2^22 nodes share one table slot */
+        /* nothing reads the FILE records when every bin is ascending: leave them out of the image */
+        if (!(d->hdr.flags & UTREE_F_IRREGULAR)) d->hdr.total_bytes = d->hdr.off_recs;
     }
+    (void)full_bytes;
+    d->image_bytes = d->hdr.total_bytes;
     HIPCHK(hipMemcpyAsync(img, &d->hdr, sizeof d->hdr, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     bind_image(d);
@@ -309,7 +329,7 @@ int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t byt
     if (!d) return UTREE_E_NOMEM;
     d->device = device; d->n_cu = n_cu; d->image = d_image; d->owns = 0;
     HIPCHK(hipMemcpy(&d->hdr, d_image, sizeof d->hdr, hipMemcpyDeviceToHost));
-    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 2 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
+    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 3 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
     if (ctr && (ctr->info.W != d->hdr.W || ctr->info.I != d->hdr.I || ctr->info.n_nodes != d->hdr.n_nodes ||
                 ctr->info.n_labels != d->hdr.n_labels)) { rc = UTREE_E_ARG; goto fail; }
     d->image_bytes = d->hdr.total_bytes;

@@ -1,0 +1,227 @@
+// device_common.hpp -- device-side formats shared by kernels.hip (search) and image_build.hip (load time).
+//
+// Two record formats live in the device image:
+//
+//  FILE records  -- the node dump as the .ctr orders it (ascending inside each 24-bit-prefix bin), one per
+//                   node, EW 8-byte words: {flag8=0 | rank16 | suffix40} (k=32, u16 labels) ... used by the
+//                   load-time kernels and by the reference-exact probe path (bins that are not ascending).
+//  MIN records   -- the same nodes re-ordered by (minimizer hash, position, rest): the bucket of a k-mer is
+//                   the hash of its MINIMIZER (the 16-mer of the k-mer with the smallest hash), so the ~8
+//                   consecutive windows of a read that share a minimizer probe the same 128-B lines.
+//                   {flag2 | key | rank16}: key = {low hash bits | minimizer position | the other k-16 bases}.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "utree_internal.h"
+
+namespace utk {
+
+constexpr uint64_t M40 = (1ull << 40) - 1;
+constexpr uint32_t INVALID = 0xFFFFFFFFu;
+
+template <int W, int I> struct RecTraits {
+    static constexpr int EW = (W == 16 ? 2 : 1) * (I == 4 ? 2 : 1);   // 8-byte words per record / table slot
+    static constexpr int KW = (W == 16 ? 1 : 0);                       // word holding the top key bits, flag, rank16
+};
+template <int W, int I> struct Entry { uint64_t w[RecTraits<W, I>::EW]; };
+
+template <int W, int I> __device__ __forceinline__ Entry<W, I> load_entry(const uint64_t *base, uint64_t i) {
+    constexpr int EW = RecTraits<W, I>::EW;
+    Entry<W, I> e;
+    if constexpr (EW == 1) e.w[0] = base[i];
+    else if constexpr (EW == 2) {
+        const ulonglong2 v = *(const ulonglong2 *)(base + i * 2);
+        e.w[0] = v.x; e.w[1] = v.y;
+    } else {
+        const ulonglong2 v0 = *(const ulonglong2 *)(base + i * 4), v1 = *(const ulonglong2 *)(base + i * 4 + 2);
+        e.w[0] = v0.x; e.w[1] = v0.y; e.w[2] = v1.x; e.w[3] = v1.y;
+    }
+    return e;
+}
+// Table slots are read once per lookup from a table far larger than any cache: the non-temporal policy
+// (`nt`) serves such random lines ~12 % faster than the default one (profiles/r01/membench_cache_policy.txt).
+template <int W, int I> __device__ __forceinline__ Entry<W, I> load_slot(const uint64_t *base, uint64_t i) {
+    constexpr int EW = RecTraits<W, I>::EW;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    Entry<W, I> e;
+    if constexpr (EW == 1) e.w[0] = __builtin_nontemporal_load(base + i);
+    else if constexpr (EW == 2) {
+        const u64x2 v = __builtin_nontemporal_load((const u64x2 *)(base + i * 2));
+        e.w[0] = v.x; e.w[1] = v.y;
+    } else {
+        const u64x2 v0 = __builtin_nontemporal_load((const u64x2 *)(base + i * 4));
+        const u64x2 v1 = __builtin_nontemporal_load((const u64x2 *)(base + i * 4 + 2));
+        e.w[0] = v0.x; e.w[1] = v0.y; e.w[2] = v1.x; e.w[3] = v1.y;
+    }
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FILE records: key = the stored suffix (low 8*(W-3) bits of the word), as the reference compares it
+//   W=8, I=2: {0 | rank16 | suffix40}      W=8, I=4: {suffix40}{rank32}
+//   W=16,I=2: {lo64}{0 | rank16 | hi40}    W=16,I=4: {lo64}{hi40}{rank32}{0}
+// ------------------------------------------------------------------------------------------------
+template <int W> struct Key { uint64_t hi, lo; };   // hi = top 40 suffix bits for W=16, else 0
+
+template <int W> __device__ __forceinline__ bool key_eq(const Key<W> &a, const Key<W> &b) {
+    if constexpr (W == 16) return a.lo == b.lo && a.hi == b.hi; else return a.lo == b.lo;
+}
+template <int W> __device__ __forceinline__ bool key_lt(const Key<W> &a, const Key<W> &b) {
+    if constexpr (W == 16) return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); else return a.lo < b.lo;
+}
+template <int W> __device__ __forceinline__ bool key_le(const Key<W> &a, const Key<W> &b) { return !key_lt<W>(b, a); }
+
+template <int W, int I> __device__ __forceinline__ Key<W> file_key(const uint64_t *recs, uint64_t i) {
+    constexpr int EW = RecTraits<W, I>::EW;
+    Key<W> k;
+    if constexpr (W == 16) { const ulonglong2 v = *(const ulonglong2 *)(recs + i * EW); k.lo = v.x; k.hi = v.y & M40; }
+    else { k.lo = recs[i * EW] & M40; k.hi = 0; }
+    return k;
+}
+template <int W, int I> __device__ __forceinline__ uint32_t file_rank(const uint64_t *recs, uint64_t i) {
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+    if constexpr (I == 4) return (uint32_t)recs[i * EW + KW + 1];
+    else {
+        uint32_t r = (uint32_t)(recs[i * EW + KW] >> 40) & 0xFFFFu;
+        return r == 0xFFFFu ? INVALID : r;
+    }
+}
+// split of the 2k-bit word khi:klo into 24-bit prefix (itree.c:684) and suffix key (itree.c:685)
+template <int W> __device__ __forceinline__ uint32_t word_prefix(uint64_t khi, uint64_t klo) {
+    return (uint32_t)(((W == 16) ? khi : klo) >> 40);
+}
+template <int W> __device__ __forceinline__ Key<W> word_suffix(uint64_t khi, uint64_t klo) {
+    Key<W> q;
+    if constexpr (W == 16) { q.hi = khi & M40; q.lo = klo; } else { q.hi = 0; q.lo = klo & M40; }
+    return q;
+}
+
+// The reference's probe sequence, verbatim in behaviour (itree.c:699-707, 728): p = first record of the
+// bin; over the remaining e-s-1 records probe record w+1 past p; "<= query" moves p there.
+template <int W, int I> __device__ uint32_t exact_probe(const uint64_t *recs, uint64_t s, uint64_t e, const Key<W> &q) {
+    uint64_t p = s, size = e - s - 1;
+    while (size) {
+        uint64_t w = size >> 1;
+        Key<W> k = file_key<W, I>(recs, p + w + 1);
+        if (key_le<W>(k, q)) { p += w + 1; size -= w + 1; }
+        else size = w;
+    }
+    Key<W> k = file_key<W, I>(recs, p);
+    return key_eq<W>(k, q) ? file_rank<W, I>(recs, p) : INVALID;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Minimizers.  m = 16 bases (32 bits); the minimizer of a k-mer is its 16-mer with the smallest mix32()
+// (leftmost on ties).  mix32 is a bijection on 32 bits, so a table slot of B <= 32 hash bits plus the
+// remaining 32-B bits identify the minimizer exactly, and {position, the other k-16 bases} the k-mer.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
+// MIN key: W=8: lo = {hlow8 | pos5 | rest32} (45 bits), hi unused.  W=16: lo = low 64 bits of the 96-bit rest,
+// hi = {hlow8 | pos6 | rest_hi32} (46 bits).
+template <int W> struct MinKey { uint64_t hi, lo; };
+template <int W> __device__ __forceinline__ bool mkey_eq(const MinKey<W> &a, const MinKey<W> &b) {
+    if constexpr (W == 16) return a.lo == b.lo && a.hi == b.hi; else return a.lo == b.lo;
+}
+template <int W> __device__ __forceinline__ bool mkey_lt(const MinKey<W> &a, const MinKey<W> &b) {
+    if constexpr (W == 16) return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); else return a.lo < b.lo;
+}
+
+// Minimizer of the word khi:klo -> hash h, position pos, and the bases outside the minimizer.
+// W=8 : rest = 16 bases (32 bits) in rest_lo.   W=16: rest = 48 bases (96 bits) in rest_hi32:rest_lo.
+template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_t klo, uint32_t &h, uint32_t &pos,
+                                                          uint32_t &rest_hi32, uint64_t &rest_lo) {
+    if constexpr (W == 8) {
+        uint32_t best = mix32((uint32_t)(klo >> 32)), bj = 0;
+#pragma unroll
+        for (uint32_t j = 1; j <= 16; ++j) {
+            const uint32_t hh = mix32((uint32_t)(klo >> (32 - 2 * j)));
+            if (hh < best) { best = hh; bj = j; }
+        }
+        h = best; pos = bj;
+        const uint64_t left = bj ? klo >> (64 - 2 * bj) : 0ull;                     // the bj bases before the minimizer
+        const uint64_t right = klo & ((1ull << (32 - 2 * bj)) - 1);                 // the 16-bj bases after it
+        rest_lo = (left << (32 - 2 * bj)) | right;
+        rest_hi32 = 0;
+    } else {
+        const unsigned __int128 w = ((unsigned __int128)khi << 64) | klo;
+        uint32_t best = mix32((uint32_t)(w >> 96)), bj = 0;
+        for (uint32_t j = 1; j <= 48; ++j) {
+            const uint32_t hh = mix32((uint32_t)(w >> (96 - 2 * j)));
+            if (hh < best) { best = hh; bj = j; }
+        }
+        h = best; pos = bj;
+        const unsigned __int128 left = bj ? w >> (128 - 2 * bj) : (unsigned __int128)0;
+        const unsigned __int128 right = w & ((((unsigned __int128)1) << (96 - 2 * bj)) - 1);
+        const unsigned __int128 rest = (left << (96 - 2 * bj)) | right;
+        rest_lo = (uint64_t)rest;
+        rest_hi32 = (uint32_t)(rest >> 64);
+    }
+}
+
+// table slot and MIN key of a word for a table of 2^B slots
+template <int W> __device__ __forceinline__ void min_split(uint64_t khi, uint64_t klo, uint32_t B, uint64_t &slot, MinKey<W> &mk) {
+    uint32_t h, pos, rh; uint64_t rl;
+    minimizer<W>(khi, klo, h, pos, rh, rl);
+    slot = (uint64_t)h >> (32 - B);
+    const uint64_t hlow = (uint64_t)h & ((1ull << (32 - B)) - 1);
+    if constexpr (W == 8) { mk.hi = 0; mk.lo = (hlow << 37) | ((uint64_t)pos << 32) | rl; }
+    else { mk.lo = rl; mk.hi = (hlow << 38) | ((uint64_t)pos << 32) | rh; }
+}
+
+// MIN records / table slots.  flag (top 2 bits of word KW): 0 record, 1 empty slot, 2 run {count22 | start40}
+//   W=8, I=2: {flag2 | 0 | key45 | rank16}                  W=8, I=4: {flag2 | 0 | key45 | 0}{rank32}
+//   W=16,I=2: {rest lo64}{flag2 | key_hi46 | rank16}        W=16,I=4: {rest lo64}{flag2 | key_hi46 | 0}{rank32}{0}
+constexpr uint64_t MFLAG_EMPTY = 1ull << 62, MFLAG_RUN = 2ull << 62;
+constexpr uint64_t M46 = (1ull << 46) - 1;
+
+template <int W, int I> __device__ __forceinline__ uint32_t mrec_flag(const Entry<W, I> &e) { return (uint32_t)(e.w[RecTraits<W, I>::KW] >> 62); }
+template <int W, int I> __device__ __forceinline__ MinKey<W> mrec_key(const Entry<W, I> &e) {
+    MinKey<W> k;
+    if constexpr (W == 16) { k.lo = e.w[0]; k.hi = (e.w[1] >> 16) & M46; } else { k.hi = 0; k.lo = (e.w[0] >> 16) & M46; }
+    return k;
+}
+template <int W, int I> __device__ __forceinline__ uint32_t mrec_rank(const Entry<W, I> &e) {
+    if constexpr (I == 4) return (uint32_t)e.w[RecTraits<W, I>::KW + 1];
+    else { uint32_t r = (uint32_t)e.w[RecTraits<W, I>::KW] & 0xFFFFu; return r == 0xFFFFu ? INVALID : r; }
+}
+template <int W, int I> __device__ __forceinline__ Entry<W, I> make_mrec(const MinKey<W> &k, uint32_t rank) {
+    Entry<W, I> e;
+#pragma unroll
+    for (int j = 0; j < RecTraits<W, I>::EW; ++j) e.w[j] = 0;
+    const uint64_t r16 = (I == 2) ? (rank == INVALID ? 0xFFFFull : (uint64_t)(rank & 0xFFFFu)) : 0ull;
+    if constexpr (W == 16) { e.w[0] = k.lo; e.w[1] = (k.hi << 16) | r16; } else { e.w[0] = (k.lo << 16) | r16; }
+    if constexpr (I == 4) e.w[RecTraits<W, I>::KW + 1] = rank;
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dispatch on (W, I) and on the image flavour
+// ------------------------------------------------------------------------------------------------
+template <int V> using IC = std::integral_constant<int, V>;
+
+template <typename Fn> int dispatch_wi(uint32_t W, uint32_t I, Fn &&fn) {
+    if (W == 8 && I == 2) fn(IC<8>{}, IC<2>{});
+    else if (W == 8 && I == 4) fn(IC<8>{}, IC<4>{});
+    else if (W == 16 && I == 2) fn(IC<16>{}, IC<2>{});
+    else if (W == 16 && I == 4) fn(IC<16>{}, IC<4>{});
+    else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+template <typename Fn> int dispatch_img(const utk_image *im, Fn &&fn) {
+    const bool exc = (im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC)) != 0;
+    const bool o64 = (im->flags & UTREE_F_OFF64) != 0;
+    return dispatch_wi(im->W, im->I, [&](auto w, auto i) {
+        if (exc && o64) fn(w, i, std::true_type{}, uint64_t{});
+        else if (exc) fn(w, i, std::true_type{}, uint32_t{});
+        else if (o64) fn(w, i, std::false_type{}, uint64_t{});
+        else fn(w, i, std::false_type{}, uint32_t{});
+    });
+}
+
+}  // namespace utk

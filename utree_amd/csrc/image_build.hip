@@ -1,0 +1,265 @@
+// image_build.hip -- load-time kernels: turn the on-disk pieces of a .ctr (bin table + packed node dump, already in
+// HBM) into the device image of DESIGN.md §3.  Runs once per database; everything here streams or sorts.
+//
+//   repack_k     on-disk SZ-byte records -> FILE records (8-byte words, label index -> strcmp rank)
+//   widen/validate   bin table at the image's offset width; per-bin "strictly ascending" check (irregular bitmap)
+//   assign_k     per node: minimizer hash, position, rest, 24-bit prefix
+//   (rocprim radix sorts: nodes ordered by (hash, position, rest))
+//   emit_k       MIN records in that order
+//   table_k      direct-mapped table over the top B hash bits: empty / the single record inline / run descriptor
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "device_common.hpp"
+
+using namespace utk;
+
+namespace {
+
+template <int W, int I>
+__global__ void repack_k(const uint8_t *__restrict__ raw, uint64_t count, const uint32_t *__restrict__ ix2rank,
+                         uint32_t n_labels, uint64_t *__restrict__ recs) {
+    constexpr int SZ = W + I - 3, SB = W - 3, EW = RecTraits<W, I>::EW;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *p = raw + i * SZ;
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            if (b < 8) lo |= (uint64_t)p[b] << (8 * b); else hi |= (uint64_t)p[b] << (8 * (b - 8));
+        }
+        uint32_t ix = 0;
+#pragma unroll
+        for (int b = 0; b < I; ++b) ix |= (uint32_t)p[SB + b] << (8 * b);
+        uint32_t rank = ix < n_labels ? ix2rank[ix] : INVALID;      // itree.c:929 `ix < maxIX`
+        uint64_t *o = recs + i * EW;
+        const uint64_t r16 = rank == INVALID ? 0xFFFFull : (uint64_t)rank;
+        if constexpr (W == 8 && I == 2) { o[0] = lo | (r16 << 40); }
+        else if constexpr (W == 8 && I == 4) { o[0] = lo; o[1] = rank; }
+        else if constexpr (W == 16 && I == 2) { o[0] = lo; o[1] = hi | (r16 << 40); }
+        else { o[0] = lo; o[1] = hi; o[2] = rank; o[3] = 0; }
+    }
+}
+
+// bin table: on-disk width -> the image's OFF width (zero-extended, itree.c:756-759)
+template <typename OFF> __global__ void widen_binix_k(const void *raw, uint32_t width, OFF *coarse) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= UTREE_NUMBINS) return;
+    coarse[i] = (OFF)(width == 4 ? (uint64_t)((const uint32_t *)raw)[i] : ((const uint64_t *)raw)[i]);
+}
+
+template <int W, int I, typename OFF>
+__global__ void validate_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t n_nodes,
+                           uint32_t *irreg, unsigned long long *counters) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= UTREE_NUMBINS - 1) return;
+    uint64_t s = coarse[p], e = coarse[p + 1];
+    if (s > e || e > n_nodes) { counters[1] = 1; return; }
+    if (e - s < 2) return;
+    Key<W> prev = file_key<W, I>(recs, s);
+    for (uint64_t j = s + 1; j < e; ++j) {
+        Key<W> cur = file_key<W, I>(recs, j);
+        if (!key_lt<W>(prev, cur)) {
+            atomicOr(&irreg[p >> 5], 1u << (p & 31));
+            atomicAdd(&counters[0], 1ull);
+            return;
+        }
+        prev = cur;
+    }
+}
+
+__global__ void fill_pad_k(uint64_t *p, uint32_t words) {
+    if (threadIdx.x < words) p[threadIdx.x] = ~0ull;
+}
+__global__ void fill_u64_k(uint64_t *p, uint64_t n, uint64_t v, uint32_t stride, uint32_t at) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i * stride + at] = v;
+}
+template <typename IDX> __global__ void iota_k(IDX *p, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = (IDX)i;
+}
+template <typename IDX, typename T> __global__ void gather_k(const T *__restrict__ src, const IDX *__restrict__ idx, T *__restrict__ dst, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+
+// one thread per 24-bit bin: minimizer pieces of every node the bin table reaches (nodes [c0, cN))
+template <int W, int I, typename OFF>
+__global__ void assign_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t c0,
+                         uint32_t *__restrict__ H, uint64_t *__restrict__ K1, uint64_t *__restrict__ K2) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= UTREE_NUMBINS - 1) return;
+    const uint64_t s = coarse[p], e = coarse[p + 1];
+    for (uint64_t j = s; j < e; ++j) {
+        const Key<W> k = file_key<W, I>(recs, j);
+        uint64_t khi, klo;
+        if constexpr (W == 16) { khi = ((uint64_t)p << 40) | k.hi; klo = k.lo; } else { khi = 0; klo = ((uint64_t)p << 40) | k.lo; }
+        uint32_t h, pos, rh; uint64_t rl;
+        minimizer<W>(khi, klo, h, pos, rh, rl);
+        H[j - c0] = h;
+        if constexpr (W == 16) { K1[j - c0] = rl; K2[j - c0] = ((uint64_t)pos << 32) | rh; }
+        else K1[j - c0] = ((uint64_t)pos << 32) | rl;
+    }
+}
+
+// MIN record j = node idx[j] (relative to c0) in the final (hash, pos, rest) order
+template <int W, int I, typename IDX>
+__global__ void emit_k(const uint64_t *__restrict__ recs, uint64_t c0, const IDX *__restrict__ idx, const uint32_t *__restrict__ H,
+                       const uint64_t *__restrict__ K1, const uint64_t *__restrict__ K2, uint32_t B, uint64_t m,
+                       uint64_t *__restrict__ out, uint32_t *__restrict__ Hs) {
+    constexpr int EW = RecTraits<W, I>::EW;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = idx[j];
+        const uint32_t h = H[i];
+        const uint64_t hlow = (uint64_t)h & ((1ull << (32 - B)) - 1);
+        MinKey<W> mk;
+        if constexpr (W == 16) { mk.lo = K1[i]; mk.hi = (hlow << 38) | K2[i]; } else { mk.hi = 0; mk.lo = (hlow << 37) | K1[i]; }
+        const Entry<W, I> e = make_mrec<W, I>(mk, file_rank<W, I>(recs, c0 + i));
+#pragma unroll
+        for (int x = 0; x < EW; ++x) out[j * EW + x] = e.w[x];
+        Hs[j] = h;
+    }
+}
+
+template <int W, int I>
+__global__ void table_k(const uint32_t *__restrict__ Hs, const uint64_t *__restrict__ mrecs, uint64_t m, uint32_t B,
+                        uint64_t *__restrict__ table, unsigned long long *overflow) {
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = (uint64_t)Hs[j] >> (32 - B);
+        if (j && ((uint64_t)Hs[j - 1] >> (32 - B)) == b) continue;          // not the first node of its slot
+        uint64_t n = 1;
+        while (j + n < m && ((uint64_t)Hs[j + n] >> (32 - B)) == b) ++n;
+        uint64_t *o = table + b * EW;
+        if (n == 1) {
+#pragma unroll
+            for (int x = 0; x < EW; ++x) o[x] = mrecs[j * EW + x];            // flag bits of a record are 0
+        } else {
+            if (n >= (1ull << 22)) { atomicAdd(overflow, 1ull); n = (1ull << 22) - 1; }
+#pragma unroll
+            for (int x = 0; x < EW; ++x) o[x] = 0;
+            o[KW] = MFLAG_RUN | (n << 40) | (j & M40);
+        }
+    }
+}
+
+unsigned grid_for(uint64_t n) {
+    uint64_t b = (n + 255) / 256;
+    return (unsigned)(b > (1u << 20) ? (1u << 20) : (b ? b : 1));
+}
+
+// stable LSD pass: order idx by key[idx] (bits [0, nbits))
+template <typename IDX>
+int sort_pass(const uint64_t *key_by_node, uint32_t nbits, IDX *&idx, IDX *&idx_alt, uint64_t *kg, uint64_t *kg_alt, uint64_t m,
+              void *tmp, size_t tmp_bytes, hipStream_t st) {
+    gather_k<IDX, uint64_t><<<grid_for(m), 256, 0, st>>>(key_by_node, idx, kg, m);
+    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kg, kg_alt, idx, idx_alt, m, 0, nbits, st);
+    if (e != hipSuccess) return (int)e;
+    IDX *t = idx; idx = idx_alt; idx_alt = t;
+    return (int)hipGetLastError();
+}
+template <typename IDX>
+int sort_pass32(const uint32_t *key_by_node, IDX *&idx, IDX *&idx_alt, uint32_t *kg, uint32_t *kg_alt, uint64_t m, void *tmp,
+                size_t tmp_bytes, hipStream_t st) {
+    gather_k<IDX, uint32_t><<<grid_for(m), 256, 0, st>>>(key_by_node, idx, kg, m);
+    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kg, kg_alt, idx, idx_alt, m, 0, 32, st);
+    if (e != hipSuccess) return (int)e;
+    IDX *t = idx; idx = idx_alt; idx_alt = t;
+    return (int)hipGetLastError();
+}
+
+// the whole MIN structure for nodes [c0, c0+m): table (2^B slots, pre-filled here) and MIN records
+template <int W, int I, typename OFF, typename IDX>
+int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, uint32_t B, uint64_t *table, uint64_t *mrecs,
+              unsigned long long *d_overflow, hipStream_t st) {
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+    const uint64_t nslots = 1ull << B;
+    for (int x = 0; x < EW; ++x) fill_u64_k<<<grid_for(nslots), 256, 0, st>>>(table, nslots, x == KW ? MFLAG_EMPTY : 0ull, EW, x);
+    if (!m) return (int)hipGetLastError();
+    uint32_t *H = nullptr, *Hg = nullptr, *Hg2 = nullptr;
+    uint64_t *K1 = nullptr, *K2 = nullptr, *kg = nullptr, *kg2 = nullptr;
+    IDX *idx = nullptr, *idx2 = nullptr;
+    void *tmp = nullptr;
+    size_t t64 = 0, t32 = 0;
+    int rc = 0;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto done; } } while (0)
+    CK(hipMalloc((void **)&H, m * 4)); CK(hipMalloc((void **)&K1, m * 8));
+    if (W == 16) CK(hipMalloc((void **)&K2, m * 8));
+    CK(hipMalloc((void **)&idx, m * sizeof(IDX))); CK(hipMalloc((void **)&idx2, m * sizeof(IDX)));
+    CK(hipMalloc((void **)&kg, m * 8)); CK(hipMalloc((void **)&kg2, m * 8));
+    CK(rocprim::radix_sort_pairs(nullptr, t64, kg, kg2, idx, idx2, m, 0, 64, st));
+    CK(rocprim::radix_sort_pairs(nullptr, t32, (uint32_t *)kg, (uint32_t *)kg2, idx, idx2, m, 0, 32, st));
+    if (t32 > t64) t64 = t32;
+    CK(hipMalloc(&tmp, t64 ? t64 : 8));
+    assign_k<W, I, OFF><<<(UTREE_NUMBINS + 255) / 256, 256, 0, st>>>(coarse, recs, c0, H, K1, K2);
+    iota_k<IDX><<<grid_for(m), 256, 0, st>>>(idx, m);
+    // least significant key first; every pass is stable
+    if (W == 16) {
+        if ((rc = sort_pass<IDX>(K1, 64, idx, idx2, kg, kg2, m, tmp, t64, st))) goto done;      // rest, low 64 bits
+        if ((rc = sort_pass<IDX>(K2, 38, idx, idx2, kg, kg2, m, tmp, t64, st))) goto done;      // position | rest high 32
+    } else {
+        if ((rc = sort_pass<IDX>(K1, 37, idx, idx2, kg, kg2, m, tmp, t64, st))) goto done;      // position | rest
+    }
+    Hg = (uint32_t *)kg; Hg2 = (uint32_t *)kg2;
+    if ((rc = sort_pass32<IDX>(H, idx, idx2, Hg, Hg2, m, tmp, t64, st))) goto done;             // minimizer hash
+    // Hg2 now holds the sorted hashes but emit_k recomputes them from H[idx]: reuse Hg as the sorted-hash array
+    emit_k<W, I, IDX><<<grid_for(m), 256, 0, st>>>(recs, c0, idx, H, K1, K2, B, m, mrecs, Hg);
+    table_k<W, I><<<grid_for(m), 256, 0, st>>>(Hg, mrecs, m, B, table, d_overflow);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(st));
+done:
+#undef CK
+    (void)hipFree(H); (void)hipFree(K1); (void)hipFree(K2); (void)hipFree(idx); (void)hipFree(idx2); (void)hipFree(kg);
+    (void)hipFree(kg2); (void)hipFree(tmp);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int utk_repack(uint32_t W_, uint32_t I_, const void *d_raw, uint64_t count, const uint32_t *d_ix2rank,
+               uint32_t n_labels, uint64_t *d_recs, void *stream) {
+    if (!count) return 0;
+    return dispatch_wi(W_, I_, [&](auto w, auto i) {
+        repack_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(count) > 65536 ? 65536 : grid_for(count)), dim3(256), 0, (hipStream_t)stream>>>(
+            (const uint8_t *)d_raw, count, d_ix2rank, n_labels, d_recs);
+    });
+}
+
+int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_coarse, void *stream) {
+    if (off64) widen_binix_k<uint64_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(d_raw_binix, width, (uint64_t *)d_coarse);
+    else widen_binix_k<uint32_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(d_raw_binix, width, (uint32_t *)d_coarse);
+    return (int)hipGetLastError();
+}
+
+int utk_validate(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
+                 uint32_t *d_irreg, unsigned long long *d_counters, void *stream) {
+    return dispatch_wi(W_, I_, [&](auto w, auto i) {
+        constexpr int W = decltype(w)::value, I = decltype(i)::value;
+        if (off64) validate_k<W, I, uint64_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+            (const uint64_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
+        else validate_k<W, I, uint32_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+            (const uint32_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
+    });
+}
+
+int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream) {
+    fill_pad_k<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(d_recs_end, words);
+    return (int)hipGetLastError();
+}
+
+/* nodes [c0, c0+m) = what the (monotone) bin table reaches.  d_overflow[0] += slots with >= 2^22 nodes. */
+int utk_build_min(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
+                  uint32_t table_bits, uint64_t *d_table, uint64_t *d_mrecs, unsigned long long *d_overflow, void *stream) {
+    int rc = 0;
+    int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
+        constexpr int W = decltype(w)::value, I = decltype(i)::value;
+        hipStream_t st = (hipStream_t)stream;
+        const bool idx64 = m >= 0xFFFFFFFFull;
+        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, table_bits, d_table, d_mrecs, d_overflow, st);
+        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, table_bits, d_table, d_mrecs, d_overflow, st);
+        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, table_bits, d_table, d_mrecs, d_overflow, st);
+    });
+    return rc ? rc : drc;
+}
+
+}  // extern "C"

@@ -13,271 +13,68 @@
 //   lookup_k        XT_getIX32 alone (tests, micro-benchmarks)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
-#include "utree_internal.h"
+#include "device_common.hpp"
+
+using namespace utk;
 
 namespace {
 
-constexpr uint64_t M40 = (1ull << 40) - 1;
-constexpr uint32_t INVALID = 0xFFFFFFFFu;
-
 // ------------------------------------------------------------------------------------------------
-// keys, records, table entries
+// XT_getIX32 (itree.c:720-730) on the device image
 // ------------------------------------------------------------------------------------------------
-// One format serves both the sorted record array and the direct-mapped prefix table.
-// EW 8-byte words per record (a power of two, so an entry never straddles a 128-B line):
-//   W=8, I=2 (EW 1): {flag8 | rank16 | suffix40}
-//   W=8, I=4 (EW 2): {flag8 | 0 | suffix40} {rank32}
-//   W=16,I=2 (EW 2): {suffix lo64} {flag8 | rank16 | suffix hi40}
-//   W=16,I=4 (EW 4): {suffix lo64} {flag8 | 0 | suffix hi40} {rank32} {0}
-// flag (top byte of the word holding the top suffix bits): 0 = a record, 1 = empty table slot,
-// 2 = table slot that points at a run of >= 2 records: {2 | count16 | start40}.
-template <int W> struct Key { uint64_t hi, lo; };   // hi = top 40 suffix bits for W=16, else 0
-
-template <int W> __device__ __forceinline__ bool key_eq(const Key<W> &a, const Key<W> &b) {
-    if constexpr (W == 16) return a.lo == b.lo && a.hi == b.hi; else return a.lo == b.lo;
-}
-template <int W> __device__ __forceinline__ bool key_lt(const Key<W> &a, const Key<W> &b) {
-    if constexpr (W == 16) return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); else return a.lo < b.lo;
-}
-template <int W> __device__ __forceinline__ bool key_le(const Key<W> &a, const Key<W> &b) { return !key_lt<W>(b, a); }
-
-template <int W, int I> struct RecTraits {
-    static constexpr int EW = (W == 16 ? 2 : 1) * (I == 4 ? 2 : 1);
-    static constexpr int KW = (W == 16 ? 1 : 0);            // word with the top suffix bits and the flag
-};
-constexpr uint64_t FLAG_EMPTY = 1ull << 56, FLAG_RUN = 2ull << 56;
-
-template <int W, int I> struct Entry { uint64_t w[RecTraits<W, I>::EW]; };
-
-template <int W, int I> __device__ __forceinline__ Entry<W, I> load_entry(const uint64_t *base, uint64_t i) {
-    constexpr int EW = RecTraits<W, I>::EW;
-    Entry<W, I> e;
-    if constexpr (EW == 1) e.w[0] = base[i];
-    else if constexpr (EW == 2) {
-        const ulonglong2 v = *(const ulonglong2 *)(base + i * 2);
-        e.w[0] = v.x; e.w[1] = v.y;
-    } else {
-        const ulonglong2 v0 = *(const ulonglong2 *)(base + i * 4), v1 = *(const ulonglong2 *)(base + i * 4 + 2);
-        e.w[0] = v0.x; e.w[1] = v0.y; e.w[2] = v1.x; e.w[3] = v1.y;
-    }
-    return e;
-}
-// Table slots are read once per lookup from a table far larger than any cache: the non-temporal policy
-// (`nt`) serves such random lines ~12 % faster than the default one (profiles/r01/membench_cache_policy.txt).
-template <int W, int I> __device__ __forceinline__ Entry<W, I> load_slot(const uint64_t *base, uint64_t i) {
-    constexpr int EW = RecTraits<W, I>::EW;
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    Entry<W, I> e;
-    if constexpr (EW == 1) e.w[0] = __builtin_nontemporal_load(base + i);
-    else if constexpr (EW == 2) {
-        const u64x2 v = __builtin_nontemporal_load((const u64x2 *)(base + i * 2));
-        e.w[0] = v.x; e.w[1] = v.y;
-    } else {
-        const u64x2 v0 = __builtin_nontemporal_load((const u64x2 *)(base + i * 4));
-        const u64x2 v1 = __builtin_nontemporal_load((const u64x2 *)(base + i * 4 + 2));
-        e.w[0] = v0.x; e.w[1] = v0.y; e.w[2] = v1.x; e.w[3] = v1.y;
-    }
-    return e;
-}
-template <int W, int I> __device__ __forceinline__ Key<W> entry_key(const Entry<W, I> &e) {
-    Key<W> k;
-    if constexpr (W == 16) { k.lo = e.w[0]; k.hi = e.w[1] & M40; } else { k.lo = e.w[0] & M40; k.hi = 0; }
-    return k;
-}
-template <int W, int I> __device__ __forceinline__ uint32_t entry_rank(const Entry<W, I> &e) {
-    if constexpr (I == 4) return (uint32_t)e.w[RecTraits<W, I>::KW + 1];
-    else {
-        uint32_t r = (uint32_t)(e.w[RecTraits<W, I>::KW] >> 40) & 0xFFFFu;
-        return r == 0xFFFFu ? INVALID : r;
-    }
-}
-template <int W, int I> __device__ __forceinline__ uint32_t entry_flag(const Entry<W, I> &e) {
-    return (uint32_t)(e.w[RecTraits<W, I>::KW] >> 56);
-}
-template <int W, int I> __device__ __forceinline__ Key<W> load_key(const uint64_t *recs, uint64_t i) {
-    constexpr int EW = RecTraits<W, I>::EW;
-    Key<W> k;
-    if constexpr (W == 16) { const ulonglong2 v = *(const ulonglong2 *)(recs + i * EW); k.lo = v.x; k.hi = v.y & M40; }
-    else { k.lo = recs[i * EW] & M40; k.hi = 0; }
-    return k;
-}
-template <int W, int I> __device__ __forceinline__ uint32_t load_rank(const uint64_t *recs, uint64_t i) {
-    return entry_rank<W, I>(load_entry<W, I>(recs, i));
-}
-
-// The reference's probe sequence, verbatim in behaviour (itree.c:699-707, 728): p = first record of the
-// bin; over the remaining e-s-1 records probe record w+1 past p; "<= query" moves p there.
-template <int W, int I> __device__ uint32_t exact_probe(const uint64_t *recs, uint64_t s, uint64_t e, const Key<W> &q) {
-    uint64_t p = s, size = e - s - 1;
-    while (size) {
-        uint64_t w = size >> 1;
-        Key<W> k = load_key<W, I>(recs, p + w + 1);
-        if (key_le<W>(k, q)) { p += w + 1; size -= w + 1; }
-        else size = w;
-    }
-    Key<W> k = load_key<W, I>(recs, p);
-    return key_eq<W>(k, q) ? load_rank<W, I>(recs, p) : INVALID;
-}
-
-// exact-match search in a strictly ascending run [lo, hi): equals the reference's result there
-template <int W, int I> __device__ uint32_t sorted_find(const uint64_t *recs, uint64_t lo, uint64_t hi, const Key<W> &q) {
-    while (lo < hi) {
-        uint64_t mid = lo + ((hi - lo) >> 1);
-        Key<W> k = load_key<W, I>(recs, mid);
-        if (key_lt<W>(k, q)) lo = mid + 1;
-        else if (key_eq<W>(k, q)) return load_rank<W, I>(recs, mid);
-        else hi = mid;
-    }
-    return INVALID;
-}
-
 template <typename OFF> __device__ __forceinline__ void coarse_bin(const utk_image &im, uint32_t p, uint64_t &s, uint64_t &e) {
     const OFF *c = (const OFF *)im.coarse;
     s = c[p]; e = c[p + 1];                                      // itree.c:724
 }
 
-// Second half of a lookup, given the table entry of the word's (24+F)-bit prefix.
+// exact-match search in a run of MIN records that ascends by key
+template <int W, int I> __device__ uint32_t min_find(const uint64_t *mrecs, uint64_t lo, uint64_t hi, const MinKey<W> &q) {
+    while (lo < hi) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        const Entry<W, I> e = load_entry<W, I>(mrecs, mid);
+        const MinKey<W> k = mrec_key<W, I>(e);
+        if (mkey_lt<W>(k, q)) lo = mid + 1;
+        else if (mkey_eq<W>(k, q)) return mrec_rank<W, I>(e);
+        else hi = mid;
+    }
+    return INVALID;
+}
+
+// Second half of a lookup, given the table slot of the word's minimizer.  Words whose 24-bit bin is not
+// strictly ascending (COMPRESS' first-bin quirk) or any word of a non-monotone table take the reference's own
+// probe sequence over the FILE records instead: only that reproduces its answers there.
 template <int W, int I, bool EXC, typename OFF>
-__device__ __forceinline__ uint32_t resolve_entry(const utk_image &im, const Entry<W, I> &t, uint32_t p, const Key<W> &q) {
+__device__ __forceinline__ uint32_t resolve_entry(const utk_image &im, const Entry<W, I> &t, const MinKey<W> &mk, uint64_t khi,
+                                                  uint64_t klo) {
     if constexpr (EXC) {
-        if ((im.irreg[p >> 5] >> (p & 31)) & 1u) {               // bin not strictly ascending (or generic mode)
+        const uint32_t p = word_prefix<W>(khi, klo);
+        if ((im.irreg[p >> 5] >> (p & 31)) & 1u) {
             uint64_t s, e;
             coarse_bin<OFF>(im, p, s, e);
             if (s >= e || e > im.n_nodes) return INVALID;        // itree.c:726
-            return exact_probe<W, I>(im.recs, s, e, q);
+            return exact_probe<W, I>(im.recs, s, e, word_suffix<W>(khi, klo));
         }
     }
-    const uint32_t flag = entry_flag<W, I>(t);
-    if (flag == 0) return key_eq<W>(entry_key<W, I>(t), q) ? entry_rank<W, I>(t) : INVALID;   // the bin's only record
-    if (flag == 1) return INVALID;                                                            // empty fine bin
-    // a run of >= 2 records in the sorted array
+    const uint32_t flag = mrec_flag<W, I>(t);
+    if (flag == 0) return mkey_eq<W>(mrec_key<W, I>(t), mk) ? mrec_rank<W, I>(t) : INVALID;   // the slot's only node
+    if (flag == 1) return INVALID;                                                            // empty slot
     const uint64_t d = t.w[RecTraits<W, I>::KW];
-    uint64_t start = d & M40, cnt = (d >> 40) & 0xFFFFu, end = start + cnt;
-    if (cnt == 0xFFFFu) { uint64_t s; coarse_bin<OFF>(im, p, s, end); if (start < s) start = s; }   // saturated: search to the bin end
-    const Entry<W, I> r0 = load_entry<W, I>(im.recs, start), r1 = load_entry<W, I>(im.recs, start + 1);
-    const Key<W> k0 = entry_key<W, I>(r0), k1 = entry_key<W, I>(r1);
-    if (key_eq<W>(k0, q)) return entry_rank<W, I>(r0);
-    if (key_lt<W>(q, k0)) return INVALID;
-    if (key_eq<W>(k1, q)) return entry_rank<W, I>(r1);
-    if (end - start == 2 || key_lt<W>(q, k1)) return INVALID;
-    return sorted_find<W, I>(im.recs, start + 2, end, q);
+    const uint64_t start = d & M40, end = start + ((d >> 40) & 0x3FFFFFull);
+    const Entry<W, I> r0 = load_entry<W, I>(im.mrecs, start), r1 = load_entry<W, I>(im.mrecs, start + 1);
+    const MinKey<W> k0 = mrec_key<W, I>(r0), k1 = mrec_key<W, I>(r1);
+    if (mkey_eq<W>(k0, mk)) return mrec_rank<W, I>(r0);
+    if (mkey_lt<W>(mk, k0)) return INVALID;
+    if (mkey_eq<W>(k1, mk)) return mrec_rank<W, I>(r1);
+    if (end - start == 2 || mkey_lt<W>(mk, k1)) return INVALID;
+    return min_find<W, I>(im.mrecs, start + 2, end, mk);
 }
 
-// split of the 2k-bit word khi:klo into 24-bit prefix (itree.c:684), suffix key and table slot
-template <int W> __device__ __forceinline__ void split_word(const utk_image &im, uint64_t khi, uint64_t klo, uint32_t &p,
-                                                            Key<W> &q, uint64_t &slot) {
-    const uint64_t top = (W == 16) ? khi : klo;           // the 64 bits holding prefix (24) + first 40 suffix bits
-    p = (uint32_t)(top >> 40);
-    if constexpr (W == 16) { q.hi = khi & M40; q.lo = klo; } else { q.hi = 0; q.lo = klo & M40; }
-    slot = top >> (40 - im.fine_bits);
-}
-
-// XT_getIX32 (itree.c:720-730) on the device image: ONE 128-B line for all but the few percent of words
-// whose fine bin holds two or more records.
 template <int W, int I, bool EXC, typename OFF>
 __device__ __forceinline__ uint32_t lookup_word(const utk_image &im, uint64_t khi, uint64_t klo) {
-    uint32_t p; Key<W> q; uint64_t slot;
-    split_word<W>(im, khi, klo, p, q, slot);
+    uint64_t slot; MinKey<W> mk;
+    min_split<W>(khi, klo, 24 + im.fine_bits, slot, mk);
     const Entry<W, I> t = load_slot<W, I>(im.table, slot);
-    return resolve_entry<W, I, EXC, OFF>(im, t, p, q);
-}
-
-// ------------------------------------------------------------------------------------------------
-// load-time kernels
-// ------------------------------------------------------------------------------------------------
-template <int W, int I>
-__global__ void repack_k(const uint8_t *__restrict__ raw, uint64_t count, const uint32_t *__restrict__ ix2rank,
-                         uint32_t n_labels, uint64_t *__restrict__ recs) {
-    constexpr int SZ = W + I - 3, SB = W - 3, EW = RecTraits<W, I>::EW;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint8_t *p = raw + i * SZ;
-        uint64_t lo = 0, hi = 0;
-#pragma unroll
-        for (int b = 0; b < SB; ++b) {
-            if (b < 8) lo |= (uint64_t)p[b] << (8 * b); else hi |= (uint64_t)p[b] << (8 * (b - 8));
-        }
-        uint32_t ix = 0;
-#pragma unroll
-        for (int b = 0; b < I; ++b) ix |= (uint32_t)p[SB + b] << (8 * b);
-        uint32_t rank = ix < n_labels ? ix2rank[ix] : INVALID;      // itree.c:929 `ix < maxIX`
-        uint64_t *o = recs + i * EW;
-        const uint64_t r16 = rank == INVALID ? 0xFFFFull : (uint64_t)rank;
-        if constexpr (W == 8 && I == 2) { o[0] = lo | (r16 << 40); }
-        else if constexpr (W == 8 && I == 4) { o[0] = lo; o[1] = rank; }
-        else if constexpr (W == 16 && I == 2) { o[0] = lo; o[1] = hi | (r16 << 40); }
-        else { o[0] = lo; o[1] = hi; o[2] = rank; o[3] = 0; }
-    }
-}
-
-// bin table: on-disk width -> the image's OFF width (zero-extended, itree.c:756-759)
-template <typename OFF> __global__ void widen_binix_k(const void *raw, uint32_t width, OFF *coarse) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= UTREE_NUMBINS) return;
-    coarse[i] = (OFF)(width == 4 ? (uint64_t)((const uint32_t *)raw)[i] : ((const uint64_t *)raw)[i]);
-}
-
-template <int W, int I, typename OFF>
-__global__ void validate_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t n_nodes,
-                           uint32_t *irreg, unsigned long long *counters) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= UTREE_NUMBINS - 1) return;
-    uint64_t s = coarse[p], e = coarse[p + 1];
-    if (s > e || e > n_nodes) { counters[1] = 1; return; }
-    if (e - s < 2) return;
-    Key<W> prev = load_key<W, I>(recs, s);
-    for (uint64_t j = s + 1; j < e; ++j) {
-        Key<W> cur = load_key<W, I>(recs, j);
-        if (!key_lt<W>(prev, cur)) {
-            atomicOr(&irreg[p >> 5], 1u << (p & 31));
-            atomicAdd(&counters[0], 1ull);
-            return;
-        }
-        prev = cur;
-    }
-}
-
-// Direct-mapped table over (24+F)-bit prefixes: slot q describes the records of 24-bit bin q>>F whose next
-// F suffix bits equal q & (2^F-1): none, exactly one (stored inline) or a run in the sorted array.
-template <int W, int I, typename OFF>
-__global__ void build_table_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint32_t F,
-                              uint64_t *__restrict__ table) {
-    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
-    const uint64_t nslots = 1ull << (24 + F);
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nslots; q += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t p = q >> F, f = q & ((1ull << F) - 1);
-        const uint64_t s = coarse[p], e = coarse[p + 1];
-        uint64_t fs = s, fe = e;
-        if (s < e) {
-            // first record with (suffix >> (SUF-F)) >= f, and >= f+1
-            auto lower = [&](uint64_t ff) {
-                if (ff >> F) return e;
-                Key<W> t;
-                if constexpr (W == 16) { t.hi = ff << (40 - F); t.lo = 0; } else { t.hi = 0; t.lo = ff << (40 - F); }
-                uint64_t lo = s, hi = e;
-                while (lo < hi) {
-                    uint64_t mid = lo + ((hi - lo) >> 1);
-                    if (key_lt<W>(load_key<W, I>(recs, mid), t)) lo = mid + 1; else hi = mid;
-                }
-                return lo;
-            };
-            fs = f ? lower(f) : s;
-            fe = lower(f + 1);
-        } else fe = fs;
-        uint64_t *o = table + q * EW;
-        const uint64_t n = fe > fs ? fe - fs : 0;
-#pragma unroll
-        for (int j = 0; j < EW; ++j) o[j] = 0;
-        if (n == 0) o[KW] = FLAG_EMPTY;
-        else if (n == 1) {
-#pragma unroll
-            for (int j = 0; j < EW; ++j) o[j] = recs[fs * EW + j];       // flag byte of a record is 0
-        } else o[KW] = FLAG_RUN | ((n < 0xFFFFu ? n : 0xFFFFull) << 40) | (fs & M40);
-    }
-}
-
-__global__ void fill_pad_k(uint64_t *p, uint32_t words) {
-    if (threadIdx.x < words) p[threadIdx.x] = ~0ull;
+    return resolve_entry<W, I, EXC, OFF>(im, t, mk, khi, klo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,6 +188,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     uint64_t *sbad = s_bad[wv];
     uint32_t *hits = s_hits[wv];
     const uint32_t wave_gid = blockIdx.x * WAVES_PER_BLOCK + wv, n_waves = gridDim.x * WAVES_PER_BLOCK;
+    const uint32_t TB = 24 + im.fine_bits;                // table bits
     unsigned long long chunk_base = 0;
     uint32_t chunk_left = 0;
 
@@ -442,7 +240,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933); two rounds of table loads in flight ----
         uint32_t F = 0;
         for (uint32_t it = 0; it * 64 < nwin; it += 2) {
-            bool ok[2]; uint32_t p[2]; Key<W> q[2]; uint64_t slot[2]; Entry<W, I> t[2];
+            bool ok[2]; uint64_t wh[2], wl[2]; MinKey<W> mk[2]; Entry<W, I> t[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const uint32_t i = (it + h) * 64 + lane;
@@ -453,16 +251,16 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                     ok[h] = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
                 }
                 if (ok[h]) {
-                    uint64_t khi, klo;
-                    window_word<W>(sw, i, khi, klo);
-                    split_word<W>(im, khi, klo, p[h], q[h], slot[h]);
-                    t[h] = load_slot<W, I>(im.table, slot[h]);
+                    uint64_t slot;
+                    window_word<W>(sw, i, wh[h], wl[h]);
+                    min_split<W>(wh[h], wl[h], TB, slot, mk[h]);
+                    t[h] = load_slot<W, I>(im.table, slot);
                 }
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 uint32_t rank = INVALID;
-                if (ok[h]) rank = resolve_entry<W, I, EXC, OFF>(im, t[h], p[h], q[h]);
+                if (ok[h]) rank = resolve_entry<W, I, EXC, OFF>(im, t[h], mk[h], wh[h], wl[h]);
                 bool hit = rank != INVALID;                     // itree.c:929-931
                 uint64_t hm = __ballot(hit);
                 if (hit) hits[F + lanes_below(hm)] = rank;
@@ -568,7 +366,7 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
             __syncthreads();
             const uint32_t tile_n = (uint32_t)(nwin - w0 < LONG_TILE ? nwin - w0 : LONG_TILE);
             for (uint32_t i0 = tid; i0 < tile_n; i0 += 2 * LONG_THREADS) {
-                bool ok[2]; uint32_t p[2]; Key<W> q[2]; uint64_t slot[2]; Entry<W, I> t[2];
+                bool ok[2]; uint64_t wh[2], wl[2]; MinKey<W> mk[2]; Entry<W, I> t[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const uint32_t i = i0 + h * LONG_THREADS;
@@ -579,16 +377,16 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
                         ok[h] = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
                     }
                     if (ok[h]) {
-                        uint64_t khi, klo;
-                        window_word<W>(s_words, i, khi, klo);
-                        split_word<W>(im, khi, klo, p[h], q[h], slot[h]);
-                        t[h] = load_slot<W, I>(im.table, slot[h]);
+                        uint64_t slot;
+                        window_word<W>(s_words, i, wh[h], wl[h]);
+                        min_split<W>(wh[h], wl[h], 24 + im.fine_bits, slot, mk[h]);
+                        t[h] = load_slot<W, I>(im.table, slot);
                     }
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if (!ok[h]) continue;
-                    const uint32_t rank = resolve_entry<W, I, EXC, OFF>(im, t[h], p[h], q[h]);
+                    const uint32_t rank = resolve_entry<W, I, EXC, OFF>(im, t[h], mk[h], wh[h], wl[h]);
                     if (rank != INVALID) {                              // itree.c:929-931
                         atomicAdd(&hist[rank], 1u);
                         atomicOr(&touch[rank >> 5], 1u << (rank & 31u));
@@ -733,81 +531,9 @@ __global__ void lookup_k(utk_image im, const uint64_t *__restrict__ hi, const ui
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// dispatch on (W, I, EXC, OFF64)
-// ------------------------------------------------------------------------------------------------
-template <int V> using IC = std::integral_constant<int, V>;
-
-template <typename Fn> int dispatch_wi(uint32_t W, uint32_t I, Fn &&fn) {
-    if (W == 8 && I == 2) fn(IC<8>{}, IC<2>{});
-    else if (W == 8 && I == 4) fn(IC<8>{}, IC<4>{});
-    else if (W == 16 && I == 2) fn(IC<16>{}, IC<2>{});
-    else if (W == 16 && I == 4) fn(IC<16>{}, IC<4>{});
-    else return (int)hipErrorInvalidValue;
-    return (int)hipGetLastError();
-}
-
-template <typename Fn> int dispatch_img(const utk_image *im, Fn &&fn) {
-    const bool exc = (im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC)) != 0;
-    const bool o64 = (im->flags & UTREE_F_OFF64) != 0;
-    return dispatch_wi(im->W, im->I, [&](auto w, auto i) {
-        if (exc && o64) fn(w, i, std::true_type{}, uint64_t{});
-        else if (exc) fn(w, i, std::true_type{}, uint32_t{});
-        else if (o64) fn(w, i, std::false_type{}, uint64_t{});
-        else fn(w, i, std::false_type{}, uint32_t{});
-    });
-}
-
 }  // namespace
 
 extern "C" {
-
-int utk_repack(uint32_t W_, uint32_t I_, const void *d_raw, uint64_t count, const uint32_t *d_ix2rank,
-               uint32_t n_labels, uint64_t *d_recs, void *stream) {
-    if (!count) return 0;
-    uint64_t blocks = (count + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    return dispatch_wi(W_, I_, [&](auto w, auto i) {
-        repack_k<decltype(w)::value, decltype(i)::value><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
-            (const uint8_t *)d_raw, count, d_ix2rank, n_labels, d_recs);
-    });
-}
-
-int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_coarse, void *stream) {
-    if (off64) widen_binix_k<uint64_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(d_raw_binix, width, (uint64_t *)d_coarse);
-    else widen_binix_k<uint32_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(d_raw_binix, width, (uint32_t *)d_coarse);
-    return (int)hipGetLastError();
-}
-
-int utk_validate(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
-                 uint32_t *d_irreg, unsigned long long *d_counters, void *stream) {
-    return dispatch_wi(W_, I_, [&](auto w, auto i) {
-        constexpr int W = decltype(w)::value, I = decltype(i)::value;
-        if (off64) validate_k<W, I, uint64_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
-            (const uint64_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
-        else validate_k<W, I, uint32_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
-            (const uint32_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
-    });
-}
-
-int utk_build_table(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs,
-                    uint32_t fine_bits, uint64_t *d_table, void *stream) {
-    uint64_t nslots = 1ull << (24 + fine_bits);
-    uint64_t blocks = (nslots + 255) / 256;
-    if (blocks > (1u << 20)) blocks = 1u << 20;
-    return dispatch_wi(W_, I_, [&](auto w, auto i) {
-        constexpr int W = decltype(w)::value, I = decltype(i)::value;
-        if (off64) build_table_k<W, I, uint64_t><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
-            (const uint64_t *)d_coarse, d_recs, fine_bits, d_table);
-        else build_table_k<W, I, uint32_t><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
-            (const uint32_t *)d_coarse, d_recs, fine_bits, d_table);
-    });
-}
-
-int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream) {
-    fill_pad_k<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(d_recs_end, words);
-    return (int)hipGetLastError();
-}
 
 int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                        uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {

@@ -31,7 +31,8 @@ typedef struct {
     uint32_t fine_bits, rec_words, n_labels, flags;
     uint64_t n_nodes;
     uint64_t n_slots;                /* 2^(24+fine_bits) table slots                                        */
-    uint64_t off_table, off_recs, off_coarse, off_irreg, off_label_off, off_label_blob, off_rank2ix;
+    uint64_t n_min;                  /* MIN records = nodes the bin table reaches                          */
+    uint64_t off_table, off_mrecs, off_recs, off_coarse, off_irreg, off_label_off, off_label_blob, off_rank2ix;
     uint64_t label_blob_bytes;
     uint64_t n_irregular;
     uint64_t total_bytes;
@@ -39,8 +40,9 @@ typedef struct {
 
 /* What kernels take by value. */
 typedef struct {
-    const uint64_t *table;           /* direct-mapped prefix table, rec_words words per slot                 */
-    const uint64_t *recs;            /* all records, sorted as in the file, rec_words words each             */
+    const uint64_t *table;           /* direct-mapped table over minimizer-hash bits, rec_words words per slot */
+    const uint64_t *mrecs;           /* MIN records: nodes ordered by (minimizer hash, position, rest)        */
+    const uint64_t *recs;            /* FILE records: nodes as the file orders them (exact-probe path only)   */
     const void *coarse;              /* the file's bin table: uint32_t* or uint64_t* (UTREE_F_OFF64)         */
     const uint32_t *irreg;           /* 2^24-bit bitmap                                                      */
     const uint32_t *label_off;       /* [n_labels+1], rank order                                             */
@@ -59,8 +61,8 @@ int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_
 /* counters[0] += irregular bins, counters[1] = 1 if the table is not monotone / exceeds n_nodes */
 int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
                  uint32_t *d_irreg, unsigned long long *d_counters, void *stream);
-int utk_build_table(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs,
-                    uint32_t fine_bits, uint64_t *d_table, void *stream);
+int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
+                  uint32_t table_bits, uint64_t *d_table, uint64_t *d_mrecs, unsigned long long *d_overflow, void *stream);
 int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream);
 
 /* workspace layout for one batch */
