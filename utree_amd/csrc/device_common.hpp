@@ -131,8 +131,26 @@ template <int W> __device__ __forceinline__ bool mkey_lt(const MinKey<W> &a, con
     if constexpr (W == 16) return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); else return a.lo < b.lo;
 }
 
-// Minimizer of the word khi:klo -> hash h, position pos, and the bases outside the minimizer.
+// The bases of khi:klo outside its 16-mer at base position pos.
 // W=8 : rest = 16 bases (32 bits) in rest_lo.   W=16: rest = 48 bases (96 bits) in rest_hi32:rest_lo.
+template <int W> __device__ __forceinline__ void min_rest(uint64_t khi, uint64_t klo, uint32_t pos, uint32_t &rest_hi32, uint64_t &rest_lo) {
+    if constexpr (W == 8) {
+        const uint64_t left = pos ? klo >> (64 - 2 * pos) : 0ull;                   // the pos bases before the minimizer
+        const uint64_t right = klo & ((1ull << (32 - 2 * pos)) - 1);                // the 16-pos bases after it
+        rest_lo = (left << (32 - 2 * pos)) | right;
+        rest_hi32 = 0;
+    } else {
+        const unsigned __int128 w = ((unsigned __int128)khi << 64) | klo;
+        const unsigned __int128 left = pos ? w >> (128 - 2 * pos) : (unsigned __int128)0;
+        const unsigned __int128 right = w & ((((unsigned __int128)1) << (96 - 2 * pos)) - 1);
+        const unsigned __int128 rest = (left << (96 - 2 * pos)) | right;
+        rest_lo = (uint64_t)rest;
+        rest_hi32 = (uint32_t)(rest >> 64);
+    }
+}
+
+// Minimizer of the word khi:klo by direct evaluation (load time; the search kernels get the same (h, pos)
+// from a sliding minimum over per-position hashes shared by the lanes of a wave).
 template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_t klo, uint32_t &h, uint32_t &pos,
                                                           uint32_t &rest_hi32, uint64_t &rest_lo) {
     if constexpr (W == 8) {
@@ -143,10 +161,6 @@ template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_
             if (hh < best) { best = hh; bj = j; }
         }
         h = best; pos = bj;
-        const uint64_t left = bj ? klo >> (64 - 2 * bj) : 0ull;                     // the bj bases before the minimizer
-        const uint64_t right = klo & ((1ull << (32 - 2 * bj)) - 1);                 // the 16-bj bases after it
-        rest_lo = (left << (32 - 2 * bj)) | right;
-        rest_hi32 = 0;
     } else {
         const unsigned __int128 w = ((unsigned __int128)khi << 64) | klo;
         uint32_t best = mix32((uint32_t)(w >> 96)), bj = 0;
@@ -155,22 +169,24 @@ template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_
             if (hh < best) { best = hh; bj = j; }
         }
         h = best; pos = bj;
-        const unsigned __int128 left = bj ? w >> (128 - 2 * bj) : (unsigned __int128)0;
-        const unsigned __int128 right = w & ((((unsigned __int128)1) << (96 - 2 * bj)) - 1);
-        const unsigned __int128 rest = (left << (96 - 2 * bj)) | right;
-        rest_lo = (uint64_t)rest;
-        rest_hi32 = (uint32_t)(rest >> 64);
     }
+    min_rest<W>(khi, klo, pos, rest_hi32, rest_lo);
 }
 
-// table slot and MIN key of a word for a table of 2^B slots
-template <int W> __device__ __forceinline__ void min_split(uint64_t khi, uint64_t klo, uint32_t B, uint64_t &slot, MinKey<W> &mk) {
-    uint32_t h, pos, rh; uint64_t rl;
-    minimizer<W>(khi, klo, h, pos, rh, rl);
+// table slot and MIN key from (h, pos) for a table of 2^B slots
+template <int W> __device__ __forceinline__ void min_finish(uint64_t khi, uint64_t klo, uint32_t h, uint32_t pos, uint32_t B,
+                                                           uint64_t &slot, MinKey<W> &mk) {
+    uint32_t rh; uint64_t rl;
+    min_rest<W>(khi, klo, pos, rh, rl);
     slot = (uint64_t)h >> (32 - B);
     const uint64_t hlow = (uint64_t)h & ((1ull << (32 - B)) - 1);
     if constexpr (W == 8) { mk.hi = 0; mk.lo = (hlow << 37) | ((uint64_t)pos << 32) | rl; }
     else { mk.lo = rl; mk.hi = (hlow << 38) | ((uint64_t)pos << 32) | rh; }
+}
+template <int W> __device__ __forceinline__ void min_split(uint64_t khi, uint64_t klo, uint32_t B, uint64_t &slot, MinKey<W> &mk) {
+    uint32_t h, pos, rh; uint64_t rl;
+    minimizer<W>(khi, klo, h, pos, rh, rl);
+    min_finish<W>(khi, klo, h, pos, B, slot, mk);
 }
 
 // MIN records / table slots.  flag (top 2 bits of word KW): 0 record, 1 empty slot, 2 run {count22 | start40}

@@ -125,6 +125,41 @@ template <int W> __device__ __forceinline__ void window_word(const uint32_t *sw,
     } else { khi = 0; klo = ((uint64_t)x0 << 32) | x1; }
 }
 
+// 32 bits (16 bases) of the packed stream starting at base j
+__device__ __forceinline__ uint32_t mmer_at(const uint32_t *sw, uint32_t j) {
+    const uint32_t w = j >> 4, sh = 32u - ((j & 15u) << 1);
+    return (uint32_t)((((uint64_t)sw[w] << 32) | sw[w + 1]) >> sh);
+}
+
+// Sliding minimizers for a tile of windows, shared by the lanes of one wave (each 16-mer is hashed ONCE instead of
+// once per window that contains it).  After the call, for a window starting at position pos0 + t:
+//     min(Kk[t], Kk[t + NEXT])  =  { hash << 32 | absolute position } of its minimizer (leftmost on ties),
+// the same (h, pos) minimizer<W>() computes from the word.  Kk needs (nch + 1) * 64 entries.
+// In place: step s replaces K[t] by min(K[t], K[t+s]); chunks ascend, so chunk c still sees chunk c+1's old values.
+template <int W> struct MinWin { static constexpr uint32_t NEXT = (W == 16) ? 17u : 1u; };   // [t,t+16)+[t+1,t+17) / [t,t+32)+[t+17,t+49)
+template <int W>
+__device__ __forceinline__ void build_minkeys(const uint32_t *sw, uint64_t *Kk, uint32_t pos0, uint32_t npos, uint32_t pos_cap, uint32_t lane) {
+    const uint32_t nch = (npos + 63) >> 6;
+    for (uint32_t c = 0; c < nch; ++c) {
+        const uint32_t j = pos0 + c * 64 + lane;
+        uint64_t key = ~0ull;
+        if (j < pos_cap) key = ((uint64_t)mix32(mmer_at(sw, j)) << 32) | j;
+        Kk[c * 64 + lane] = key;
+    }
+    Kk[nch * 64 + lane] = ~0ull;
+    wave_lds_fence();
+#pragma unroll
+    for (uint32_t s = 1; s <= ((W == 16) ? 16u : 8u); s <<= 1) {
+        for (uint32_t c = 0; c < nch; ++c) {
+            const uint32_t t = c * 64 + lane;
+            const uint64_t a = Kk[t], b = Kk[t + s];
+            wave_lds_fence();
+            Kk[t] = b < a ? b : a;
+            wave_lds_fence();
+        }
+    }
+}
+
 __device__ __forceinline__ void store_result(utree_result *out, uint32_t label, int32_t cut, uint32_t found,
                                              uint32_t uix, uint32_t sl, uint32_t ol) {
     uint32_t *o = (uint32_t *)out;
@@ -162,6 +197,7 @@ __global__ __launch_bounds__(256) void route_k(const uint32_t *__restrict__ len,
 constexpr int SHORT_CAP = UTREE_SHORT_CAP;          // 150 bp + reverse strand fits
 constexpr int MID_CAP = UTREE_MID_CAP;              // 1 kb + reverse strand fits; longer reads take classify_long_k
 constexpr int WAVES_PER_BLOCK = 4;
+constexpr uint32_t KEY_TILE = 256;                    // windows per sliding-minimizer tile
 constexpr uint32_t TALLY_CHUNK = UTREE_TALLY_CHUNK;
 constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read waits for vote_k
 
@@ -172,7 +208,7 @@ constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read w
 // longer ones to the mid / long lists; CAP = MID_CAP (LISTED) walks the mid list.  Its 37 KB of LDS per
 // workgroup allow 4 workgroups per CU, so it may use 128 VGPRs.
 template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED>
-__global__ __launch_bounds__(256, CAP > SHORT_CAP ? 4 : ((W == 8 && I == 2) ? 8 : 5))
+__global__ __launch_bounds__(256, CAP > SHORT_CAP ? 3 : ((W == 8 && I == 2) ? 8 : 5))
 void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
                       const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
                       utk_workspace ws) {
@@ -181,12 +217,14 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     __shared__ uint32_t s_words[WAVES_PER_BLOCK][NWORDS];
     __shared__ uint64_t s_bad[WAVES_PER_BLOCK][NCH + 2];
     __shared__ uint32_t s_hits[WAVES_PER_BLOCK][CAP];
+    __shared__ uint64_t s_keys[WAVES_PER_BLOCK][KEY_TILE + 128];
     const uint32_t lane = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
     uint32_t *sw = s_words[wv];
     uint8_t *sb = (uint8_t *)sw;
     uint64_t *sbad = s_bad[wv];
     uint32_t *hits = s_hits[wv];
+    uint64_t *Kk = s_keys[wv];
     const uint32_t wave_gid = blockIdx.x * WAVES_PER_BLOCK + wv, n_waves = gridDim.x * WAVES_PER_BLOCK;
     const uint32_t TB = 24 + im.fine_bits;                // table bits
     unsigned long long chunk_base = 0;
@@ -239,33 +277,41 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         wave_lds_fence();
         // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933); two rounds of table loads in flight ----
         uint32_t F = 0;
-        for (uint32_t it = 0; it * 64 < nwin; it += 2) {
-            bool ok[2]; uint64_t wh[2], wl[2]; MinKey<W> mk[2]; Entry<W, I> t[2];
+        for (uint32_t wb = 0; wb < nwin; wb += KEY_TILE) {
+            const uint32_t tn = nwin - wb < KEY_TILE ? nwin - wb : KEY_TILE;
+            build_minkeys<W>(sw, Kk, wb, tn + K - 16, (uint32_t)CAP, lane);      // 16-mers of windows wb .. wb+tn-1
+            for (uint32_t it = 0; it * 64 < tn; it += 2) {
+                bool ok[2]; uint64_t wh[2], wl[2]; MinKey<W> mk[2]; Entry<W, I> t[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t i = (it + h) * 64 + lane;
-                ok[h] = false;
-                if ((it + h) * 64 < nwin) {
-                    uint64_t b0 = sbad[it + h], b1 = sbad[it + h + 1];
-                    uint64_t x = (b0 >> lane) | (lane ? (b1 << (64 - lane)) : 0ull);     // bad flags of bases i..i+63
-                    ok[h] = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t tw = (it + h) * 64 + lane, i = wb + tw;       // window index in the tile / in the read
+                    ok[h] = false;
+                    if (tw < tn) {
+                        const uint32_t ch = i >> 6, bit = i & 63u;
+                        const uint64_t b0 = sbad[ch], b1 = sbad[ch + 1];
+                        const uint64_t x = (b0 >> bit) | (bit ? (b1 << (64 - bit)) : 0ull);  // bad flags of bases i..i+63
+                        ok[h] = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
+                    }
+                    if (ok[h]) {
+                        uint64_t slot;
+                        window_word<W>(sw, i, wh[h], wl[h]);
+                        const uint64_t ka = Kk[tw], kb = Kk[tw + MinWin<W>::NEXT];
+                        const uint64_t km = kb < ka ? kb : ka;
+                        min_finish<W>(wh[h], wl[h], (uint32_t)(km >> 32), (uint32_t)km - i, TB, slot, mk[h]);
+                        t[h] = load_slot<W, I>(im.table, slot);
+                    }
                 }
-                if (ok[h]) {
-                    uint64_t slot;
-                    window_word<W>(sw, i, wh[h], wl[h]);
-                    min_split<W>(wh[h], wl[h], TB, slot, mk[h]);
-                    t[h] = load_slot<W, I>(im.table, slot);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    uint32_t rank = INVALID;
+                    if (ok[h]) rank = resolve_entry<W, I, EXC, OFF>(im, t[h], mk[h], wh[h], wl[h]);
+                    bool hit = rank != INVALID;                     // itree.c:929-931
+                    uint64_t hm = __ballot(hit);
+                    if (hit) hits[F + lanes_below(hm)] = rank;
+                    F += (uint32_t)__popcll(hm);
                 }
             }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint32_t rank = INVALID;
-                if (ok[h]) rank = resolve_entry<W, I, EXC, OFF>(im, t[h], mk[h], wh[h], wl[h]);
-                bool hit = rank != INVALID;                     // itree.c:929-931
-                uint64_t hm = __ballot(hit);
-                if (hit) hits[F + lanes_below(hm)] = rank;
-                F += (uint32_t)__popcll(hm);
-            }
+            wave_lds_fence();
         }
         wave_lds_fence();
         // ---- tally (itree.c:1028-1040): unique labels with counts, ascending rank = strcmp order ----
