@@ -134,18 +134,21 @@ template <int W> __device__ __forceinline__ bool mkey_lt(const MinKey<W> &a, con
 // The bases of khi:klo outside its 16-mer at base position pos.
 // W=8 : rest = 16 bases (32 bits) in rest_lo.   W=16: rest = 48 bases (96 bits) in rest_hi32:rest_lo.
 template <int W> __device__ __forceinline__ void min_rest(uint64_t khi, uint64_t klo, uint32_t pos, uint32_t &rest_hi32, uint64_t &rest_lo) {
+    // word = [pos bases | 16-mer | the other bases]; rest = [pos bases | the other bases].  With T = the word without its
+    // last 16 bases, L = the word without its first 16 bases and M = ones over the bases after the 16-mer:
+    // rest = (T & ~M) | (L & M)  -- one bit-select per 32 bits.
     if constexpr (W == 8) {
-        const uint64_t left = pos ? klo >> (64 - 2 * pos) : 0ull;                   // the pos bases before the minimizer
-        const uint64_t right = klo & ((1ull << (32 - 2 * pos)) - 1);                // the 16-pos bases after it
-        rest_lo = (left << (32 - 2 * pos)) | right;
+        const uint32_t T = (uint32_t)(klo >> 32), L = (uint32_t)klo;
+        const uint32_t M = (uint32_t)(0xFFFFFFFFull >> (2 * pos));
+        rest_lo = (T & ~M) | (L & M);
         rest_hi32 = 0;
     } else {
-        const unsigned __int128 w = ((unsigned __int128)khi << 64) | klo;
-        const unsigned __int128 left = pos ? w >> (128 - 2 * pos) : (unsigned __int128)0;
-        const unsigned __int128 right = w & ((((unsigned __int128)1) << (96 - 2 * pos)) - 1);
-        const unsigned __int128 rest = (left << (96 - 2 * pos)) | right;
-        rest_lo = (uint64_t)rest;
-        rest_hi32 = (uint32_t)(rest >> 64);
+        const uint64_t T_hi = khi >> 32, T_lo = (khi << 32) | (klo >> 32);     // word >> 32 (96 bits: T_hi is 32 bits)
+        const uint64_t L_hi = khi & 0xFFFFFFFFull, L_lo = klo;                 // word & (2^96 - 1)
+        const unsigned __int128 m = ((((unsigned __int128)1) << 96) - 1) >> (2 * pos);
+        const uint64_t M_hi = (uint64_t)(m >> 64), M_lo = (uint64_t)m;
+        rest_lo = (T_lo & ~M_lo) | (L_lo & M_lo);
+        rest_hi32 = (uint32_t)((T_hi & ~M_hi) | (L_hi & M_hi));
     }
 }
 

@@ -318,7 +318,35 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         if (F == 0) { if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); continue; }
         const uint32_t h0 = hits[0];
         if (F == 1) { if (lane == 0) store_result(&out[r], im.rank2ix[h0], -2, 1, 1, 0, 0); continue; }
-        // all hits equal?  (the common case for reads from one taxon)
+        if (F <= 64) {
+            // Up to one hit per lane: peel off distinct labels with readlane + ballot (no LDS shuffles).
+            const bool mine = lane < F;
+            const uint32_t hv = mine ? hits[lane] : 0u;
+            uint64_t left = __ballot(mine);
+            uint32_t nu = 0, myv = 0, myc = 0;                   // lane u keeps distinct label u and its count
+            while (left) {
+                const uint32_t lead = (uint32_t)__builtin_ctzll(left);
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)hv, (int)lead);
+                const uint64_t m = __ballot(mine && hv == v) & left;
+                if (lane == nu) { myv = v; myc = (uint32_t)__popcll(m); }
+                ++nu; left &= ~m;
+            }
+            if (nu == 1) { if (lane == 0) store_result(&out[r], im.rank2ix[h0], -2, F, 1, 0, 0); continue; }
+            if (nu > chunk_left) {
+                unsigned long long nb = 0;
+                if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)TALLY_CHUNK);
+                chunk_base = __shfl(nb, 0);
+                chunk_left = TALLY_CHUNK;
+            }
+            // ascending rank = strcmp order (itree.c:1041): lane u's place = distinct labels smaller than its own
+            uint32_t place = 0;
+            for (uint32_t u = 0; u < nu; ++u) place += (uint32_t)__builtin_amdgcn_readlane((int)myv, (int)u) < myv;
+            if (lane < nu) ws.tally[chunk_base + place] = (uint64_t)myv | ((uint64_t)myc << 32);
+            if (lane == 0) store_result(&out[r], im.rank2ix[h0], CUT_PENDING, F, nu, (uint32_t)chunk_base, (uint32_t)(chunk_base >> 32));
+            chunk_base += nu; chunk_left -= nu;
+            continue;
+        }
+        // many hits (long or densely covered reads): distinct labels by repeated wave-min over the LDS list
         uint32_t mn = INVALID, mx = 0;
         for (uint32_t j = lane; j < F; j += 64) { uint32_t h = hits[j]; mn = h < mn ? h : mn; mx = h > mx ? h : mx; }
         mn = wave_min_u32(mn);
