@@ -145,8 +145,9 @@ template <int W> __device__ __forceinline__ void min_rest(uint64_t khi, uint64_t
     } else {
         const uint64_t T_hi = khi >> 32, T_lo = (khi << 32) | (klo >> 32);     // word >> 32 (96 bits: T_hi is 32 bits)
         const uint64_t L_hi = khi & 0xFFFFFFFFull, L_lo = klo;                 // word & (2^96 - 1)
-        const unsigned __int128 m = ((((unsigned __int128)1) << 96) - 1) >> (2 * pos);
-        const uint64_t M_hi = (uint64_t)(m >> 64), M_lo = (uint64_t)m;
+        const uint32_t s = 2 * pos;                                            // 0..96
+        const uint64_t M_hi = s < 32 ? (0xFFFFFFFFull >> s) : 0ull;            // (2^96 - 1) >> s, as 32 + 64 bits
+        const uint64_t M_lo = s <= 32 ? ~0ull : (s >= 96 ? 0ull : (~0ull >> (s - 32)));
         rest_lo = (T_lo & ~M_lo) | (L_lo & M_lo);
         rest_hi32 = (uint32_t)((T_hi & ~M_hi) | (L_hi & M_hi));
     }

@@ -125,6 +125,8 @@ template <int W> __device__ __forceinline__ void window_word(const uint32_t *sw,
     } else { khi = 0; klo = ((uint64_t)x0 << 32) | x1; }
 }
 
+constexpr uint32_t KEY_TILE = 256;                    // windows per sliding-minimizer tile
+
 // 32 bits (16 bases) of the packed stream starting at base j
 __device__ __forceinline__ uint32_t mmer_at(const uint32_t *sw, uint32_t j) {
     const uint32_t w = j >> 4, sh = 32u - ((j & 15u) << 1);
@@ -157,6 +159,52 @@ __device__ __forceinline__ void build_minkeys(const uint32_t *sw, uint64_t *Kk, 
             Kk[t] = b < a ? b : a;
             wave_lds_fence();
         }
+    }
+}
+
+// One wave looks up the windows [w0, w0+n) of a staged buffer (sw = packed bases, sbad = bad-base bit words, both
+// indexed from the buffer's first base) and hands every lane's result to on_rank(rank) -- called by all lanes,
+// INVALID for lanes without a hit -- twice per 128 windows.  Two table slots are in flight per lane.
+template <int W, int I, bool EXC, typename OFF, typename HitFn>
+__device__ __forceinline__ void wave_scan_windows(const utk_image &im, const uint32_t *sw, const uint64_t *sbad, uint64_t *Kk,
+                                                  uint32_t w0, uint32_t n, uint32_t pos_cap, uint32_t TB, uint32_t lane,
+                                                  HitFn &&on_rank) {
+    constexpr uint32_t K = 4 * W;
+    for (uint32_t wb = 0; wb < n; wb += KEY_TILE) {
+        const uint32_t tn = n - wb < KEY_TILE ? n - wb : KEY_TILE;
+        build_minkeys<W>(sw, Kk, w0 + wb, tn + K - 16, pos_cap, lane);      // 16-mers of windows w0+wb .. w0+wb+tn-1
+#if defined(UTREE_ABLATE) && UTREE_ABLATE == 2
+        continue;
+#endif
+        for (uint32_t it = 0; it * 64 < tn; it += 2) {
+            bool ok[2]; uint64_t wh[2], wl[2]; MinKey<W> mk[2]; Entry<W, I> t[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t tw = (it + h) * 64 + lane, i = w0 + wb + tw;  // window index in the tile / in the buffer
+                ok[h] = false;
+                if (tw < tn) {
+                    const uint32_t ch = i >> 6, bit = i & 63u;
+                    const uint64_t b0 = sbad[ch], b1 = sbad[ch + 1];
+                    const uint64_t x = (b0 >> bit) | (bit ? (b1 << (64 - bit)) : 0ull);  // bad flags of bases i..i+63
+                    ok[h] = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
+                }
+                if (ok[h]) {
+                    uint64_t slot;
+                    window_word<W>(sw, i, wh[h], wl[h]);
+                    const uint64_t ka = Kk[tw], kb = Kk[tw + MinWin<W>::NEXT];
+                    const uint64_t km = kb < ka ? kb : ka;
+                    min_finish<W>(wh[h], wl[h], (uint32_t)(km >> 32), (uint32_t)km - i, TB, slot, mk[h]);
+                    t[h] = load_slot<W, I>(im.table, slot);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t rank = INVALID;
+                if (ok[h]) rank = resolve_entry<W, I, EXC, OFF>(im, t[h], mk[h], wh[h], wl[h]);
+                on_rank(rank);                                               // itree.c:929-931
+            }
+        }
+        wave_lds_fence();
     }
 }
 
@@ -197,7 +245,6 @@ __global__ __launch_bounds__(256) void route_k(const uint32_t *__restrict__ len,
 constexpr int SHORT_CAP = UTREE_SHORT_CAP;          // 150 bp + reverse strand fits
 constexpr int MID_CAP = UTREE_MID_CAP;              // 1 kb + reverse strand fits; longer reads take classify_long_k
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr uint32_t KEY_TILE = 256;                    // windows per sliding-minimizer tile
 constexpr uint32_t TALLY_CHUNK = UTREE_TALLY_CHUNK;
 constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read waits for vote_k
 
@@ -208,7 +255,7 @@ constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read w
 // longer ones to the mid / long lists; CAP = MID_CAP (LISTED) walks the mid list.  Its 37 KB of LDS per
 // workgroup allow 4 workgroups per CU, so it may use 128 VGPRs.
 template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED>
-__global__ __launch_bounds__(256, CAP > SHORT_CAP ? 3 : ((W == 8 && I == 2) ? 8 : 5))
+__global__ __launch_bounds__(256, CAP > SHORT_CAP ? (I == 2 ? 5 : 3) : ((W == 8 && I == 2) ? 8 : 5))
 void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
                       const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
                       utk_workspace ws) {
@@ -216,14 +263,15 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     constexpr int NCH = CAP / 64, NWORDS = CAP / 16 + 6;
     __shared__ uint32_t s_words[WAVES_PER_BLOCK][NWORDS];
     __shared__ uint64_t s_bad[WAVES_PER_BLOCK][NCH + 2];
-    __shared__ uint32_t s_hits[WAVES_PER_BLOCK][CAP];
+    using HIT = typename std::conditional<I == 2, uint16_t, uint32_t>::type;     // ranks of u16-label databases fit 16 bits
+    __shared__ HIT s_hits[WAVES_PER_BLOCK][CAP];
     __shared__ uint64_t s_keys[WAVES_PER_BLOCK][KEY_TILE + 128];
     const uint32_t lane = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
     uint32_t *sw = s_words[wv];
     uint8_t *sb = (uint8_t *)sw;
     uint64_t *sbad = s_bad[wv];
-    uint32_t *hits = s_hits[wv];
+    HIT *hits = s_hits[wv];
     uint64_t *Kk = s_keys[wv];
     const uint32_t wave_gid = blockIdx.x * WAVES_PER_BLOCK + wv, n_waves = gridDim.x * WAVES_PER_BLOCK;
     const uint32_t TB = 24 + im.fine_bits;                // table bits
@@ -275,45 +323,23 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         }
         if (lane == 0) sbad[nch] = ~0ull;
         wave_lds_fence();
+#if defined(UTREE_ABLATE) && UTREE_ABLATE == 1
+        if (lane == 0) store_result(&out[r], sw[lane], -2, 0, 0, 0, 0);
+        continue;
+#endif
         // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933); two rounds of table loads in flight ----
         uint32_t F = 0;
-        for (uint32_t wb = 0; wb < nwin; wb += KEY_TILE) {
-            const uint32_t tn = nwin - wb < KEY_TILE ? nwin - wb : KEY_TILE;
-            build_minkeys<W>(sw, Kk, wb, tn + K - 16, (uint32_t)CAP, lane);      // 16-mers of windows wb .. wb+tn-1
-            for (uint32_t it = 0; it * 64 < tn; it += 2) {
-                bool ok[2]; uint64_t wh[2], wl[2]; MinKey<W> mk[2]; Entry<W, I> t[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t tw = (it + h) * 64 + lane, i = wb + tw;       // window index in the tile / in the read
-                    ok[h] = false;
-                    if (tw < tn) {
-                        const uint32_t ch = i >> 6, bit = i & 63u;
-                        const uint64_t b0 = sbad[ch], b1 = sbad[ch + 1];
-                        const uint64_t x = (b0 >> bit) | (bit ? (b1 << (64 - bit)) : 0ull);  // bad flags of bases i..i+63
-                        ok[h] = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
-                    }
-                    if (ok[h]) {
-                        uint64_t slot;
-                        window_word<W>(sw, i, wh[h], wl[h]);
-                        const uint64_t ka = Kk[tw], kb = Kk[tw + MinWin<W>::NEXT];
-                        const uint64_t km = kb < ka ? kb : ka;
-                        min_finish<W>(wh[h], wl[h], (uint32_t)(km >> 32), (uint32_t)km - i, TB, slot, mk[h]);
-                        t[h] = load_slot<W, I>(im.table, slot);
-                    }
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    uint32_t rank = INVALID;
-                    if (ok[h]) rank = resolve_entry<W, I, EXC, OFF>(im, t[h], mk[h], wh[h], wl[h]);
-                    bool hit = rank != INVALID;                     // itree.c:929-931
-                    uint64_t hm = __ballot(hit);
-                    if (hit) hits[F + lanes_below(hm)] = rank;
-                    F += (uint32_t)__popcll(hm);
-                }
-            }
-            wave_lds_fence();
-        }
+        wave_scan_windows<W, I, EXC, OFF>(im, sw, sbad, Kk, 0u, nwin, (uint32_t)CAP, TB, lane, [&](uint32_t rank) {
+            const bool hit = rank != INVALID;
+            const uint64_t hm = __ballot(hit);
+            if (hit) hits[F + lanes_below(hm)] = (HIT)rank;
+            F += (uint32_t)__popcll(hm);
+        });
         wave_lds_fence();
+#if defined(UTREE_ABLATE) && UTREE_ABLATE == 3
+        if (lane == 0) store_result(&out[r], hits[0], -2, F, 0, 0, 0);
+        continue;
+#endif
         // ---- tally (itree.c:1028-1040): unique labels with counts, ascending rank = strcmp order ----
         if (F == 0) { if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); continue; }
         const uint32_t h0 = hits[0];
@@ -389,7 +415,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 // HBM and set a bit in a touched-label bitmap; the bitmap is then swept in rank order, which yields the same
 // sorted (rank,count) list the wave kernel emits, and only touched histogram entries are read and cleared.
 // ------------------------------------------------------------------------------------------------
-constexpr int LONG_TILE = 4096;                       // windows per tile
+constexpr int LONG_TILE = 2048;                       // windows per tile: 512 per wave
 constexpr int LONG_THREADS = 256;
 constexpr uint32_t LONG_LDS_BITWORDS = 2048;          // labels whose bitmap fits LDS (65 536); else a bitmap in HBM
 
@@ -404,6 +430,7 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
     __shared__ uint64_t s_bad[STAGE / 64 + 2];
     __shared__ uint32_t s_scan[LONG_THREADS / 64 + 1];
     __shared__ uint32_t s_touch[LONG_LDS_BITWORDS];
+    __shared__ uint64_t s_keys[LONG_THREADS / 64][KEY_TILE + 128];
     __shared__ unsigned long long s_base;
     __shared__ uint32_t s_first;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -439,35 +466,17 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
             if (tid == 0) s_bad[STAGE / 64] = ~0ull;
             __syncthreads();
             const uint32_t tile_n = (uint32_t)(nwin - w0 < LONG_TILE ? nwin - w0 : LONG_TILE);
-            for (uint32_t i0 = tid; i0 < tile_n; i0 += 2 * LONG_THREADS) {
-                bool ok[2]; uint64_t wh[2], wl[2]; MinKey<W> mk[2]; Entry<W, I> t[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t i = i0 + h * LONG_THREADS;
-                    ok[h] = false;
-                    if (i < tile_n) {
-                        const uint32_t ch = i >> 6, bit = i & 63u;
-                        uint64_t x = (s_bad[ch] >> bit) | (bit ? (s_bad[ch + 1] << (64 - bit)) : 0ull);
-                        ok[h] = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
-                    }
-                    if (ok[h]) {
-                        uint64_t slot;
-                        window_word<W>(s_words, i, wh[h], wl[h]);
-                        min_split<W>(wh[h], wl[h], 24 + im.fine_bits, slot, mk[h]);
-                        t[h] = load_slot<W, I>(im.table, slot);
-                    }
+            // every wave takes a quarter of the tile and runs the same window scan as the wave-per-read kernel
+            constexpr uint32_t PER_WAVE = LONG_TILE / (LONG_THREADS / 64);
+            const uint32_t a = wv * PER_WAVE < tile_n ? wv * PER_WAVE : tile_n;
+            const uint32_t b = a + PER_WAVE < tile_n ? a + PER_WAVE : tile_n;
+            wave_scan_windows<W, I, EXC, OFF>(im, s_words, s_bad, s_keys[wv], a, b - a, STAGE, 24 + im.fine_bits, lane, [&](uint32_t rank) {
+                if (rank != INVALID) {
+                    atomicAdd(&hist[rank], 1u);
+                    atomicOr(&touch[rank >> 5], 1u << (rank & 31u));
+                    ++my_hits;
                 }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (!ok[h]) continue;
-                    const uint32_t rank = resolve_entry<W, I, EXC, OFF>(im, t[h], mk[h], wh[h], wl[h]);
-                    if (rank != INVALID) {                              // itree.c:929-931
-                        atomicAdd(&hist[rank], 1u);
-                        atomicOr(&touch[rank >> 5], 1u << (rank & 31u));
-                        ++my_hits;
-                    }
-                }
-            }
+            });
             __syncthreads();
         }
         // F = total hits
@@ -632,7 +641,7 @@ int utk_classify_mid(const utk_image *im, const uint8_t *d_bases, const uint64_t
                      uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
     uint32_t blocks = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    uint32_t cap = (uint32_t)n_cu * 4u;
+    uint32_t cap = (uint32_t)n_cu * 5u;
     if (blocks > cap) blocks = cap;
     return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
         classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), MID_CAP, true>
