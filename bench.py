@@ -63,6 +63,12 @@ def main():
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line: libraries that chat on fd 1 (RCCL prints a version banner there when its
+    # communicator is created) are sent to stderr until that line is written
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -71,6 +77,7 @@ def main():
     from utree_amd.search import CtrDB, DeviceTree
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist_on = world > 1 or bool(os.environ.get("UTREE_BENCH_FORCE_DIST"))   # the env var rehearses the N>1 code path with one rank
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -79,7 +86,7 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if dist_on:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -93,7 +100,7 @@ def main():
     if rank == 0:
         sdb = synth.make_db(dev, args.nodes, W=W, fine_bits=args.fine_bits, keep_raw=want_cpu)
         tree, ctr = sdb.tree, sdb.ctr
-    if world > 1:
+    if dist_on:
         meta = None
         if rank == 0:
             used = tree.image_ptr()[1]                      # the built image may be smaller than its allocation
@@ -131,18 +138,18 @@ def main():
         step(i)
     torch.cuda.synchronize()
     tree.kernel_time(reset=True)                 # switches the HIP-event bracket of the dominant kernel on
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.time()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.time() - t1
-    if world > 1:
+    if dist_on:
         elapsed = udist.max_over_ranks(elapsed, dev)
     k_ms, k_launches = tree.kernel_time(reset=True)
 
@@ -174,7 +181,7 @@ def main():
                                    % (args.nodes, args.kmer, synth.N_LABELS, tree.info.image_bytes / 2**30, tree.info.fine_bits,
                                       args.batch_reads * args.steps, args.read_len, args.steps, args.batch_reads, args.rc),
                        "parallelism": "reads sharded over %d GPU(s), CTR image replicated%s; batches alternate over %d HIP stream(s) per GPU" %
-                                      (world, " by one RCCL broadcast (%.2f s)" % bcast_s if world > 1 else "", ns)},
+                                      (world, " by one RCCL broadcast (%.2f s)" % bcast_s if dist_on else "", ns)},
             "roofline": {"bound": "hbm", "kernel": tree.kernel_name(), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_read": b_read, "reads_per_launch": args.batch_reads,
@@ -183,8 +190,11 @@ def main():
         }
         if want_cpu:
             line["cpu_baseline"] = cpu_baseline(args, sdb, batches[0], outs, tree, total_bases)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -238,3 +238,25 @@ def test_size_independent_properties_at_scale(torch_cuda):
     perm = torch.randperm(reads.off.numel(), device=seq.device)
     r3 = tree.classify(reads.bases, reads.off[perm], reads.length[perm], rc=True)
     assert torch.equal(base[perm], r3)
+
+
+def test_attached_image_copy_classifies_identically(torch_cuda):
+    """The N>1 path: a byte copy of the flat device image (what the RCCL broadcast delivers to the other ranks)
+    is adopted with utree_dev_attach and must give identical results; the image really is position independent."""
+    torch = torch_cuda
+    from utree_amd import synth
+    sdb = synth.make_db(torch.device("cuda:0"), n_nodes=3_000_000, seed=synth.DB_SEED)
+    reads = synth.make_reads(sdb, n_reads=100_000, read_len=150, seed=11)
+    base = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=True).clone()
+    ptr, used = sdb.tree.image_ptr()
+    src = sdb.tree.image_tensor()
+    assert src.data_ptr() == ptr and used <= src.numel()
+    pad = torch.empty(4096 + used, dtype=torch.uint8, device="cuda:0")      # a different address, differently aligned (mod 8 KiB)
+    copy = pad[4096:4096 + used]
+    copy.copy_(src[:used])
+    ctr2 = CtrDB.from_memory(sdb.W, 2, sdb.n_nodes, np.zeros((1 << 24) + 1, dtype=np.uint64), None, sdb.label_text)
+    t2 = DeviceTree.attach(ctr2, copy, 0)
+    assert t2.info.fine_bits == sdb.tree.info.fine_bits and t2.info.image_bytes == used
+    again = t2.classify(reads.bases, reads.off, reads.length, rc=True)
+    assert torch.equal(base, again)
+    assert int((base[:, 2] > 0).sum()) > 80_000
