@@ -84,6 +84,12 @@ __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi
 __device__ __forceinline__ uint32_t lanes_below(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
+// wave-uniform values the compiler cannot prove uniform: pin them to scalar registers so that the loops and
+// address arithmetic they drive run on the scalar unit instead of as exec-masked vector code
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v);
+}
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
@@ -267,7 +273,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     __shared__ HIT s_hits[WAVES_PER_BLOCK][CAP];
     __shared__ uint64_t s_keys[WAVES_PER_BLOCK][KEY_TILE + 128];
     const uint32_t lane = lane_id();
-    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t wv = uni32(threadIdx.x >> 6);
     uint32_t *sw = s_words[wv];
     uint8_t *sb = (uint8_t *)sw;
     uint64_t *sbad = s_bad[wv];
@@ -280,9 +286,9 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 
     const uint32_t n_items = LISTED ? (uint32_t)ws.cursors[UTREE_CUR_MID] : n_reads;
     for (uint32_t item = wave_gid; item < n_items; item += n_waves) {
-        const uint32_t r = LISTED ? ws.mid_list[item] : item;
-        const uint32_t L = len[r];
-        const uint64_t o = off[r];
+        const uint32_t r = LISTED ? uni32(ws.mid_list[item]) : item;
+        const uint32_t L = uni32(len[r]);
+        const uint64_t o = uni64(off[r]);
         const uint64_t total64 = do_rc ? 2 * (uint64_t)L + 1 : L;
         if (total64 > (uint64_t)CAP) {                     // route_k listed it for the mid-length pass or classify_long_k
             continue;
@@ -361,7 +367,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             if (nu > chunk_left) {
                 unsigned long long nb = 0;
                 if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)TALLY_CHUNK);
-                chunk_base = __shfl(nb, 0);
+                chunk_base = uni64(nb);
                 chunk_left = TALLY_CHUNK;
             }
             // ascending rank = strcmp order (itree.c:1041): lane u's place = distinct labels smaller than its own
@@ -384,7 +390,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             unsigned long long nb = 0;
             const uint32_t need = F > TALLY_CHUNK ? F : TALLY_CHUNK;
             if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)need);
-            chunk_base = __shfl(nb, 0);
+            chunk_base = uni64(nb);
             chunk_left = need;
         }
         const unsigned long long base = chunk_base;
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
     __shared__ uint64_t s_keys[LONG_THREADS / 64][KEY_TILE + 128];
     __shared__ unsigned long long s_base;
     __shared__ uint32_t s_first;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = uni32(tid >> 6);
     uint8_t *sb = (uint8_t *)s_words;
     const uint32_t nl = im.n_labels, nbw = (nl + 31) >> 5;
     uint32_t *hist = ws.hist + (size_t)blockIdx.x * nl;                       // all zero between reads
