@@ -543,6 +543,13 @@ __device__ __forceinline__ uint32_t cut_of(uint32_t x) {          // itree.c:104
     return c;
 }
 
+// bytes 0..7 of a label at byte offset p (labels are NUL-terminated inside a zero-padded blob)
+__device__ __forceinline__ uint64_t label8(const char *s, uint32_t p) {
+    uint64_t x;
+    __builtin_memcpy(&x, s + p, 8);
+    return x;
+}
+
 __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__restrict__ out, utk_workspace ws, uint32_t n_reads) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
@@ -552,63 +559,70 @@ __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__rest
     const uint64_t *T = ws.tally + ((uint64_t)res[4] | ((uint64_t)res[5] << 32));
     const char *blob = im.label_blob;
     const uint32_t *loff = im.label_off;
-#define T_RANK(z) ((uint32_t)T[z])
-#define T_CNT(z) ((uint32_t)(T[z] >> 32))
     uint32_t cutoff = cut_of(F);
     uint32_t st = 0, ed = uix, dv = 0xFFFFFFFFu, orun = F, sl, ol;
     for (;;) {
-        uint32_t run = T_CNT(st), td = dv;
+        const uint64_t t_st = T[st];
+        uint32_t run = (uint32_t)(t_st >> 32), td = dv;
+        // (s1, c1) = label text and count of the list entry just before z; it moves along with z
+        const char *s1 = blob + loff[(uint32_t)t_st];
+        uint32_t c1 = run;
+        const uint32_t probe = dv + (dv == 0xFFFFFFFFu);                      // 0 while nothing is agreed, else dv
+        const bool skip0 = dv != 0xFFFFFFFFu;                                // then byte `probe` itself is not compared
         for (uint32_t z = st + 1; z < ed; ++z) {
-            const char *s1 = blob + loff[T_RANK(z - 1)], *s2 = blob + loff[T_RANK(z)];
-            const uint32_t nz = T_CNT(z);
-            bool aside = false;
-            if (!s1[dv + (dv == 0xFFFFFFFFu)]) aside = true;                 // itree.c:1052
+            const uint64_t tz = T[z];
+            const uint32_t nz = (uint32_t)(tz >> 32);
+            const char *s2 = blob + loff[(uint32_t)tz];
+            uint64_t x1 = label8(s1, probe);
+            bool aside = false, stop = false;
+            if (!(x1 & 0xFFull)) aside = true;                                // previous label exhausted: itree.c:1052
             else {
-                // itree.c:1060-1061: td = first index > dv where s1 ends, differs from s2, or is ';'.
-                // Eight bytes per step (labels are NUL-terminated inside a zero-padded blob).
-                td = dv + 1;
+                // itree.c:1060-1061: td = first index > dv where s1 ends, differs from s2, or is ';' -- eight bytes per step
+                uint64_t x2 = label8(s2, probe);
+                uint32_t base = probe, idx, prevlast = 0;
+                bool first = true;
                 for (;;) {
-                    uint64_t x1, x2;
-                    __builtin_memcpy(&x1, s1 + td, 8);
-                    __builtin_memcpy(&x2, s2 + td, 8);
-                    const uint64_t semi = x1 ^ 0x3B3B3B3B3B3B3B3Bull;
-                    // bytes of interest -> 0x00 in one of the three words; classic exact zero-byte detector
-                    const uint64_t d = x1 ^ x2;
+                    const uint64_t semi = x1 ^ 0x3B3B3B3B3B3B3B3Bull, d = x1 ^ x2;
+                    // exact per-byte flags: x1 byte == 0, x1 byte == ';', bytes differ (lowest set flag is what we need)
                     uint64_t m = (((x1 - 0x0101010101010101ull) & ~x1) | ((semi - 0x0101010101010101ull) & ~semi)) & 0x8080808080808080ull;
-                    // a difference: mark every non-zero byte of d (exact: no borrow tricks)
                     m |= (((d & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | d) & 0x8080808080808080ull;
-                    if (m) { td += (uint32_t)(__builtin_ctzll(m) >> 3); break; }
-                    td += 8;
+                    if (first && skip0) m &= ~0xFFull;
+                    if (m) { idx = (uint32_t)(__builtin_ctzll(m) >> 3); break; }
+                    prevlast = (uint32_t)(x1 >> 56);
+                    base += 8; first = false;
+                    x1 = label8(s1, base); x2 = label8(s2, base);
                 }
-                const char a = s1[td], b = s2[td];
-                if (a == b) { run += nz; continue; }                           // itree.c:1062
-                const char before = td ? s1[td - 1] : 0;
-                if ((!a && b == ';') || ((a == ';' || !a) && before == '_')) aside = true;   // 1063
-                else if (run >= cutoff) { ed = z; break; }                     // itree.c:1068
-                else { run = nz; st = z; continue; }                           // itree.c:1069
+                td = base + idx;
+                const uint32_t a = (uint32_t)(x1 >> (8 * idx)) & 0xFFu, b = (uint32_t)(x2 >> (8 * idx)) & 0xFFu;
+                // s1[td-1]; reading before the string (td == 0) counts as "not '_'"
+                const uint32_t before = idx ? ((uint32_t)(x1 >> (8 * idx - 8)) & 0xFFu) : (first ? 0u : prevlast);
+                if (a == b) run += nz;                                                         // same token: itree.c:1062
+                else if ((!a && b == ';') || ((a == ';' || !a) && before == '_')) aside = true;   // less specific: 1063
+                else if (run >= cutoff) { ed = z; stop = true; }                               // group wins: itree.c:1068
+                else { run = nz; st = z; }                                                     // restart: itree.c:1069
             }
             if (aside) {                                                       // 1053-1056 / 1064-1067
                 run = nz; st = z;
-                orun -= T_CNT(z - 1);
+                orun -= c1;
                 cutoff = cut_of(orun);
             }
+            if (stop) break;
+            s1 = s2; c1 = nz;
         }
         sl = run; ol = orun;                                                   // itree.c:1071
         if (run < cutoff) break;                                               // itree.c:1072
         if (st + 1 >= ed) {                                                    // itree.c:1073-1079
-            if (T_CNT(ed - 1) >= cutoff) dv = 0xFFFFFFFEu;
+            if ((uint32_t)(T[ed - 1] >> 32) >= cutoff) dv = 0xFFFFFFFEu;
             break;
         }
         orun = run; dv = td; cutoff = cut_of(run);                             // itree.c:1082-1085
     }
-    const uint32_t rk = T_RANK(ed - 1);
+    const uint32_t rk = (uint32_t)T[ed - 1];
     int32_t cut;
     if (dv == 0xFFFFFFFFu) cut = -1;                                           // itree.c:1087
     else if (dv == 0xFFFFFFFEu) cut = -2;
     else { uint32_t Ls = loff[rk + 1] - loff[rk] - 1; cut = (int32_t)(dv < Ls ? dv : Ls); }   // 1088
     store_result(&out[r], im.rank2ix[rk], cut, F, uix, sl, ol);
-#undef T_RANK
-#undef T_CNT
 }
 
 template <int W, int I, bool EXC, typename OFF>
