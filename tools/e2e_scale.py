@@ -86,7 +86,7 @@ def main():
 
     ours = os.path.join(args.dir, "ours.txt")
     code, secs, so, se = run([lib.CLI_PATH, ctr_path, fa_path, ours, str(args.threads)] + rcarg)
-    out["ours"] = {"exit": code, "wall_seconds": secs, "stderr_tail": se.strip().splitlines()[-2:]}
+    out["ours"] = {"exit": code, "wall_seconds": secs, "stderr_tail": [l for l in se.splitlines() if l.startswith("[utree_amd]")]}
     for ln in se.splitlines():
         if "search" in ln and "reads/s" in ln:
             out["ours"]["search_line"] = ln.strip()

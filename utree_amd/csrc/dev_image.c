@@ -29,6 +29,10 @@ void utree_dev_set_hip_error(int err, const char *what) {
 }
 const char *utree_last_hip_error(void) { return g_hip_msg; }
 
+#include <time.h>
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static int timing_on(void) { return getenv("UTREE_TIMING") != NULL || getenv("UTREE_DEBUG") != NULL; }
+
 static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
@@ -120,8 +124,10 @@ typedef struct {
 static int build_begin(builder *b, const utree_ctr *ctr, int device, int fine_bits, void *d_image, size_t image_bytes,
                        hipStream_t stream) {
     int rc = UTREE_OK, n_cu = 0;
+    double tb0 = now_s();
     memset(b, 0, sizeof *b);
     if ((rc = device_ok(device, &n_cu))) return rc;
+    double tb1 = now_s();
     utree_dev *d = (utree_dev *)calloc(1, sizeof *d);
     if (!d) return UTREE_E_NOMEM;
     b->d = d; b->ctr = ctr; b->stream = stream;
@@ -134,6 +140,7 @@ static int build_begin(builder *b, const utree_ctr *ctr, int device, int fine_bi
         HIPCHK(hipMalloc(&d->image, d->hdr.total_bytes));
         d->owns = 1;
     }
+    if (timing_on()) fprintf(stderr, "[utree_amd] image: device init %.3f s, hipMalloc(%.1f GiB) %.3f s\n", tb1 - tb0, (double)d->hdr.total_bytes / 1073741824.0, now_s() - tb1);
     d->image_bytes = d->hdr.total_bytes;
     bind_image(d);
     char *img = (char *)d->image;
@@ -259,8 +266,10 @@ int utree_dev_upload(const utree_ctr *ctr, int device, int fine_bits, utree_dev 
     *out = NULL;
     if (!ctr->path && !ctr->h_records) return UTREE_E_ARG;
     builder b;
+    double t0 = now_s();
     int rc = build_begin(&b, ctr, device, fine_bits, NULL, 0, NULL);
     if (rc) return rc;
+    double t1 = now_s(), t2 = t1, t3 = t1;
     const size_t SZ = ctr->info.SZ;
     const size_t chunk_recs = ((size_t)48 << 20) / SZ;
     const size_t chunk_bytes = chunk_recs * SZ;
@@ -295,9 +304,13 @@ int utree_dev_upload(const utree_ctr *ctr, int device, int fine_bits, utree_dev 
         HIPCHK(hipEventRecord(ev[slot], NULL));
         done += cnt;
     }
+    HIPCHK(hipDeviceSynchronize());
+    t2 = now_s();
     HIPCHK(hipMalloc(&d_binix, (size_t)UTREE_NUMBINS * ctr->info.binix_width));
     HIPCHK(hipMemcpyAsync(d_binix, ctr->binix_raw, (size_t)UTREE_NUMBINS * ctr->info.binix_width, hipMemcpyHostToDevice, NULL));
     rc = build_finish(&b, d_binix);
+    t3 = now_s();
+    if (timing_on()) fprintf(stderr, "[utree_amd] image: alloc+labels %.3f s, stream+repack nodes %.3f s, validate+sort+table %.3f s\n", t1 - t0, t2 - t1, t3 - t2);
     if (!rc) *out = b.d;
     b.d = NULL;
 fail:
