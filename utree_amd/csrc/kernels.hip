@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void route_k(const uint32_t *__restrict__ len,
 constexpr int SHORT_CAP = UTREE_SHORT_CAP;          // 150 bp + reverse strand fits
 constexpr int MID_CAP = UTREE_MID_CAP;              // 1 kb + reverse strand fits; longer reads take classify_long_k
 constexpr int WAVES_PER_BLOCK = 4;
+constexpr uint32_t WORK_GRAB = 64;                   // reads a wave takes per visit to the work counter
 constexpr uint32_t TALLY_CHUNK = UTREE_TALLY_CHUNK;
 constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read waits for vote_k
 
@@ -261,7 +262,10 @@ constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read w
 // longer ones to the mid / long lists; CAP = MID_CAP (LISTED) walks the mid list.  Its 37 KB of LDS per
 // workgroup allow 4 workgroups per CU, so it may use 128 VGPRs.
 template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED>
-__global__ __launch_bounds__(256, CAP > SHORT_CAP ? (I == 2 ? 5 : 3) : ((W == 8 && I == 2) ? 8 : 5))
+#ifndef UTREE_SHORT_MIN_WAVES
+#define UTREE_SHORT_MIN_WAVES 8
+#endif
+__global__ __launch_bounds__(256, CAP > SHORT_CAP ? (I == 2 ? 5 : 3) : ((W == 8 && I == 2) ? UTREE_SHORT_MIN_WAVES : 5))
 void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
                       const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
                       utk_workspace ws) {
@@ -284,9 +288,22 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     unsigned long long chunk_base = 0;
     uint32_t chunk_left = 0;
 
+    // Reads are handed out dynamically, WORK_GRAB at a time per wave (one atomic per grab): the grid need not match
+    // the kernel's residency and long and short reads balance out.
     const uint32_t n_items = LISTED ? (uint32_t)ws.cursors[UTREE_CUR_MID] : n_reads;
-    for (uint32_t item = wave_gid; item < n_items; item += n_waves) {
-        const uint32_t r = LISTED ? uni32(ws.mid_list[item]) : item;
+    unsigned long long *work = &ws.cursors[LISTED ? UTREE_CUR_WORK_MID : UTREE_CUR_WORK];
+    (void)wave_gid; (void)n_waves;
+    uint32_t item = 0, item_end = 0;
+    for (;;) {
+        if (item == item_end) {
+            unsigned long long g = 0;
+            if (lane == 0) g = atomicAdd(work, (unsigned long long)WORK_GRAB);
+            item = uni32((uint32_t)g);
+            if (item >= n_items) break;
+            item_end = item + WORK_GRAB < n_items ? item + WORK_GRAB : n_items;
+        }
+        const uint32_t cur_item = item++;
+        const uint32_t r = LISTED ? uni32(ws.mid_list[cur_item]) : cur_item;
         const uint32_t L = uni32(len[r]);
         const uint64_t o = uni64(off[r]);
         const uint64_t total64 = do_rc ? 2 * (uint64_t)L + 1 : L;
@@ -448,7 +465,13 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
     if (nbw <= LONG_LDS_BITWORDS) for (uint32_t x = tid; x < nbw; x += LONG_THREADS) s_touch[x] = 0;
     __syncthreads();
 
-    for (uint32_t li = blockIdx.x; li < n_long; li += gridDim.x) {
+    for (;;) {
+        // long reads differ in length by orders of magnitude: hand them out one at a time
+        if (tid == 0) s_first = (uint32_t)atomicAdd(&ws.cursors[UTREE_CUR_WORK_LONG], 1ull);
+        __syncthreads();
+        const uint32_t li = s_first;
+        __syncthreads();
+        if (li >= n_long) break;
         const uint32_t r = ws.long_list[li];
         const uint64_t L64 = len[r];
         const uint64_t o = off[r];

@@ -16,6 +16,9 @@ extern "C" {
 #define UTREE_TALLY_CHUNK 4096u                  /* tally entries a wave reserves with one atomic              */
 #define UTREE_CUR_LONG 32                        /* cursors[] index of the long-read counter (own 256-B line)   */
 #define UTREE_CUR_MID 16                         /* ... of the mid-length-read counter                           */
+#define UTREE_CUR_WORK 48                        /* ... of the next unclaimed read (150-bp-class pass)           */
+#define UTREE_CUR_WORK_LONG 40                   /* ... of the next unclaimed long-list entry                    */
+#define UTREE_CUR_WORK_MID 56                    /* ... of the next unclaimed mid-list entry                     */
 #define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds      */
 #define UTREE_MID_CAP 2112u                      /* ... and its mid-length instantiation; longer: classify_long */
 
