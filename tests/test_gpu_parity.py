@@ -260,3 +260,15 @@ def test_attached_image_copy_classifies_identically(torch_cuda):
     again = t2.classify(reads.bases, reads.off, reads.length, rc=True)
     assert torch.equal(base, again)
     assert int((base[:, 2] > 0).sum()) > 80_000
+
+
+@pytest.mark.parametrize("name", ["toy", "katq2", "generic", "k64"])
+def test_64bit_offset_instantiations(torch_cuda, name, monkeypatch):
+    """Databases with N >= 2^32-1 nodes use 8-byte bin-table entries and 64-bit offsets on the device; no fixture can
+    be that large, so a test hook builds the image of a small database with the 64-bit instantiations instead."""
+    monkeypatch.setenv("UTREE_FORCE_OFF64", "1")
+    db = CtrDB.open(util.fixture_ctr(name))
+    tree = DeviceTree.upload(db, 0, 2)
+    got = classify_fasta_bytes(db, tree, util.fixture_bytes(util.READS_OF.get(name, name) + "_reads.fa.gz"), rc=False)
+    assert got == util.fixture_bytes(name + "_out.txt.gz")
+    tree.close()

@@ -60,7 +60,8 @@ static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     h->W = ctr->info.W; h->I = ctr->info.I; h->k = ctr->info.k;
     h->fine_bits = F; h->rec_words = utree_rec_words(h->W, h->I);
     h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
-    h->flags = ctr->info.binix_width == 8 ? UTREE_F_OFF64 : 0;
+    /* UTREE_FORCE_OFF64: test hook that runs the 64-bit-offset instantiations (N >= 2^32-1 databases) on small files */
+    h->flags = (ctr->info.binix_width == 8 || getenv("UTREE_FORCE_OFF64")) ? UTREE_F_OFF64 : 0;
     h->n_slots = 1ull << (24 + F);
     uint64_t off = UTREE_IMG_HEADER_BYTES;
     h->off_table = off; off = align_up(off + h->n_slots * h->rec_words * 8, 4096);
