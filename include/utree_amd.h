@@ -186,6 +186,19 @@ typedef struct {
 int utree_search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path,
                       const char *out_path, int do_rc, int host_threads, utree_search_stats *stats);
 
+/* ------------------------------------------------------------------------------------------------
+ * `.ubt` -> `.ctr` = XT_cmp32(filename, outfile) (itree.c:1234-1315; `xtree-compress`), SURVEY.md §8(f) rank 2.
+ * Node dump streamed through `device`; output byte-identical to the reference's, first-bin quirk included.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t n_nodes, n_labels;
+    uint64_t label_count_total;   /* "Total nodes in tree: %llu" (itree.c:1314): sum of the label counts */
+    uint32_t W, I;
+    double   seconds;
+} utree_compress_stats;
+
+int utree_compress_file(const char *ubt_path, const char *ctr_path, int device, utree_compress_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -507,9 +507,46 @@ def gen_irregular(manifest, seed=123):
         manifest["generic_out_lines"] = out.count(b"\n")
 
 
+def gen_compress(manifest, seed=4242):
+    """`.ubt` -> `.ctr` by the reference's xtree-compress on hand-made `.ubt` files that hit its
+    corners: first bin with ONE record (bin-table quirk), first bin with several, a repeated label line (its count lands
+    on the newest label), unsorted words (the table records first NON-ZERO occurrences)."""
+    rng = np.random.default_rng(seed)
+    cases = {}
+
+    def words_in(prefixes, per):
+        out = []
+        for p, n in zip(prefixes, per):
+            out += [(p << 40) | int(x) for x in rng.integers(0, 1 << 40, n)]
+        return np.array(sorted(set(out)), dtype=np.uint64)
+
+    labels = [b"k__A;p__L%d\t%d\n" % (i, 100 + i) for i in range(9)]
+    cases["cq_single_first"] = (words_in([7, 9, 300, 70000, (1 << 24) - 1], [1, 5, 3, 40, 2]), b"".join(labels))
+    cases["cq_multi_first"] = (words_in([0, 1, 2, 5000], [4, 1, 1, 30]), b"".join(labels))
+    cases["cq_dup_labels"] = (words_in([11, 12, 9000], [2, 2, 20]), b"".join(labels[:4]) + labels[1] + labels[5] + b"k__A;p__L0\t77\n" + labels[6])
+    w = words_in([21, 22, 23, 40000], [3, 3, 3, 25])
+    cases["cq_unsorted"] = (w[rng.permutation(len(w))], b"".join(labels))
+    with tempfile.TemporaryDirectory() as td:
+        for nm, (w, tail) in cases.items():
+            ix = rng.integers(0, 9, size=len(w)).astype(np.uint32)
+            ubt = os.path.join(td, nm + ".ubt")
+            ctrfile.write_ubt(ubt, 8, 2, np.zeros_like(w), w, ix, tail)
+            ctr = os.path.join(td, nm + ".ctr")
+            code, so, se = run([os.path.join(REF, "xtree-compress"), ubt, ctr])
+            assert code == 0, (nm, code, so[-300:])
+            np.savez_compressed(os.path.join(HERE, nm + "_ubt.npz"), lo=w, ix=ix, tail=np.frombuffer(tail, dtype=np.uint8))
+            manifest[nm + "_ctr_sha256"] = ctrfile.sha256_file(ctr)
+            manifest[nm + "_stdout_tail"] = so.decode().strip().splitlines()[-1]
+
+
 def main():
     if not os.path.exists(os.path.join(REF, "xtree-searchGG")):
         sys.exit("build the reference first: make -C oracle ref")
+    if len(sys.argv) > 1 and sys.argv[1] == "compress":       # add the COMPRESS fixtures to an existing golden set
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+        gen_compress(manifest)
+        json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "irregular":      # add the irregular-bin fixtures to an existing golden set
         manifest = json.load(open(os.path.join(HERE, "manifest.json")))
         gen_irregular(manifest)
@@ -522,6 +559,7 @@ def main():
     gen_vote(manifest)
     gen_kat(manifest)
     gen_irregular(manifest)
+    gen_compress(manifest)
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(manifest, indent=1, sort_keys=True))
 

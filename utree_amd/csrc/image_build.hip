@@ -141,6 +141,24 @@ __global__ void table_k(const uint32_t *__restrict__ Hs, const uint64_t *__restr
     }
 }
 
+// COMPRESS (itree.c:1282-1286, 1306-1309): per record, drop the 3 prefix bytes; per prefix, the smallest NON-ZERO index
+template <int W, int I>
+__global__ void compress_chunk_k(const uint8_t *__restrict__ in, uint64_t first, uint64_t count, unsigned long long *first_ix,
+                                 uint8_t *__restrict__ out) {
+    constexpr int DR = W + I, SZ = W + I - 3, SB = W - 3;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t *p = in + t * DR;
+        uint8_t *o = out + t * SZ;
+#pragma unroll
+        for (int b = 0; b < SB; ++b) o[b] = p[b];
+#pragma unroll
+        for (int b = 0; b < I; ++b) o[SB + b] = p[W + b];
+        const uint32_t v = ((uint32_t)p[W - 1] << 16) | ((uint32_t)p[W - 2] << 8) | p[W - 3];      // top 24 bits of the LE word
+        const uint64_t gi = first + t;
+        if (gi) atomicMin(&first_ix[v], (unsigned long long)gi);              // `if (!BinIx[v]) BinIx[v] = i` never records i == 0
+    }
+}
+
 unsigned grid_for(uint64_t n) {
     uint64_t b = (n + 255) / 256;
     return (unsigned)(b > (1u << 20) ? (1u << 20) : (b ? b : 1));
@@ -239,6 +257,15 @@ int utk_validate(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, cons
             (const uint64_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
         else validate_k<W, I, uint32_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
             (const uint32_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
+    });
+}
+
+int utk_compress_chunk(uint32_t W_, uint32_t I_, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
+                       void *d_out, void *stream) {
+    if (!count) return 0;
+    return dispatch_wi(W_, I_, [&](auto w, auto i) {
+        compress_chunk_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(count) > 16384 ? 16384 : grid_for(count)), dim3(256), 0, (hipStream_t)stream>>>(
+            (const uint8_t *)d_in, first, count, d_first, (uint8_t *)d_out);
     });
 }
 

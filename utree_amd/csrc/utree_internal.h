@@ -66,6 +66,8 @@ int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const 
                  uint32_t *d_irreg, unsigned long long *d_counters, void *stream);
 int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
                   uint32_t table_bits, uint64_t *d_table, uint64_t *d_mrecs, unsigned long long *d_overflow, void *stream);
+int utk_compress_chunk(uint32_t W, uint32_t I, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
+                       void *d_out, void *stream);
 int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream);
 
 /* workspace layout for one batch */

@@ -204,6 +204,21 @@ def read_ubt(path: str):
     return W, I, v[:, 1].copy(), v[:, 0].copy(), ixb.view("<u4")[:, 0].copy(), text
 
 
+def write_ubt(path: str, W: int, I: int, hi: np.ndarray, lo: np.ndarray, ix: np.ndarray, label_text: bytes) -> None:
+    """`.ubt` as UT_writeTreeBinary leaves it (itree.c:1317-1343): header, N x (W-byte LE word, I-byte ix), label lines."""
+    n = len(lo)
+    full = np.zeros((n, 16), dtype=np.uint8)
+    full[:, :8] = np.ascontiguousarray(lo.astype("<u8")).view(np.uint8).reshape(n, 8)
+    full[:, 8:] = np.ascontiguousarray(hi.astype("<u8")).view(np.uint8).reshape(n, 8)
+    rec = np.empty((n, W + I), dtype=np.uint8)
+    rec[:, :W] = full[:, :W]
+    rec[:, W:] = np.ascontiguousarray(ix.astype("<u4")).view(np.uint8).reshape(n, 4)[:, :I]
+    with open(path, "wb") as f:
+        f.write(np.array([W, 0, I, n], dtype="<u8").tobytes())
+        f.write(rec.tobytes())
+        f.write(label_text)
+
+
 def sha256_file(path: str) -> str:
     h = hashlib.sha256()
     with open(path, "rb") as f:

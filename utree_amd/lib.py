@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libutree_amd.so")
 CLI_PATH = os.path.join(_HERE, "xtree-searchGG")
+COMPRESS_CLI_PATH = os.path.join(_HERE, "xtree-compress")
 _LIB = None
 
 OK, E_IO, E_FORMAT, E_UNSUPPORTED, E_NOMEM, E_HIP, E_ARG, E_NOLABELS, E_FASTA, E_RCCL = range(10)
@@ -35,6 +36,11 @@ class FastaError(C.Structure):
 class SearchStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("good_finds", C.c_uint64), ("seconds_total", C.c_double),
                 ("seconds_kernels", C.c_double), ("fasta_error", FastaError)]
+
+
+class CompressStats(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_labels", C.c_uint64), ("label_count_total", C.c_uint64), ("W", C.c_uint32),
+                ("I", C.c_uint32), ("seconds", C.c_double)]
 
 
 class Result(C.Structure):
@@ -71,6 +77,7 @@ SYMBOLS = {
                                     C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(FastaError)]),
     "utree_format_records": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "utree_compress_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(CompressStats)]),
     "utree_search_file": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
                                     C.POINTER(SearchStats)]),
 }

@@ -242,6 +242,13 @@ def search_gg(db: CtrDB, trees: Sequence[DeviceTree], fasta: str, out: str, rc: 
     return code, st
 
 
+def compress(ubt: str, ctr: str, device: int = 0):
+    """XT_cmp32(preTree.ubt, compTree.ctr) (itree.c:1234): returns (code, stats)."""
+    st = _lib.CompressStats()
+    code = _lib.load().utree_compress_file(ubt.encode(), ctr.encode(), device, C.byref(st))
+    return code, st
+
+
 def classify_fasta_bytes(db: CtrDB, tree: DeviceTree, data: bytes, rc: bool = False) -> bytes:
     """Convenience for tests: frame -> upload -> classify -> format, through the C-ABI pieces."""
     import torch
