@@ -253,6 +253,7 @@ constexpr int MID_CAP = UTREE_MID_CAP;              // 1 kb + reverse strand fit
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr uint32_t WORK_GRAB = 64;                   // reads a wave takes per visit to the work counter
 constexpr uint32_t TALLY_CHUNK = UTREE_TALLY_CHUNK;
+constexpr uint32_t TALLY_DIRECT = UTREE_TALLY_CHUNK / 16;   // hit lists this long get their own reservation
 constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read waits for vote_k
 
 // 8 waves/SIMD for the default record format measured 4 % faster than 5 (r01: 325 vs 313 M reads/s) even with a
@@ -401,16 +402,25 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         mn = wave_min_u32(mn);
         mx = ~wave_min_u32(~mx);
         if (mn == mx) { if (lane == 0) store_result(&out[r], im.rank2ix[h0], -2, F, 1, 0, 0); continue; }
-        // (rank,count) list space: every wave sub-allocates from chunks it reserves with ONE atomic per
-        // TALLY_CHUNK entries (a per-read atomic on one address serialises the whole chip)
-        if (F > chunk_left) {
+        // (rank,count) list space: every wave sub-allocates from TALLY_CHUNK-entry chunks it reserves with ONE atomic
+        // (a per-read atomic on one address serialises the whole chip).  A refill abandons < TALLY_DIRECT entries of
+        // the old chunk; reads with more hits than that take their space directly, so the workspace bound
+        // windows * 9/8 + waves * TALLY_CHUNK (dev_image.c) always holds.
+        unsigned long long base;
+        const bool direct = F >= TALLY_DIRECT;
+        if (direct) {
             unsigned long long nb = 0;
-            const uint32_t need = F > TALLY_CHUNK ? F : TALLY_CHUNK;
-            if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)need);
-            chunk_base = uni64(nb);
-            chunk_left = need;
+            if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)F);
+            base = uni64(nb);
+        } else {
+            if (F > chunk_left) {
+                unsigned long long nb = 0;
+                if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)TALLY_CHUNK);
+                chunk_base = uni64(nb);
+                chunk_left = TALLY_CHUNK;
+            }
+            base = chunk_base;
         }
-        const unsigned long long base = chunk_base;
         uint32_t uix = 0, cur = mn;
         for (;;) {
             uint32_t c = 0, nxt = INVALID;
@@ -426,7 +436,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             if (nxt == INVALID) break;
             cur = nxt;
         }
-        chunk_base += uix; chunk_left -= uix;
+        if (!direct) { chunk_base += uix; chunk_left -= uix; }
         // vote_k finishes this read: cut = CUT_PENDING marks it, sl/ol carry the tally offset
         if (lane == 0) store_result(&out[r], im.rank2ix[h0], CUT_PENDING, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
     }

@@ -13,7 +13,7 @@ extern "C" {
 #define UTREE_INVALID 0xFFFFFFFFu
 #define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
 #define UTREE_IMG_HEADER_BYTES 4096u
-#define UTREE_TALLY_CHUNK 4096u                  /* tally entries a wave reserves with one atomic              */
+#define UTREE_TALLY_CHUNK 8192u                  /* tally entries a wave reserves with one atomic              */
 #define UTREE_CUR_LONG 32                        /* cursors[] index of the long-read counter (own 256-B line)   */
 #define UTREE_CUR_MID 16                         /* ... of the mid-length-read counter                           */
 #define UTREE_CUR_WORK 48                        /* ... of the next unclaimed read (150-bp-class pass)           */
