@@ -26,6 +26,16 @@ RESULT_DTYPE = np.dtype([("label", "<u4"), ("cut", "<i4"), ("found", "<u4"), ("u
                          ("sl", "<u4"), ("ol", "<u4")])
 
 
+class RankParams(C.Structure):
+    """SLACK / SPARSITY / TOLERANCE_THRESHOLD (itree.c:952-960)."""
+    _fields_ = [("slack", C.c_uint32), ("sparsity", C.c_uint32), ("tolerance", C.c_uint32)]
+
+
+class RankResult(C.Structure):
+    _fields_ = [("label", C.c_uint32), ("printed", C.c_uint32), ("found", C.c_uint32), ("most", C.c_uint32),
+                ("second", C.c_uint32)]
+
+
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "utree_oracle.c")
@@ -64,6 +74,16 @@ def lib():
         L.orc_search_file.restype = C.c_int
         L.orc_search_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+        L.orc_rank_state_new.restype = C.c_void_p
+        L.orc_rank_state_new.argtypes = [C.c_void_p]
+        L.orc_rank_state_free.argtypes = [C.c_void_p]
+        L.orc_rank_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(RankParams),
+                                    C.POINTER(RankResult)]
+        L.orc_rank_format.restype = C.c_size_t
+        L.orc_rank_format.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(RankResult), C.c_char_p, C.c_size_t]
+        L.orc_rank_search_file.restype = C.c_int
+        L.orc_rank_search_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(RankParams),
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -158,6 +178,51 @@ class OracleDB:
         code = lib().orc_search_file(self._h, fasta.encode(), out.encode(), threads, int(rc), C.byref(nr), C.byref(gf),
                                      err, 512)
         return code, nr.value, gf.value, err.value.decode("latin-1")
+
+
+class RankSearch:
+    """`xtree-search` restated (itree.c:969-1007): reads go through in file order, one state object."""
+
+    def __init__(self, db: OracleDB, slack: int = 2, sparsity: int = 4, tolerance: int = 2):
+        self.db = db
+        self.prm = RankParams(slack, sparsity, tolerance)
+        self._st = lib().orc_rank_state_new(db._h)
+
+    def read(self, seq: bytes, rc: bool = False) -> RankResult:
+        r = RankResult()
+        b = np.frombuffer(seq, dtype=np.uint8)
+        lib().orc_rank_read(self.db._h, self._st, b.ctypes.data if len(b) else None, len(b), int(rc),
+                            C.byref(self.prm), C.byref(r))
+        return r
+
+    def format(self, name: bytes, r: RankResult) -> bytes:
+        cap = len(name) + 70000
+        out = C.create_string_buffer(cap)
+        n = lib().orc_rank_format(self.db._h, name, len(name), C.byref(r), out, cap)
+        return out.raw[:n]
+
+    def close(self):
+        if self._st:
+            lib().orc_rank_state_free(self._st)
+            self._st = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rank_search_file(db: OracleDB, fasta: str, out: str, rc: bool = False, slack: int = 2, sparsity: int = 4,
+                     tolerance: int = 2):
+    """Returns (exit_code, n_reads, good_finds, err)."""
+    nr = C.c_uint64(0)
+    gf = C.c_uint64(0)
+    err = C.create_string_buffer(512)
+    prm = RankParams(slack, sparsity, tolerance)
+    code = lib().orc_rank_search_file(db._h, fasta.encode(), out.encode(), int(rc), C.byref(prm), C.byref(nr),
+                                      C.byref(gf), err, 512)
+    return code, nr.value, gf.value, err.value.decode("latin-1")
 
 
 def windows(seq: bytes, k: int):

@@ -450,22 +450,20 @@ static size_t next_line(const uint8_t *buf, size_t n, size_t pos) {
     return nl ? (size_t)(nl - (buf + pos)) + 1 : lim;
 }
 
-int orc_search_file(const orc_db *db, const char *fasta, const char *outp, int threads, int do_rc,
-                    uint64_t *n_reads, uint64_t *good_finds, char *err, size_t errlen) {
+typedef struct { size_t name, name_len, seq, seq_len; } frame;
+
+/* Reads the whole file and frames it (itree.c:866-890).  Returns the reference's exit code for the first
+ * malformed record (reads before it are still processed, as the reference has already printed them). */
+static int load_and_frame(const char *fasta, uint8_t **pbuf, frame **pfr, size_t *pnr, char *err, size_t errlen) {
     FILE *fp = fopen(fasta, "rb");
-    FILE *fo = fopen(outp, "wb");
-    if (!fp) { if (fo) fclose(fo); set_err(err, errlen, "Invalid input files"); return 1; }   /* itree.c:835 */
-    if (!fo) { fclose(fp); set_err(err, errlen, "Invalid output file"); return 1; }
+    if (!fp) { set_err(err, errlen, "Invalid input files"); return 1; }                       /* itree.c:835 */
     fseeko(fp, 0, SEEK_END);
     size_t n = (size_t)ftello(fp);
     fseeko(fp, 0, SEEK_SET);
     uint8_t *buf = (uint8_t *)malloc(n + 1);
-    if (!buf || fread(buf, 1, n, fp) != n) { fclose(fp); fclose(fo); free(buf); set_err(err, errlen, "read error"); return 3; }
+    if (!buf || fread(buf, 1, n, fp) != n) { fclose(fp); free(buf); set_err(err, errlen, "read error"); return 3; }
     fclose(fp);
     buf[n] = 0;
-
-    /* pass 1: frame reads */
-    typedef struct { size_t name, name_len, seq, seq_len; } frame;
     size_t cap = 1024, nr = 0;
     frame *fr = (frame *)malloc(sizeof(frame) * cap);
     int rc = 0;
@@ -491,6 +489,17 @@ int orc_search_file(const orc_db *db, const char *fasta, const char *outp, int t
         ++nr;
         pos = spos + sl_;
     }
+    *pbuf = buf; *pfr = fr; *pnr = nr;
+    return rc;
+}
+
+int orc_search_file(const orc_db *db, const char *fasta, const char *outp, int threads, int do_rc,
+                    uint64_t *n_reads, uint64_t *good_finds, char *err, size_t errlen) {
+    uint8_t *buf = NULL; frame *fr = NULL; size_t nr = 0;
+    FILE *fo = fopen(outp, "wb");
+    int rc = load_and_frame(fasta, &buf, &fr, &nr, err, errlen);
+    if (!buf) { if (fo) fclose(fo); return rc; }
+    if (!fo) { free(buf); free(fr); set_err(err, errlen, "Invalid output file"); return 1; }
     /* pass 2: classify (parallel), pass 3: write in order */
     orc_result *res = (orc_result *)calloc(nr ? nr : 1, sizeof(orc_result));
 #ifdef _OPENMP
@@ -520,6 +529,161 @@ int orc_search_file(const orc_db *db, const char *fasta, const char *outp, int t
     }
     fclose(fo);
     free(line); free(res); free(fr); free(buf);
+    if (n_reads) *n_reads = nr;
+    if (good_finds) *good_finds = good;
+    return rc;
+}
+
+/* =============================================================================================
+ * Rank-specific search: `xtree-search` (itree.c -D SEARCH; main passes doCollapse = 0, itree.c:1376).
+ * Same framing, windows and lookups; the differences are restated below.  The reference runs this
+ * branch on ONE thread (no omp pragma in it, itree.c:969-1007), and reads are NOT independent:
+ *
+ *  - hit selection (XT_SHALLOWVOTE, itree.c:948-951): after a hit at the window ending at i the next
+ *    window examined ends at i + PACKSIZE/SPARSITY (the macro adds PACKSIZE/SPARSITY-1, the loop 1);
+ *    windows in between are never looked up, and the roller's word register is left in a state that
+ *    is NOT the query's k-mer for the next PACKSIZE - PACKSIZE/SPARSITY windows (see rank_hits).
+ *  - the vote (980-1003) runs over kingsMen+1 entries of AllTheKingsHorses: `if (!kingsMen++)` (982)
+ *    is never true when foundUniq > 0, and its post-increment makes the loops at 984 and 988 read ONE
+ *    entry past the read's own hits.  That entry is whatever an earlier read with more hits left at
+ *    that index -- the array is allocated once (970) and never cleared -- or 0 while untouched
+ *    (a 64 MiB malloc is served by fresh zero pages; [probed] with the genuine binary).
+ *    So the output of a read depends on the reads before it; rank_state carries that array.
+ *  - most / secondMost (986-997): first-come maximum of the per-label counts and the runner-up;
+ *    a line is printed iff most >= TOLERANCE_THRESHOLD and most >= SLACK*secondMost (1000), as
+ *    name \t label \t %f \t %d with 1 - secondMost/most and most (1002).
+ * ============================================================================================= */
+struct orc_rank_state {
+    uint32_t *horses;  size_t cap;      /* AllTheKingsHorses (itree.c:970), persistent                */
+    uint32_t *hashes;                   /* Hashes (971)                                              */
+    uint8_t *rcbuf; size_t rc_cap;
+};
+
+orc_rank_state *orc_rank_state_new(const orc_db *db) {
+    orc_rank_state *st = (orc_rank_state *)calloc(1, sizeof *st);
+    if (!st) return NULL;
+    st->cap = 1024;
+    st->horses = (uint32_t *)calloc(st->cap, sizeof(uint32_t));
+    st->hashes = (uint32_t *)calloc(db->n_labels ? db->n_labels : 1, sizeof(uint32_t));
+    if (!st->horses || !st->hashes) { orc_rank_state_free(st); return NULL; }
+    return st;
+}
+void orc_rank_state_free(orc_rank_state *st) {
+    if (!st) return;
+    free(st->horses); free(st->hashes); free(st->rcbuf); free(st);
+}
+
+/* Hit selection with the reference's word register (itree.c:906-933 with XT_SHALLOWVOTE, 948-951).
+ * Let S = PACKSIZE/SPARSITY.  After a hit at the window ending at i0 whose looked-up word was w0, the next
+ * window examined ends at i0+S.  For S < PACKSIZE-1 the roller takes its "continue from z" path (920): it
+ * first shifts the register by (i-z-1) = S-1 bases and then shifts in ALL S bases z+1..i, so the register
+ * ends up shifted by 2S-1 bases with only S new ones: S-1 zero ("A") positions are left in the middle and
+ * the oldest bases are not yet gone.  That word -- not the query's real k-mer -- is what gets looked up,
+ * and the register rolls on from it one base at a time, so every window ending at i0+d, S <= d < PACKSIZE,
+ * is looked up as   (w0 << 2(d+S-1)) | (the d bases i0+1..i0+d)   in 2*PACKSIZE-bit arithmetic; from
+ * d = PACKSIZE on the real k-mer is back.  A hit on such a word starts the same thing over from it.
+ * A bad base clears everything (923), exactly as in for_each_window. */
+static size_t rank_hits(const orc_db *db, const uint8_t *seq, size_t len, uint32_t sparsity, uint32_t *hits) {
+    const uint32_t k = db->k;
+    const u128 keep = (k == 64) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1);
+    const size_t S = k / sparsity;
+    u128 real = 0, w0 = 0;                /* the query's real k-mer register; the word of the last hit  */
+    size_t good = 0, i0 = 0, n = 0;
+    int after_hit = 0;
+    for (size_t i = 0; i < len; ++i) {
+        int c = base_code(seq[i]);
+        if (c < 0) { good = 0; real = 0; after_hit = 0; continue; }
+        real = ((real << 2) | (u128)c) & keep;
+        if (++good < k) continue;
+        u128 word = real;
+        if (after_hit) {
+            size_t d = i - i0;
+            if (d < S) continue;                                       /* not examined (950) */
+            if (d < k) {
+                size_t sh = 2 * (d + S - 1);
+                u128 newbits = real & ((((u128)1) << (2 * d)) - 1);
+                word = ((sh >= 2 * (size_t)k ? (u128)0 : (w0 << sh)) | newbits) & keep;
+            }
+        }
+        uint32_t ix = lookup_word(db, word);
+        if (ix >= db->n_labels) continue;                              /* itree.c:929 */
+        hits[n++] = ix;                                                /* 951 */
+        after_hit = 1; i0 = i; w0 = word;
+    }
+    return n;
+}
+
+void orc_rank_read(const orc_db *db, orc_rank_state *st, const uint8_t *seq, size_t len, int do_rc,
+                   const orc_rank_params *prm, orc_rank_result *res) {
+    memset(res, 0, sizeof *res);
+    if (do_rc) {
+        size_t need = 2 * len + 1;
+        if (need > st->rc_cap) { free(st->rcbuf); st->rcbuf = (uint8_t *)malloc(need + 64); st->rc_cap = need + 64; }
+        orc_revcomp_append(seq, len, st->rcbuf);
+        seq = st->rcbuf; len = need;
+    }
+    if (len + 2 > st->cap) {                                           /* the reference's array is simply huge */
+        size_t nc = len + 1024;
+        uint32_t *h = (uint32_t *)realloc(st->horses, nc * sizeof(uint32_t));
+        if (!h) return;
+        memset(h + st->cap, 0, (nc - st->cap) * sizeof(uint32_t));
+        st->horses = h; st->cap = nc;
+    }
+    const size_t nh = rank_hits(db, seq, len, prm->sparsity, st->horses);
+    res->found = (uint32_t)nh;
+    if (!nh) return;                                                   /* itree.c:980 */
+    uint32_t *A = st->horses, *H = st->hashes;
+    size_t km = nh + 1;                                                /* 982: kingsMen++ */
+    for (size_t i = 0; i < km; ++i) ++H[A[i]];                         /* 984-985 */
+    uint32_t most = 0, second = 0, most_ix = 0;
+    for (size_t i = 0; i < km; ++i) {                                  /* 988-997 */
+        uint32_t c = H[A[i]];
+        if (c > most) { second = most; most_ix = A[i]; most = c; }
+        else if (c > second) second = c;
+        H[A[i]] = 0;
+    }
+    res->label = most_ix; res->most = most; res->second = second;
+    res->printed = !((int)most < (int)prm->tolerance || (int)most < (int)(prm->slack * second));   /* 1000 */
+}
+
+size_t orc_rank_format(const orc_db *db, const char *name, size_t name_len, const orc_rank_result *r, char *out,
+                       size_t cap) {
+    if (!r->found || !r->printed) return 0;
+    const char *lab = db->labels[r->label];
+    size_t lablen = strlen(lab);
+    if (name_len + lablen + 96 > cap) return 0;
+    char *o = out;
+    memcpy(o, name, name_len); o += name_len; *o++ = '\t';
+    memcpy(o, lab, lablen); o += lablen;
+    o += sprintf(o, "\t%f\t%d\n", (double)1 - (double)r->second / r->most, (int)r->most);       /* 1002 */
+    return (size_t)(o - out);
+}
+
+int orc_rank_search_file(const orc_db *db, const char *fasta, const char *outp, int do_rc,
+                         const orc_rank_params *prm, uint64_t *n_reads, uint64_t *good_finds, char *err,
+                         size_t errlen) {
+    uint8_t *buf = NULL; frame *fr = NULL; size_t nr = 0;
+    FILE *fo = fopen(outp, "wb");
+    int rc = load_and_frame(fasta, &buf, &fr, &nr, err, errlen);
+    if (!buf) { if (fo) fclose(fo); return rc; }
+    if (!fo) { free(buf); free(fr); set_err(err, errlen, "Invalid output file"); return 1; }
+    orc_rank_state *st = orc_rank_state_new(db);
+    uint64_t good = 0;
+    size_t lcap = 1 << 20;
+    char *line = (char *)malloc(lcap);
+    for (size_t i = 0; st && i < nr; ++i) {
+        orc_rank_result r;
+        orc_rank_read(db, st, buf + fr[i].seq, fr[i].seq_len, do_rc, prm, &r);
+        if (!r.found || !r.printed) continue;                          /* 981, 1000: ++goodFinds / --goodFinds */
+        ++good;
+        size_t need = fr[i].name_len + 70000 + 96;
+        if (need > lcap) { lcap = need * 2; line = (char *)realloc(line, lcap); }
+        size_t L = orc_rank_format(db, (const char *)buf + fr[i].name, fr[i].name_len, &r, line, lcap);
+        fwrite(line, 1, L, fo);
+    }
+    fclose(fo);
+    orc_rank_state_free(st);
+    free(line); free(fr); free(buf);
     if (n_reads) *n_reads = nr;
     if (good_finds) *good_finds = good;
     return rc;

@@ -70,6 +70,27 @@ void orc_classify_batch(const orc_db *db, const uint8_t *buf, const uint64_t *of
 int orc_search_file(const orc_db *db, const char *fasta, const char *out, int threads, int do_rc,
                     uint64_t *n_reads, uint64_t *good_finds, char *err, size_t errlen);
 
+/* ---- rank-specific search: `xtree-search`, itree.c -D SEARCH (doCollapse = 0 branch, 969-1007) --------
+ * Sequential by construction: each read's vote also counts one entry left in the hit array by an
+ * earlier read (itree.c:982), so a state object is threaded through the reads in file order. */
+typedef struct { uint32_t slack, sparsity, tolerance; } orc_rank_params;   /* itree.c:952-960: 2, 4, 2 */
+typedef struct {
+    uint32_t label;     /* mostIX                                                                      */
+    uint32_t printed;   /* 1 iff the reference prints a line (itree.c:1000-1002)                        */
+    uint32_t found;     /* hits kept after the sparsity skip (foundUniq == kingsMen)                    */
+    uint32_t most, second;
+} orc_rank_result;
+typedef struct orc_rank_state orc_rank_state;
+orc_rank_state *orc_rank_state_new(const orc_db *db);
+void orc_rank_state_free(orc_rank_state *st);
+void orc_rank_read(const orc_db *db, orc_rank_state *st, const uint8_t *seq, size_t len, int do_rc,
+                   const orc_rank_params *prm, orc_rank_result *res);
+size_t orc_rank_format(const orc_db *db, const char *name, size_t name_len, const orc_rank_result *r, char *out,
+                       size_t cap);
+int orc_rank_search_file(const orc_db *db, const char *fasta, const char *out, int do_rc,
+                         const orc_rank_params *prm, uint64_t *n_reads, uint64_t *good_finds, char *err,
+                         size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

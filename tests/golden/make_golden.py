@@ -539,12 +539,137 @@ def gen_compress(manifest, seed=4242):
             manifest[nm + "_stdout_tail"] = so.decode().strip().splitlines()[-1]
 
 
+RANK_BINS = {            # binary -> (slack, sparsity, tolerance): the compile-time knobs of itree.c:952-960
+    "xtree-search": (2, 4, 2),
+    "xtree-search-s3p8": (3, 8, 2),
+    "xtree-search-p1": (2, 1, 2),
+    "xtree-search-p2": (2, 2, 2),
+    "xtree-search-p32s1t1": (1, 32, 1),
+}
+
+
+def gen_rank(manifest, seed=777):
+    """the rank-specific `xtree-search` (itree.c -D SEARCH).  Outputs of the genuine binaries
+    (several SLACK / SPARSITY / TOLERANCE_THRESHOLD builds) on
+      * the existing toy / k64 / ix32 / vote fixtures, and
+      * `rk`: a DENSE direct-written DB (every window of 48 related references) plus planted "register" words --
+        what the reference really looks up after a hit (see oracle/utree_oracle.c rank_hits) -- and homopolymer /
+        repeat k-mers; reads of 30 bp .. 120 kb in one file, so that the entry a read's vote picks up from an
+        earlier read's hit list (itree.c:982) comes from far and near."""
+    rng = np.random.default_rng(seed)
+    k = 32
+    out_names = {}
+    # ---- (a) existing fixtures through the rank-specific binaries
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util  # noqa: E402
+    for name, binn in (("toy", "xtree-search"), ("toy", "xtree-search-s3p8"), ("k64", "xtree-search-k64"),
+                       ("ix32", "xtree-search-ix32"), ("vote", "xtree-search")):
+        ctr = util.fixture_ctr(name)
+        fa = util.fixture_reads_path(name)
+        for rc in (0, 1):
+            code, out, so, se = ref_search(binn, ctr, fa, rc)
+            assert code == 0, (binn, code, se[-300:])
+            tag = "%s_rank%s%s" % (name, binn[len("xtree-search"):].replace("-k64", "").replace("-ix32", ""), "_rc" if rc else "")
+            gz_write(os.path.join(HERE, tag + ".txt.gz"), out)
+            out_names[tag] = {"db": name, "reads": name, "bin": binn, "rc": rc, "lines": out.count(b"\n")}
+    # ---- (b) the dense DB
+    labels = ["lab_%02d_%s" % (i, "".join(chr(97 + int(c)) for c in rng.integers(0, 26, 5))) for i in range(48)]
+    roots = [rand_seq(rng, 1500) for _ in range(6)]
+    refs = [mutate(rng, roots[i % 6], 0.03) for i in range(48)]
+    kmers = {}
+    for li, s in enumerate(refs):
+        b = bytes(s).decode()
+        for j in range(len(b) - k + 1):
+            kmers.setdefault(b[j:j + k], li)
+
+    def garbage(word, newbases, S):
+        """what the reference's register holds d = len(newbases) bases after a hit on `word` (S = k/SPARSITY)"""
+        d, E = len(newbases), S - 1
+        return (word[d + E:] + "A" * E + newbases) if d + E <= k else ("A" * (k - d) + newbases)
+
+    planted = []
+    for n in range(60):                                   # reads whose post-hit register words are in the DB
+        li = int(rng.integers(0, 48))
+        a = int(rng.integers(0, 1500 - 200))
+        r = bytes(refs[li][a:a + 160]).decode()
+        w0 = r[:k]
+        S = 8
+        d = int(rng.integers(S, k))                        # a register word d bases after the first hit
+        g1 = garbage(w0, r[k:k + d], S)
+        kmers.setdefault(g1, int(rng.integers(0, 48)))
+        if n % 2:                                          # and a second one chained from it
+            d2 = int(rng.integers(S, k))
+            g2 = garbage(g1, r[k + d:k + d + d2], S)
+            kmers.setdefault(g2, int(rng.integers(0, 48)))
+        planted.append(("plant%d" % n, np.frombuffer(r.encode(), dtype=np.uint8)))
+    for hp in ("A" * k, "C" * k, "ACGT" * 8, "AC" * 16, "T" * k):
+        kmers.setdefault(hp, int(rng.integers(0, 48)))
+    ks = list(kmers)
+    hi, lo = ctrfile.encode_kmers(ks)
+    ix = np.array([kmers[s] for s in ks], dtype=np.uint32)
+    srt = np.argsort(lo, kind="stable")
+    reads = []
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+
+    def draw(n, lo_len, hi_len, tag):
+        for i in range(n):
+            L = int(rng.integers(lo_len, hi_len))
+            parts = []
+            while sum(len(p) for p in parts) < L:          # stitched from several references (chimeras for long reads)
+                ref = refs[int(rng.integers(0, 48))]
+                seg = int(rng.integers(20, 1200))
+                a = int(rng.integers(0, 1500 - 20))
+                parts.append(mutate(rng, ref[a:a + seg], float(rng.choice([0.0, 0.005, 0.02, 0.3]))))
+            s = np.concatenate(parts)[:L].copy()
+            q = rng.random()
+            if q < 0.1 and L > 4:
+                s[rng.integers(0, L, size=max(1, L // 300))] = ord("N")
+            elif q < 0.15:
+                s = np.frombuffer(bytes(s).lower(), dtype=np.uint8).copy()
+            elif q < 0.25:
+                s = np.array([comp.get(int(c), 78) for c in s[::-1]], dtype=np.uint8)
+            reads.append(("%s%d" % (tag, i), s))
+
+    draw(1500, 30, 400, "s")
+    draw(25, 1000, 6000, "m")
+    draw(2, 30000, 60000, "l")
+    reads += planted[:30]
+    draw(1, 119000, 120000, "x")
+    draw(1200, 30, 700, "t")
+    reads += planted[30:]
+    for nm, s in (("polyA", "A" * 300), ("polyC", "C" * 90 + "A" * 90), ("acgt", "ACGT" * 60), ("ac", "AC" * 100 + "N" + "T" * 70)):
+        reads.append((nm, np.frombuffer(s.encode(), dtype=np.uint8)))
+    draw(300, 30, 300, "u")
+    with tempfile.TemporaryDirectory() as td:
+        ctr = os.path.join(td, "rk.ctr")
+        ctrfile.write_ctr(ctr, 8, 2, hi[srt], lo[srt], ix[srt], labels)
+        save_db_fixture("rk", ctr, manifest)
+        fa = os.path.join(td, "reads.fa")
+        write_fasta(fa, reads)
+        gz_write(os.path.join(HERE, "rk_reads.fa.gz"), open(fa, "rb").read())
+        for binn in RANK_BINS:
+            for rc in ((0, 1) if binn in ("xtree-search", "xtree-search-p2") else (0,)):
+                code, out, so, se = ref_search(binn, ctr, fa, rc)
+                assert code == 0, (binn, code, se[-300:])
+                tag = "rk_rank%s%s" % (binn[len("xtree-search"):], "_rc" if rc else "")
+                gz_write(os.path.join(HERE, tag + ".txt.gz"), out)
+                out_names[tag] = {"db": "rk", "reads": "rk", "bin": binn, "rc": rc, "lines": out.count(b"\n")}
+    for v in out_names.values():
+        v["params"] = list(RANK_BINS[v["bin"].replace("-k64", "").replace("-ix32", "")])
+    manifest["rank_outputs"] = out_names
+
+
 def main():
     if not os.path.exists(os.path.join(REF, "xtree-searchGG")):
         sys.exit("build the reference first: make -C oracle ref")
     if len(sys.argv) > 1 and sys.argv[1] == "compress":       # add the COMPRESS fixtures to an existing golden set
         manifest = json.load(open(os.path.join(HERE, "manifest.json")))
         gen_compress(manifest)
+        json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "rank":           # add the rank-specific (`xtree-search`) fixtures
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+        gen_rank(manifest)
         json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "irregular":      # add the irregular-bin fixtures to an existing golden set
@@ -560,6 +685,7 @@ def main():
     gen_kat(manifest)
     gen_irregular(manifest)
     gen_compress(manifest)
+    gen_rank(manifest)
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(manifest, indent=1, sort_keys=True))
 

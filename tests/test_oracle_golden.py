@@ -99,3 +99,52 @@ def test_windows_skip_bad_bases():
     # lowercase and high bytes
     pos2, _, lo2 = orc.windows((b"acgt" * 8) + bytes([200]) + b"A" * 32, 32)
     assert list(pos2) == [31, 64] and int(lo2[1]) == 0
+
+
+# ---- rank-specific search (`xtree-search`, itree.c -D SEARCH): SURVEY §8(f) rank 1 ---------------------
+RANK_TAGS = sorted(util.manifest().get("rank_outputs", {}))
+
+
+@pytest.mark.parametrize("tag", RANK_TAGS)
+def test_rank_search_file_matches_reference(tag, tmpdir_mod):
+    """Every byte of the genuine binaries' outputs (5 SLACK/SPARSITY/TOLERANCE builds, k=64 and u32-label builds,
+    +RC), including the order dependence through the hit array the reference never clears (itree.c:982)."""
+    v = util.manifest()["rank_outputs"][tag]
+    db = orc.OracleDB.load(util.fixture_ctr(v["db"]))
+    out = os.path.join(str(tmpdir_mod), tag + ".txt")
+    sl, sp, tol = v["params"]
+    code, nr, good, err = orc.rank_search_file(db, util.fixture_reads_path(v["reads"]), out, rc=bool(v["rc"]),
+                                               slack=sl, sparsity=sp, tolerance=tol)
+    want = util.fixture_bytes(tag + ".txt.gz")
+    assert code == 0
+    assert open(out, "rb").read() == want
+    assert good == want.count(b"\n") == v["lines"]
+
+
+def test_rank_vote_reads_one_stale_entry():
+    """The carried entry in isolation: a read with ONE hit is printed iff the entry an earlier, longer hit list
+    left at index 1 (or the initial 0) is the same label -- (most, second) = (2, 0)."""
+    d = util.load_db_fixture("vote")
+    db = orc.OracleDB.load(util.fixture_ctr("vote"))
+    hi, lo = d.suffixes()
+    ixs = d.ix()
+    # full words: bin prefix (24 bits) + stored suffix
+    b = d.binix
+    prefix = np.searchsorted(b, np.arange(d.n_nodes), side="right") - 1
+    words = (prefix.astype(np.uint64) << np.uint64(40)) | lo
+    kmer_of = {}
+    for w, i in zip(words, ixs):
+        kmer_of.setdefault(int(i), ctrfile.decode_kmer(0, int(w), 32))
+    labs = sorted(kmer_of)
+    a, c = [l for l in labs if l != 0][:2]
+    rs = orc.RankSearch(db)
+    r = rs.read(kmer_of[a].encode())                      # first read: entry [1] is still 0 -> label 0 gets the vote
+    assert (r.found, r.most, r.second, r.printed) == (1, 1, 1, 0)
+    two = (kmer_of[c] + "N" + kmer_of[a]).encode()        # leaves [c, a] in the array
+    r = rs.read(two)
+    assert r.found == 2
+    r = rs.read(kmer_of[a].encode())                      # one hit (a) + stale entry [1] = a  -> printed, 2 votes
+    assert (r.found, r.label, r.most, r.second, r.printed) == (1, a, 2, 0, 1)
+    assert rs.format(b"q", r) == b"q\t" + db.label(a) + b"\t1.000000\t2\n"
+    r = rs.read(kmer_of[c].encode())                      # one hit (c) + stale a -> 1 : 1, not printed
+    assert (r.found, r.most, r.second, r.printed) == (1, 1, 1, 0)
