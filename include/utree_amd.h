@@ -187,6 +187,41 @@ int utree_search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const c
                       const char *out_path, int do_rc, int host_threads, utree_search_stats *stats);
 
 /* ------------------------------------------------------------------------------------------------
+ * Rank-specific search = the `xtree-search` binary (itree.c -D SEARCH: XT_doSearch32 with doCollapse = 0,
+ * itree.c:969-1007, 1376).  SURVEY.md §8(f) rank 1.  Same `.ctr`, framing, windows and node lookups as the GG
+ * path; different hit selection and vote, with the reference's compile-time knobs as run-time parameters.
+ *
+ * Reads are NOT independent here: the reference's vote also counts one entry an earlier read left in its hit
+ * array (itree.c:982), so batches must be submitted in file order, on one device image per input file; the image
+ * carries that array from batch to batch.  utree_rank_reset() starts a new file.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t slack;       /* SLACK (itree.c:955, default 2): most >= slack * secondMost, or no line               */
+    uint32_t sparsity;    /* SPARSITY (itree.c:958, default 4): a hit skips PACKSIZE/sparsity - 1 windows (950)   */
+    uint32_t tolerance;   /* TOLERANCE_THRESHOLD (itree.c:952, default 2): most >= tolerance, or no line          */
+} utree_rank_params;
+void utree_rank_params_default(utree_rank_params *p);
+
+size_t utree_rank_workspace_bytes(const utree_dev *dev, uint32_t n_reads, uint64_t total_bases, uint32_t max_len,
+                                  int do_rc, const utree_rank_params *params);
+/* Arguments as utree_classify_batch.  d_out[r]: found = hits kept (foundUniq, itree.c:930), label = mostIX,
+ * sl = most, ol = secondMost (itree.c:986-997), cut = -2 if the reference prints the read (1000-1002) else -4;
+ * uix is 0. */
+int utree_rank_batch(utree_dev *dev, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
+                     uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc,
+                     const utree_rank_params *params, utree_result *d_out, void *d_workspace, size_t workspace_bytes,
+                     void *stream);
+/* Forget the carried array (a fresh process of the reference). */
+int utree_rank_reset(utree_dev *dev);
+/* "name \t label \t %f \t %d \n" (itree.c:1002); same conventions as utree_format_records. */
+size_t utree_format_rank_records(const utree_ctr *ctr, const uint8_t *h_buf, const uint64_t *name_off,
+                                 const uint32_t *name_len, const utree_result *h_res, size_t n, char *h_out, size_t cap,
+                                 uint64_t *good_finds);
+/* Whole file on ONE device image (the reference runs this branch on one thread); resets the carried array first. */
+int utree_rank_search_file(const utree_ctr *ctr, utree_dev *dev, const char *fasta_path, const char *out_path,
+                           int do_rc, const utree_rank_params *params, int host_threads, utree_search_stats *stats);
+
+/* ------------------------------------------------------------------------------------------------
  * `.ubt` -> `.ctr` = XT_cmp32(filename, outfile) (itree.c:1234-1315; `xtree-compress`), SURVEY.md §8(f) rank 2.
  * Node dump streamed through `device`; output byte-identical to the reference's, first-bin quirk included.
  * ---------------------------------------------------------------------------------------------- */

@@ -132,6 +132,24 @@ def test_format_matches_oracle_format():
     assert got == util.fixture_bytes("toy_out.txt.gz")
 
 
+def test_rank_format_matches_reference_lines():
+    """Host formatting of the rank-specific lines (itree.c:1002, "%f" and "%d") with the oracle's records as input:
+    reproduces the genuine xtree-search output."""
+    p = util.fixture_ctr("toy")
+    db = CtrDB.open(p)
+    o = orc.OracleDB.load(p)
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    fr = frame_fasta(data, final=True)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    rs = orc.RankSearch(o)
+    res = np.zeros((len(fr["seq_off"]), 6), dtype=np.int32)
+    for i in range(len(res)):
+        s, l = int(fr["seq_off"][i]), int(fr["seq_len"][i])
+        r = rs.read(data[s:s + l])
+        res[i] = (r.label, -2 if r.printed else -4, r.found, 0, r.most, r.second)
+    assert db.format(buf, fr["name_off"], fr["name_len"], res, rank=True) == util.fixture_bytes("toy_rank.txt.gz")
+
+
 def test_synthetic_ctr_roundtrip(tmp_path):
     rng = np.random.default_rng(5)
     lo = np.unique(rng.integers(0, 1 << 63, size=5000, dtype=np.uint64))

@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--threads", type=int, default=os.cpu_count())
     ap.add_argument("--prefix-reads", type=int, default=100_000, help="reads of the ordered (1-thread) reference comparison")
     ap.add_argument("--skip-reference", action="store_true")
+    ap.add_argument("--rank", action="store_true",
+                    help="the rank-specific `xtree-search` pair instead of xtree-searchGG: the reference is sequential there, "
+                         "so the two output FILES must be identical byte for byte")
     ap.add_argument("--sweep-threads", default="", help="comma list: extra reference runs at these thread counts")
     args = ap.parse_args()
     import numpy as np
@@ -85,7 +88,9 @@ def main():
     rcarg = ["RC"] if args.rc else []
 
     ours = os.path.join(args.dir, "ours.txt")
-    code, secs, so, se = run([lib.CLI_PATH, ctr_path, fa_path, ours, str(args.threads)] + rcarg)
+    our_cli = lib.RANK_CLI_PATH if args.rank else lib.CLI_PATH
+    out["cli"] = os.path.basename(our_cli)
+    code, secs, so, se = run([our_cli, ctr_path, fa_path, ours, str(args.threads)] + rcarg)
     out["ours"] = {"exit": code, "wall_seconds": secs, "stderr_tail": [l for l in se.splitlines() if l.startswith("[utree_amd]")]}
     for ln in se.splitlines():
         if "search" in ln and "reads/s" in ln:
@@ -94,7 +99,7 @@ def main():
     out["ours"]["lines"] = o_lines
     out["ours"]["sorted_sha256"] = o_sha
 
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "xtree-searchGG" + ("-k64" if args.kmer == 64 else ""))
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", ("xtree-search" if args.rank else "xtree-searchGG") + ("-k64" if args.kmer == 64 else ""))
     if not args.skip_reference and os.path.exists(ref_bin):
         empty = os.path.join(args.dir, "empty.fa")
         open(empty, "wb").close()
@@ -106,6 +111,13 @@ def main():
                             "search_seconds": secs - load_secs, "reads_per_second": args.reads / max(1e-9, secs - load_secs),
                             "lines": r_lines, "sorted_sha256": r_sha}
         out["parity_sorted_lines_identical"] = (r_sha == o_sha)
+        if args.rank:
+            sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
+            out["parity_files_identical"] = (sha(ref) == sha(ours))
+            print(json.dumps(out, indent=1))
+            for f in os.listdir(args.dir):
+                os.remove(os.path.join(args.dir, f))
+            return
         # ordered comparison on a prefix with ONE reference thread
         n = min(args.prefix_reads, args.reads)
         pfa = os.path.join(args.dir, "prefix.fa")

@@ -174,6 +174,7 @@ static int build_begin(builder *b, const utree_ctr *ctr, int device, int fine_bi
 fail:
     if (b->d_ix2rank) hipFree(b->d_ix2rank);
     if (d->owns && d->image) hipFree(d->image);
+    if (d->rank_state) hipFree(d->rank_state);
     free(d);
     b->d = NULL;
     return rc;
@@ -360,6 +361,7 @@ void utree_dev_free(utree_dev *d) {
     hipSetDevice(d->device);
     for (int i = 0; i < d->n_events; ++i) hipEventDestroy(d->events[i]);
     if (d->owns && d->image) hipFree(d->image);
+    if (d->rank_state) hipFree(d->rank_state);
     free(d);
 }
 

@@ -16,6 +16,9 @@ struct utree_dev {
     void *events[2 * UTREE_MAX_PENDING];
     double ms_total;
     uint64_t launches;
+    /* rank-specific search: the reference's never-cleared hit array as later reads see it (rank.c) */
+    void *rank_state;
+    uint64_t rank_state_cap;
 };
 
 void utree_dev_set_hip_error(int err, const char *what);

@@ -2,6 +2,10 @@
  *
  *     xtree-searchGG compTree.ctr fastaToSearch.fa output.txt [threads] [SPEED <X>] [RC]
  *
+ * and, compiled with -DUTREE_RANK_SPECIFIC, the rank-specific `xtree-search` (itree.c -D SEARCH; README.md:71-76),
+ * whose compile-time knobs SLACK / SPARSITY / TOLERANCE_THRESHOLD (itree.c:952-960) are read from the
+ * environment here: UTREE_SLACK, UTREE_SPARSITY, UTREE_TOLERANCE (defaults 2, 4, 2).  It uses one GPU.
+ *
  * Same positional arguments, same stdout banners, same exit codes (0 bad/malformed DB, 1 usage or input
  * file, 2 malformed read, 3 out of memory / short tree).  New behaviour is reachable only through
  * environment variables so the command line stays bit-compatible:
@@ -21,12 +25,17 @@
 #include "../../include/utree_amd.h"
 
 #define VER "[v2.0RF SigNature Edition]"          /* itree.c:1350 */
+#ifdef UTREE_RANK_SPECIFIC
+#define DO_GG 0
+#else
+#define DO_GG 1
+#endif
 static const char *TYPEARR[17] = {"NA", "uint8_t", "uint16_t", "NA", "uint32_t", "NA", "NA", "NA", "uint64_t", "NA", "NA",
                                   "NA", "NA", "NA", "NA", "NA", "__uint128_t"};
 
 int main(int argc, char *argv[]) {
     if (argc < 4) {                                                                       /* itree.c:1358-1360 */
-        printf(VER " usage: xtree-search%s compTree.ctr fastaToSearch.fa output.txt [threads] [SPEED <X>] [RC]\n", "GG");
+        printf(VER " usage: xtree-search%s compTree.ctr fastaToSearch.fa output.txt [threads] [SPEED <X>] [RC]\n", DO_GG ? "GG" : "");
         exit(1);
     }
     printf("This is UTree " VER "\n");
@@ -63,6 +72,7 @@ int main(int argc, char *argv[]) {
     int n_dev = n_vis;
     const char *eg = getenv("UTREE_GPUS");
     if (eg && atoi(eg) > 0 && atoi(eg) < n_dev) n_dev = atoi(eg);
+    if (!DO_GG) n_dev = 1;                                                                /* reads depend on their predecessors */
     utree_dev **devs = (utree_dev **)calloc((size_t)n_dev, sizeof(utree_dev *));
     int *ids = (int *)calloc((size_t)n_dev, sizeof(int));
     for (int i = 0; i < n_dev; ++i) ids[i] = i;
@@ -85,7 +95,16 @@ int main(int argc, char *argv[]) {
     fflush(stdout);
 
     utree_search_stats st;
+#ifdef UTREE_RANK_SPECIFIC
+    utree_rank_params prm;
+    utree_rank_params_default(&prm);
+    if (getenv("UTREE_SLACK")) prm.slack = (uint32_t)atoi(getenv("UTREE_SLACK"));
+    if (getenv("UTREE_SPARSITY")) prm.sparsity = (uint32_t)atoi(getenv("UTREE_SPARSITY"));
+    if (getenv("UTREE_TOLERANCE")) prm.tolerance = (uint32_t)atoi(getenv("UTREE_TOLERANCE"));
+    rc = utree_rank_search_file(ctr, devs[0], argv[2], argv[3], doRC, &prm, threads, &st);
+#else
     rc = utree_search_file(ctr, devs, n_dev, argv[2], argv[3], doRC, threads, &st);
+#endif
     if (rc == UTREE_E_IO) { puts("Invalid input files"); exit(1); }                      /* itree.c:835 */
     if (rc == UTREE_E_FASTA) {
         switch (st.fasta_error.code) {                                                    /* itree.c:872, 880, 886, 888 */

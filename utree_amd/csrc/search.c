@@ -74,6 +74,7 @@ typedef struct {
     int fd, fo;                                 /* input, output                                            */
     off_t out_pos;
     int do_rc, host_threads;
+    const utree_rank_params *rank;              /* non-NULL: the rank-specific `xtree-search` (rank.c), one device  */
     slot_t slot[NSLOTS];
     pthread_mutex_t mu; pthread_cond_t cv;
     int rc;                                     /* first error of any stage                                  */
@@ -196,8 +197,10 @@ static void *gpu_main(void *arg) {
             HIPOK(hipMemcpyAsync(c->d_buf, s->h_buf + lo, hi - lo, hipMemcpyHostToDevice, c->stream));
             HIPOK(hipMemcpyAsync(c->d_off, s->rel_off + first, count * 8, hipMemcpyHostToDevice, c->stream));
             HIPOK(hipMemcpyAsync(c->d_len, s->seq_len + first, count * 4, hipMemcpyHostToDevice, c->stream));
-            int e = utree_classify_batch(c->dev, c->d_buf, c->d_off, c->d_len, (uint32_t)count, total, mx, P->do_rc, c->d_out,
-                                         c->d_ws, c->ws_bytes, c->stream);
+            int e = P->rank ? utree_rank_batch(c->dev, c->d_buf, c->d_off, c->d_len, (uint32_t)count, total, mx, P->do_rc,
+                                               P->rank, c->d_out, c->d_ws, c->ws_bytes, c->stream)
+                            : utree_classify_batch(c->dev, c->d_buf, c->d_off, c->d_len, (uint32_t)count, total, mx, P->do_rc,
+                                                   c->d_out, c->d_ws, c->ws_bytes, c->stream);
             if (e) { set_error(P, e); return NULL; }
             HIPOK(hipMemcpyAsync(s->h_res + first, c->d_out, count * sizeof(utree_result), hipMemcpyDeviceToHost, c->stream));
         }
@@ -236,12 +239,15 @@ static void *writer_main(void *arg) {
                 const utree_result *q = &s->h_res[r];
                 if (!q->found) continue;
                 uint32_t ll = q->label < P->ctr->info.n_labels ? P->ctr->label_len[q->label] : 0;
-                need += (size_t)s->name_len[r] + ll + 48;
+                need += (size_t)s->name_len[r] + ll + 64;
             }
             if (need > fmt_cap[t]) { free(fmt_buf[t]); fmt_buf[t] = (char *)malloc(need + need / 4); fmt_cap[t] = fmt_buf[t] ? need + need / 4 : 0; }
             uint64_t good = 0;
-            size_t L = fmt_buf[t] ? utree_format_records(P->ctr, s->h_buf, s->name_off + a, s->name_len + a, s->h_res + a, b - a,
-                                                        fmt_buf[t], fmt_cap[t], &good) : (size_t)-1;
+            size_t L = !fmt_buf[t] ? (size_t)-1
+                       : P->rank ? utree_format_rank_records(P->ctr, s->h_buf, s->name_off + a, s->name_len + a, s->h_res + a, b - a,
+                                                             fmt_buf[t], fmt_cap[t], &good)
+                                 : utree_format_records(P->ctr, s->h_buf, s->name_off + a, s->name_len + a, s->h_res + a, b - a,
+                                                        fmt_buf[t], fmt_cap[t], &good);
             if (L == (size_t)-1) { fail |= 1; fmt_len[t] = 0; } else { fmt_len[t] = L; good_total += good; }
         }
         double t1 = now_s();
@@ -292,14 +298,14 @@ static void free_ctx(gpu_ctx *g) {
 
 #define HIPM(x) do { if ((x) != hipSuccess) { rc = UTREE_E_HIP; goto done; } } while (0)
 
-int utree_search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
-                      int do_rc, int host_threads, utree_search_stats *stats) {
+static int search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
+                       int do_rc, const utree_rank_params *rank, int host_threads, utree_search_stats *stats) {
     if (!ctr || !devs || n_dev < 1 || !fasta_path || !out_path) return UTREE_E_ARG;
     int rc = UTREE_OK;
     double t_start = now_s();
     pipe_t *P = (pipe_t *)calloc(1, sizeof *P);
     if (!P) return UTREE_E_NOMEM;
-    P->ctr = ctr; P->n_dev = n_dev; P->do_rc = do_rc;
+    P->ctr = ctr; P->n_dev = n_dev; P->do_rc = do_rc; P->rank = rank;
     P->fd = open(fasta_path, O_RDONLY);
     P->fo = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);                   /* fopen(outfile, "wb"), itree.c:834 */
     if (P->fd < 0 || P->fo < 0) {                                                 /* itree.c:835 */
@@ -329,7 +335,9 @@ int utree_search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const c
         HIPM(hipMalloc((void **)&c->d_off, MAX_READS_PER_BATCH * 8));
         HIPM(hipMalloc((void **)&c->d_len, MAX_READS_PER_BATCH * 4));
         HIPM(hipMalloc((void **)&c->d_out, MAX_READS_PER_BATCH * sizeof(utree_result)));
-        c->ws_bytes = utree_classify_workspace_bytes(devs[g], (uint32_t)MAX_READS_PER_BATCH, CHUNK_BYTES, LINELEN_MAX, do_rc);
+        c->ws_bytes = rank ? utree_rank_workspace_bytes(devs[g], (uint32_t)MAX_READS_PER_BATCH, CHUNK_BYTES, LINELEN_MAX, do_rc, rank)
+                           : utree_classify_workspace_bytes(devs[g], (uint32_t)MAX_READS_PER_BATCH, CHUNK_BYTES, LINELEN_MAX, do_rc);
+        if (!c->ws_bytes) { rc = UTREE_E_ARG; goto done; }
         HIPM(hipMalloc(&c->d_ws, c->ws_bytes));
     }
     {
@@ -366,4 +374,19 @@ done:
     pthread_cond_destroy(&P->cv);
     free(P);
     return rc;
+}
+
+int utree_search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
+                      int do_rc, int host_threads, utree_search_stats *stats) {
+    return search_file(ctr, devs, n_dev, fasta_path, out_path, do_rc, NULL, host_threads, stats);
+}
+
+/* XT_doSearch32(utree, in, out, 0, speed, doRC) (itree.c:1376 without DO_GG): the same three-stage pipeline; the
+ * batches go to ONE device in file order because each read's vote depends on the reads before it (rank.c). */
+int utree_rank_search_file(const utree_ctr *ctr, utree_dev *dev, const char *fasta_path, const char *out_path, int do_rc,
+                           const utree_rank_params *params, int host_threads, utree_search_stats *stats) {
+    if (!dev || !params) return UTREE_E_ARG;
+    int rc = utree_rank_reset(dev);
+    if (rc) return rc;
+    return search_file(ctr, &dev, 1, fasta_path, out_path, do_rc, params, host_threads, stats);
 }

@@ -93,6 +93,30 @@ int utk_classify_long(const utk_image *im, const uint8_t *d_bases, const uint64_
 int utk_vote(const utk_image *im, utree_result *d_out, const utk_workspace *ws, uint32_t n_reads, void *stream);
 int utk_lookup(const utk_image *im, const uint64_t *d_hi, const uint64_t *d_lo, uint64_t n, uint32_t *d_ix,
                void *stream);
+/* ---- rank-specific search (`xtree-search`, itree.c -D SEARCH): rank_kernels.hip --------------------------- */
+typedef struct {
+    unsigned long long *cursors;     /* [0] hit-list bump, [1..3] work counters (hits, short vote, long vote); 512 B */
+    uint32_t *nh;                    /* [n_reads] hits kept per read (foundUniq == kingsMen, itree.c:930,951)  */
+    uint64_t *hoff;                  /* [n_reads] where the read's hits start in `hits`                        */
+    uint32_t *hits;                  /* file-order label indices, in hit order                                 */
+    uint64_t hits_cap;
+    uint32_t *lvl[3];                /* maxima of nh over 64, 4096, 262144 consecutive reads                   */
+    uint32_t nlvl[3];
+    uint32_t *hist;                  /* long vote: [hist_waves][n_labels] counters, all zero between reads     */
+    uint32_t hist_waves;
+    uint32_t *state;                 /* the reference's never-cleared hit array, as far as later reads can see */
+    uint32_t state_cap;              /* it: state[j] = entry j of the latest read that had more than j hits    */
+    uint32_t step;                   /* PACKSIZE / SPARSITY (itree.c:950)                                      */
+    uint32_t slack, tolerance;       /* SLACK, TOLERANCE_THRESHOLD (itree.c:1000)                              */
+} utk_rank_ws;
+
+int utk_rank_hits(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
+                  uint32_t n_reads, int do_rc, const utk_rank_ws *ws, int n_cu, void *stream);
+int utk_rank_levels(const utk_rank_ws *ws, uint32_t n_reads, void *stream);
+int utk_rank_vote(const utk_image *im, utree_result *d_out, uint32_t n_reads, const utk_rank_ws *ws, int n_cu,
+                  void *stream);
+int utk_rank_state(uint32_t n_reads, const utk_rank_ws *ws, void *stream);
+
 const char *utk_classify_short_name(uint32_t W, uint32_t I);
 const char *utk_classify_long_name(void);
 

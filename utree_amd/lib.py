@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libutree_amd.so")
 CLI_PATH = os.path.join(_HERE, "xtree-searchGG")
 COMPRESS_CLI_PATH = os.path.join(_HERE, "xtree-compress")
+RANK_CLI_PATH = os.path.join(_HERE, "xtree-search")
 _LIB = None
 
 OK, E_IO, E_FORMAT, E_UNSUPPORTED, E_NOMEM, E_HIP, E_ARG, E_NOLABELS, E_FASTA, E_RCCL = range(10)
@@ -41,6 +42,11 @@ class SearchStats(C.Structure):
 class CompressStats(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_labels", C.c_uint64), ("label_count_total", C.c_uint64), ("W", C.c_uint32),
                 ("I", C.c_uint32), ("seconds", C.c_double)]
+
+
+class RankParams(C.Structure):
+    """SLACK, SPARSITY, TOLERANCE_THRESHOLD of the rank-specific search (itree.c:952-960)."""
+    _fields_ = [("slack", C.c_uint32), ("sparsity", C.c_uint32), ("tolerance", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -78,6 +84,16 @@ SYMBOLS = {
     "utree_format_records": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "utree_compress_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(CompressStats)]),
+    "utree_rank_params_default": (None, [C.POINTER(RankParams)]),
+    "utree_rank_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int,
+                                                C.POINTER(RankParams)]),
+    "utree_rank_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32,
+                                   C.c_int, C.POINTER(RankParams), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "utree_rank_reset": (C.c_int, [C.c_void_p]),
+    "utree_format_rank_records": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                               C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "utree_rank_search_file": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(RankParams),
+                                         C.c_int, C.POINTER(SearchStats)]),
     "utree_search_file": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
                                     C.POINTER(SearchStats)]),
 }

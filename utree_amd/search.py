@@ -63,8 +63,10 @@ class CtrDB:
         p = _lib.load().utree_ctr_label(self._h, ix, C.byref(n))
         return None if not p else C.string_at(p, n.value)
 
-    def format(self, buf: np.ndarray, name_off: np.ndarray, name_len: np.ndarray, results: np.ndarray) -> bytes:
-        """Output lines of itree.c:1032/1040/1096 for framed reads and their results."""
+    def format(self, buf: np.ndarray, name_off: np.ndarray, name_len: np.ndarray, results: np.ndarray,
+               rank: bool = False) -> bytes:
+        """Output lines of itree.c:1032/1040/1096 for framed reads and their results (rank=True: the
+        rank-specific search's lines, itree.c:1002)."""
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         name_off = np.ascontiguousarray(name_off, dtype=np.uint64)
         name_len = np.ascontiguousarray(name_len, dtype=np.uint32)
@@ -76,8 +78,9 @@ class CtrDB:
         while True:
             out = np.empty(cap, dtype=np.uint8)
             good = C.c_uint64(0)
-            L = _lib.load().utree_format_records(self._h, buf.ctypes.data, name_off.ctypes.data, name_len.ctypes.data,
-                                                 results.ctypes.data, n, out.ctypes.data, cap, C.byref(good))
+            fn = _lib.load().utree_format_rank_records if rank else _lib.load().utree_format_records
+            L = fn(self._h, buf.ctypes.data, name_off.ctypes.data, name_len.ctypes.data,
+                   results.ctypes.data, n, out.ctypes.data, cap, C.byref(good))
             if L != bad:
                 break
             if cap > (1 << 34):
@@ -208,6 +211,35 @@ class DeviceTree:
                                                     workspace.numel(), stream), "utree_classify_batch")
         return out
 
+    def rank_search(self, bases, off, length, rc: bool = False, slack: int = 2, sparsity: int = 4, tolerance: int = 2,
+                    total_bases: Optional[int] = None, max_len: Optional[int] = None, out=None):
+        """One batch of the rank-specific search (`xtree-search`, itree.c:969-1007).  Batches must come in file
+        order: each read's vote also counts an entry left by an earlier read (itree.c:982); rank_reset() starts a
+        new file.  Returns int32 [n, 6]: (mostIX, -2 printed / -4 not, hits kept, 0, most, secondMost)."""
+        import torch
+        n = off.numel()
+        dev = bases.device
+        if total_bases is None:
+            total_bases = int(length.sum().item())
+        if max_len is None:
+            max_len = int(length.max().item()) if n else 0
+        if out is None:
+            out = torch.empty((n, 6), dtype=torch.int32, device=dev)
+        prm = _lib.RankParams(slack, sparsity, tolerance)
+        need = _lib.load().utree_rank_workspace_bytes(self._h, n, total_bases, max_len, int(rc), C.byref(prm))
+        if n and not need:
+            raise _lib.UtreeError(_lib.E_ARG, "utree_rank_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.load().utree_rank_batch(self._h, bases.data_ptr(), off.data_ptr(), length.data_ptr(), n,
+                                                total_bases, max_len, int(rc), C.byref(prm), out.data_ptr(),
+                                                self._ws.data_ptr(), self._ws.numel(), stream), "utree_rank_batch")
+        return out
+
+    def rank_reset(self):
+        _lib.check(_lib.load().utree_rank_reset(self._h), "utree_rank_reset")
+
     def kernel_name(self) -> str:
         return _lib.load().utree_classify_kernel_name(self._h).decode()
 
@@ -239,6 +271,16 @@ def search_gg(db: CtrDB, trees: Sequence[DeviceTree], fasta: str, out: str, rc: 
     st = _lib.SearchStats()
     code = _lib.load().utree_search_file(db._h, arr, len(trees), fasta.encode(), out.encode(), int(rc), threads,
                                          C.byref(st))
+    return code, st
+
+
+def search_rank(db: CtrDB, tree: DeviceTree, fasta: str, out: str, rc: bool = False, slack: int = 2, sparsity: int = 4,
+                tolerance: int = 2, threads: int = 0):
+    """XT_doSearch32(utree, in, out, 0, speed, doRC): the `xtree-search` binary (itree.c:1376 without DO_GG)."""
+    st = _lib.SearchStats()
+    prm = _lib.RankParams(slack, sparsity, tolerance)
+    code = _lib.load().utree_rank_search_file(db._h, tree._h, fasta.encode(), out.encode(), int(rc), C.byref(prm), threads,
+                                              C.byref(st))
     return code, st
 
 
