@@ -39,7 +39,8 @@ class RankResult(C.Structure):
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "utree_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    src2 = os.path.join(_HERE, "utree_build_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(src2)):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -84,6 +85,9 @@ def lib():
         L.orc_rank_search_file.restype = C.c_int
         L.orc_rank_search_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(RankParams),
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+        L.orc_build_file.restype = C.c_int
+        L.orc_build_file.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -223,6 +227,15 @@ def rank_search_file(db: OracleDB, fasta: str, out: str, rc: bool = False, slack
     code = lib().orc_rank_search_file(db._h, fasta.encode(), out.encode(), int(rc), C.byref(prm), C.byref(nr),
                                       C.byref(gf), err, 512)
     return code, nr.value, gf.value, err.value.decode("latin-1")
+
+
+def build_file(fasta: str, mapfile: str, out_ubt: str, W: int = 8, I: int = 2, complevel: int = 1, gg: bool = True):
+    """`utree-build[GG] in.fa labels.map out.ubt threads complevel` restated.  Returns (exit_code, seqs, nodes, labels, err)."""
+    ns, nn, nl = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    err = C.create_string_buffer(512)
+    code = lib().orc_build_file(fasta.encode(), mapfile.encode(), out_ubt.encode(), W, I, complevel, int(gg), C.byref(ns),
+                                C.byref(nn), C.byref(nl), err, 512)
+    return code, ns.value, nn.value, nl.value, err.value.decode("latin-1")
 
 
 def windows(seq: bytes, k: int):

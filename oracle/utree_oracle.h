@@ -91,6 +91,12 @@ int orc_rank_search_file(const orc_db *db, const char *fasta, const char *out, i
                          const orc_rank_params *prm, uint64_t *n_reads, uint64_t *good_finds, char *err,
                          size_t errlen);
 
+/* ---- database BUILD: `utree-build` / `utree-buildGG` (itree.c -D BUILD / BUILD_GG), utree_build_oracle.c ---------
+ * FASTA (header line + sequence line per reference) + `name \t label` map -> `.ubt` and `<out>[.gg].log`.
+ * Returns 0 or the reference's exit code (1 files, 2 malformed map / FASTA / no k-mers, 4 name not in the map). */
+int orc_build_file(const char *fasta, const char *map, const char *out_ubt, int W, int I, int complevel, int gg,
+                   uint64_t *n_seqs, uint64_t *n_nodes, uint64_t *n_labels, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

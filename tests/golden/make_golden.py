@@ -659,6 +659,73 @@ def gen_rank(manifest, seed=777):
     manifest["rank_outputs"] = out_names
 
 
+def gen_build(manifest, seed=2025):
+    """database BUILD.  Inputs (FASTA + map) are committed; expected = SHA-256 of the `.ubt` and of the
+    `[.gg].log` the genuine `utree-build` / `utree-buildGG` (and the PACKSIZE=64 / IXTYPE=uint32_t builds) write."""
+    rng = np.random.default_rng(seed)
+    sets = {}
+    # (a) related references: k-mer collisions at every rank, several references per leaf label
+    leaves = make_taxonomy(rng, 60)
+    leaves = leaves + [leaves[int(i)] for i in rng.integers(0, 60, 40)]            # repeated labels
+    refs = make_refs(rng, leaves, 900, per_level_rate=0.004)
+    fa = b"".join(b">" + n.encode() + b"\n" + bytes(sq) + b"\n" for n, _, sq in refs)
+    mp = b"".join(n.encode() + b"\t" + t.encode() + b"\n" for n, t, _ in refs[::-1])   # map order != FASTA order
+    sets["rel"] = (fa, mp)
+    # (b) corners
+    def rs(n):
+        return bytes(rand_seq(rng, n))
+    A = "k__K;p__P;c__C;o__O;f__F;g__G;s__S1;t__T1"
+    B = "k__K;p__P;c__C;o__O;f__F;g__G;s__S2;t__T2"
+    Cc = "k__K;p__P2;c__C;o__O;f__F;g__G;s__S9;t__T9"
+    S, S2, S3, S4 = rs(300), rs(120), rs(150), rs(200)
+    items = [
+        ("r1 first", A, S), ("r2 same seq other species", B, S), ("r3 first label again", A, S), ("r4 other phylum", Cc, S),
+        ("r5", "k__K;p__P", S2), ("r6", "k__K;p__P;c__X", S2),
+        ("r7 lower", A, rs(100).lower()), ("r8 n", B, S4[:70] + b"N" + S4[71:140] + b"nn" + S4[142:]),
+        ("r9 short", A, rs(31)), ("r10 exact", B, rs(32)), ("r11 crlf", Cc, rs(90) + b"\r"),
+        ("r12", A, rs(80)),
+        ("r13", "a;b;c;d", S3), ("r14", "a;b;c;e", S3), ("r15", "a;b;c", S3), ("r16", "a;b;c;d", S3), ("r17", "a;b;x", S3),
+        ("r18 iupac", B, S4[:50] + b"RYK" + S4[53:120]),
+        ("r19 polyA", Cc, b"A" * 80), ("r20 polyA2", "k__K;p__P2;c__C;o__O2", b"A" * 70 + b"C" * 40),
+    ]
+    fa = b"".join(b">" + n.encode() + b"\n" + sq + b"\n" for n, _, sq in items)
+    mp = b"".join(n.encode() + b"\t" + t.encode() + b"\n" for n, t, _ in sorted(items, key=lambda x: x[0][::-1]))
+    sets["corner"] = (fa, mp)
+    sets["err_missing"] = (b">zz not in map\n" + rs(50) + b"\n", b"other\tk__K;p__P\n")
+    sets["err_map_no_newline"] = (b">a\n" + rs(50) + b"\n", b"a\tk__K;p__P")
+    sets["err_no_kmers"] = (b">a\n" + rs(20) + b"\n", b"a\tk__K;p__P\n")
+    sets["err_missing_seq"] = (b">a\n" + rs(50) + b"\n>b\n", b"a\tk__K;p__P\nb\tk__K;p__Q\n")
+    runs = [("rel", "utree-buildGG", 8, 2, c, 1) for c in (0, 1, 2, 4)] + [
+        ("rel", "utree-build", 8, 2, 1, 0), ("rel", "utree-buildGG-k64", 16, 2, 1, 1), ("rel", "utree-buildGG-ix32", 8, 4, 2, 1),
+        ("corner", "utree-buildGG", 8, 2, 0, 1), ("corner", "utree-buildGG", 8, 2, 1, 1), ("corner", "utree-build", 8, 2, 0, 0),
+        ("corner", "utree-buildGG-k64", 16, 2, 0, 1),
+        ("err_missing", "utree-buildGG", 8, 2, 0, 1), ("err_map_no_newline", "utree-buildGG", 8, 2, 0, 1),
+        ("err_no_kmers", "utree-buildGG", 8, 2, 0, 1), ("err_missing_seq", "utree-buildGG", 8, 2, 0, 1)]
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for nm, (fa, mp) in sets.items():
+            gz_write(os.path.join(HERE, "build_%s.fa.gz" % nm), fa)
+            gz_write(os.path.join(HERE, "build_%s.map.gz" % nm), mp)
+            open(os.path.join(td, nm + ".fa"), "wb").write(fa)
+            open(os.path.join(td, nm + ".map"), "wb").write(mp)
+        for nm, binn, W, I, cl, gg in runs:
+            ubt = os.path.join(td, "o.ubt")
+            log = ubt + (".gg.log" if gg else ".log")
+            for f in (ubt, log):
+                if os.path.exists(f):
+                    os.remove(f)
+            code, so, se = run([os.path.join(REF, binn), os.path.join(td, nm + ".fa"), os.path.join(td, nm + ".map"), ubt, "1", str(cl)])
+            tag = "%s_%s_c%d" % (nm, binn.replace("utree-", ""), cl)
+            rec = {"set": nm, "bin": binn, "W": W, "I": I, "complevel": cl, "gg": gg, "exit": code}
+            if code == 0:
+                rec["ubt_sha256"] = ctrfile.sha256_file(ubt)
+                rec["log_sha256"] = ctrfile.sha256_file(log)
+                rec["ubt_bytes"] = os.path.getsize(ubt)
+                rec["stdout_tail"] = so.decode(errors="replace").strip().splitlines()[-3:]
+            out[tag] = rec
+    manifest["build_outputs"] = out
+
+
 def main():
     if not os.path.exists(os.path.join(REF, "xtree-searchGG")):
         sys.exit("build the reference first: make -C oracle ref")
@@ -670,6 +737,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "rank":           # add the rank-specific (`xtree-search`) fixtures
         manifest = json.load(open(os.path.join(HERE, "manifest.json")))
         gen_rank(manifest)
+        json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "build":          # add the BUILD / BUILD_GG fixtures
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+        gen_build(manifest)
         json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "irregular":      # add the irregular-bin fixtures to an existing golden set
@@ -686,6 +758,7 @@ def main():
     gen_irregular(manifest)
     gen_compress(manifest)
     gen_rank(manifest)
+    gen_build(manifest)
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(manifest, indent=1, sort_keys=True))
 

@@ -148,3 +148,31 @@ def test_rank_vote_reads_one_stale_entry():
     assert rs.format(b"q", r) == b"q\t" + db.label(a) + b"\t1.000000\t2\n"
     r = rs.read(kmer_of[c].encode())                      # one hit (c) + stale a -> 1 : 1, not printed
     assert (r.found, r.most, r.second, r.printed) == (1, 1, 1, 0)
+
+
+# ---- database BUILD (`utree-build`, `utree-buildGG`): SURVEY §8(f) rank 3 ------------------------------
+BUILD_TAGS = sorted(util.manifest().get("build_outputs", {}))
+
+
+def build_inputs(setname, tmpdir):
+    fa = os.path.join(str(tmpdir), setname + ".fa")
+    mp = os.path.join(str(tmpdir), setname + ".map")
+    if not os.path.exists(fa):
+        open(fa, "wb").write(util.fixture_bytes("build_%s.fa.gz" % setname))
+        open(mp, "wb").write(util.fixture_bytes("build_%s.map.gz" % setname))
+    return fa, mp
+
+
+@pytest.mark.parametrize("tag", BUILD_TAGS)
+def test_build_matches_reference(tag, tmpdir_mod):
+    """`.ubt` and `[.gg].log` byte-identical (SHA-256) to what the genuine builders wrote: complevel 0/1/2/4, the
+    rank-specific BUILD, PACKSIZE=64, IXTYPE=uint32_t, collision chains down to BAD, and the exit codes of bad inputs."""
+    v = util.manifest()["build_outputs"][tag]
+    fa, mp = build_inputs(v["set"], tmpdir_mod)
+    ubt = os.path.join(str(tmpdir_mod), tag + ".ubt")
+    code, ns, nn, nl, err = orc.build_file(fa, mp, ubt, W=v["W"], I=v["I"], complevel=v["complevel"], gg=bool(v["gg"]))
+    assert code == v["exit"], err
+    if code == 0:
+        assert ctrfile.sha256_file(ubt) == v["ubt_sha256"]
+        assert ctrfile.sha256_file(ubt + (".gg.log" if v["gg"] else ".log")) == v["log_sha256"]
+        assert ("Total nodes in tree: %d [%d labels]" % (nn, nl)) in v["stdout_tail"]
