@@ -38,7 +38,8 @@ enum {
     UTREE_E_ARG = 6,         /* bad argument                                                                    */
     UTREE_E_NOLABELS = 7,    /* no label text after the node dump ("No annotation found in tree file.", 776)    */
     UTREE_E_FASTA = 8,       /* malformed read: details in utree_fasta_error (872, 880, 886, 888 -> exit 2)     */
-    UTREE_E_RCCL = 9
+    UTREE_E_RCCL = 9,
+    UTREE_E_BUILD = 10       /* BUILD input rejected: details in utree_build_stats.error_kind                   */
 };
 
 const char *utree_strerror(int code);
@@ -233,6 +234,36 @@ typedef struct {
 } utree_compress_stats;
 
 int utree_compress_file(const char *ubt_path, const char *ctr_path, int device, utree_compress_stats *stats);
+
+/* ------------------------------------------------------------------------------------------------
+ * Database BUILD = the `utree-build` / `utree-buildGG` binaries (itree.c -D BUILD / BUILD_GG, main 1379-1407:
+ * UT_parseSampFastaExternOSFA + UT_writeTreeBinary + UT_writeSamples).  SURVEY.md §8(f) rank 3.
+ * FASTA (one header line + one sequence line per reference) + `name \t label` map -> `<ubt_path>` and
+ * `<ubt_path>.gg.log` (gg) / `<ubt_path>.log`, byte-identical to the reference's.  PACKSIZE (4*W), IXTYPE (I bytes) and
+ * the compression level (itree.c:595-606) are run-time arguments; `gg` selects BUILD_GG's relabelling of colliding
+ * k-mers (itree.c:268-307) instead of BUILD's "collision = BAD" (242-266).  k-mers are extracted, sorted and folded
+ * on `device`; everything has to fit its HBM at once (about 36 B per k-mer occurrence plus the FASTA itself).
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+    UTREE_BUILD_E_MAP_EMPTY = 1,  /* "Input map empty." (itree.c:512)                         -> reference exit 1 */
+    UTREE_BUILD_E_MAP = 2,        /* malformed map line `error_line` (533-553)                -> exit 2           */
+    UTREE_BUILD_E_FASTA = 3,      /* header without sequence, reference `error_line` (585)    -> exit 2           */
+    UTREE_BUILD_E_NO_KMERS = 4,   /* "Error: no k-mers. Bad input/params!" (631)              -> exit 2           */
+    UTREE_BUILD_E_NAME = 5        /* "Error: taxon map incomplete (line %u)" (582)            -> exit 4           */
+};
+typedef struct {
+    uint64_t n_seqs;        /* references parsed (return value of UT_parseSampFastaExternOSFA)                    */
+    uint64_t n_kmers;       /* k-mers added, repeats included                                                     */
+    uint64_t n_nodes;       /* "Total nodes in tree: %llu" (itree.c:1337)                                         */
+    uint64_t n_labels;      /* "[%llu labels]"                                                                    */
+    uint64_t error_line;
+    int      error_kind;    /* UTREE_BUILD_E_* when the call returns UTREE_E_BUILD (or UTREE_E_IO for MAP_EMPTY)  */
+    uint32_t W, I;
+    double   seconds;
+} utree_build_stats;
+
+int utree_build_file(const char *fasta_path, const char *map_path, const char *ubt_path, uint32_t W, uint32_t I,
+                     int complevel, int gg, int device, utree_build_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ const char *utree_strerror(int code) {
         case UTREE_E_NOLABELS: return "No annotation found in tree file.";
         case UTREE_E_FASTA: return "malformed query file";
         case UTREE_E_RCCL: return "RCCL error";
+        case UTREE_E_BUILD: return "BUILD input rejected";
         default: return "unknown error";
     }
 }

@@ -13,9 +13,12 @@ SO_PATH = os.path.join(_HERE, "libutree_amd.so")
 CLI_PATH = os.path.join(_HERE, "xtree-searchGG")
 COMPRESS_CLI_PATH = os.path.join(_HERE, "xtree-compress")
 RANK_CLI_PATH = os.path.join(_HERE, "xtree-search")
+BUILD_GG_CLI_PATH = os.path.join(_HERE, "utree-buildGG")
+BUILD_CLI_PATH = os.path.join(_HERE, "utree-build")
 _LIB = None
 
-OK, E_IO, E_FORMAT, E_UNSUPPORTED, E_NOMEM, E_HIP, E_ARG, E_NOLABELS, E_FASTA, E_RCCL = range(10)
+OK, E_IO, E_FORMAT, E_UNSUPPORTED, E_NOMEM, E_HIP, E_ARG, E_NOLABELS, E_FASTA, E_RCCL, E_BUILD = range(11)
+BUILD_E_MAP_EMPTY, BUILD_E_MAP, BUILD_E_FASTA, BUILD_E_NO_KMERS, BUILD_E_NAME = range(1, 6)
 FINE_AUTO = -1
 
 
@@ -42,6 +45,12 @@ class SearchStats(C.Structure):
 class CompressStats(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_labels", C.c_uint64), ("label_count_total", C.c_uint64), ("W", C.c_uint32),
                 ("I", C.c_uint32), ("seconds", C.c_double)]
+
+
+class BuildStats(C.Structure):
+    _fields_ = [("n_seqs", C.c_uint64), ("n_kmers", C.c_uint64), ("n_nodes", C.c_uint64), ("n_labels", C.c_uint64),
+                ("error_line", C.c_uint64), ("error_kind", C.c_int), ("W", C.c_uint32), ("I", C.c_uint32),
+                ("seconds", C.c_double)]
 
 
 class RankParams(C.Structure):
@@ -94,6 +103,8 @@ SYMBOLS = {
                                                C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "utree_rank_search_file": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(RankParams),
                                          C.c_int, C.POINTER(SearchStats)]),
+    "utree_build_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(BuildStats)]),
     "utree_search_file": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
                                     C.POINTER(SearchStats)]),
 }

@@ -284,6 +284,14 @@ def search_rank(db: CtrDB, tree: DeviceTree, fasta: str, out: str, rc: bool = Fa
     return code, st
 
 
+def build(fasta: str, mapfile: str, ubt: str, W: int = 8, I: int = 2, complevel: int = 1, gg: bool = True, device: int = 0):
+    """`utree-build[GG] in.fa labels.map out.ubt threads complevel` (itree.c:1379-1407): returns (code, stats)."""
+    st = _lib.BuildStats()
+    code = _lib.load().utree_build_file(fasta.encode(), mapfile.encode(), ubt.encode(), W, I, complevel, int(gg), device,
+                                        C.byref(st))
+    return code, st
+
+
 def compress(ubt: str, ctr: str, device: int = 0):
     """XT_cmp32(preTree.ubt, compTree.ctr) (itree.c:1234): returns (code, stats)."""
     st = _lib.CompressStats()
