@@ -272,3 +272,15 @@ def test_64bit_offset_instantiations(torch_cuda, name, monkeypatch):
     got = classify_fasta_bytes(db, tree, util.fixture_bytes(util.READS_OF.get(name, name) + "_reads.fa.gz"), rc=False)
     assert got == util.fixture_bytes(name + "_out.txt.gz")
     tree.close()
+
+
+@pytest.mark.parametrize("name,parts", [("toy", 4), ("k64", 8), ("ix32", 64), ("katq2", 2), ("vote", 16)])
+def test_image_built_in_parts(torch_cuda, name, parts, monkeypatch):
+    """Trees of billions of nodes get their (hash, position, rest) order in 2..64 parts by the top hash bits so that the sort
+    buffers fit beside the image (tools/big_tree_check.py runs a 4.4 G-node tree); a hook forces that path on small ones."""
+    monkeypatch.setenv("UTREE_BUILD_PARTS", str(parts))
+    db = CtrDB.open(util.fixture_ctr(name))
+    tree = DeviceTree.upload(db, 0, 3)
+    got = classify_fasta_bytes(db, tree, util.fixture_bytes(util.READS_OF.get(name, name) + "_reads.fa.gz"), rc=False)
+    assert got == util.fixture_bytes(name + "_out.txt.gz")
+    tree.close()

@@ -207,6 +207,7 @@ static int build_finish(builder *b, const void *d_binix_raw) {
                       b->d_counters, st));
     HIPCHK(hipMemcpyAsync(counters, b->d_counters, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (timing_on()) fprintf(stderr, "[utree_amd] image: bin table checked (%llu irregular bins%s)\n", counters[0], counters[1] ? ", not monotone" : "");
     d->hdr.n_irregular = counters[0];
     uint64_t full_bytes = d->hdr.total_bytes;
     if (counters[1]) {
@@ -308,6 +309,7 @@ int utree_dev_upload(const utree_ctr *ctr, int device, int fine_bits, utree_dev 
     }
     HIPCHK(hipDeviceSynchronize());
     t2 = now_s();
+    if (timing_on()) fprintf(stderr, "[utree_amd] image: %llu nodes streamed and repacked in %.3f s\n", (unsigned long long)N, t2 - t1);
     HIPCHK(hipMalloc(&d_binix, (size_t)UTREE_NUMBINS * ctr->info.binix_width));
     HIPCHK(hipMemcpyAsync(d_binix, ctr->binix_raw, (size_t)UTREE_NUMBINS * ctr->info.binix_width, hipMemcpyHostToDevice, NULL));
     rc = build_finish(&b, d_binix);

@@ -9,7 +9,13 @@
 //   table_k      direct-mapped table over the top B hash bits: empty / the single record inline / run descriptor
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include "device_common.hpp"
 
 using namespace utk;
@@ -47,23 +53,41 @@ template <typename OFF> __global__ void widen_binix_k(const void *raw, uint32_t 
     coarse[i] = (OFF)(width == 4 ? (uint64_t)((const uint32_t *)raw)[i] : ((const uint64_t *)raw)[i]);
 }
 
+// the 24-bit bin that holds node j of a monotone table: largest p with coarse[p] <= j (< coarse[p+1])
+template <typename OFF> __device__ __forceinline__ uint32_t bin_of(const OFF *__restrict__ coarse, uint64_t j) {
+    uint32_t a = 0, b = UTREE_NUMBINS - 1;
+    while (b - a > 1) { const uint32_t m = a + ((b - a) >> 1); if ((uint64_t)coarse[m] <= j) a = m; else b = m; }
+    return a;
+}
+
+// Work is spread over NODES, not bins: a `.ctr` may put billions of nodes into one bin (the reference only ever
+// binary-searches inside a bin, itree.c:699-707), and one thread per bin would then walk it alone.
+template <typename OFF>
+__global__ void monotone_k(const OFF *__restrict__ coarse, uint64_t n_nodes, unsigned long long *counters) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= UTREE_NUMBINS - 1) return;
+    const uint64_t s = coarse[p], e = coarse[p + 1];
+    if (s > e || e > n_nodes) counters[1] = 1;
+}
+constexpr uint32_t NODE_RUN = 16;     // consecutive nodes per thread: one binary search, then the bin only moves forward
 template <int W, int I, typename OFF>
 __global__ void validate_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t n_nodes,
                            uint32_t *irreg, unsigned long long *counters) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= UTREE_NUMBINS - 1) return;
-    uint64_t s = coarse[p], e = coarse[p + 1];
-    if (s > e || e > n_nodes) { counters[1] = 1; return; }
-    if (e - s < 2) return;
-    Key<W> prev = file_key<W, I>(recs, s);
-    for (uint64_t j = s + 1; j < e; ++j) {
-        Key<W> cur = file_key<W, I>(recs, j);
-        if (!key_lt<W>(prev, cur)) {
-            atomicOr(&irreg[p >> 5], 1u << (p & 31));
-            atomicAdd(&counters[0], 1ull);
-            return;
+    if (counters[1]) return;                                           // not monotone: every bin takes the exact-probe path anyway
+    const uint64_t c0 = coarse[0], cN = coarse[UTREE_NUMBINS - 1];
+    for (uint64_t j0 = c0 + 1 + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * NODE_RUN; j0 < cN;
+         j0 += (uint64_t)gridDim.x * blockDim.x * NODE_RUN) {
+        uint32_t p = bin_of<OFF>(coarse, j0);
+        const uint64_t j1 = j0 + NODE_RUN < cN ? j0 + NODE_RUN : cN;
+        for (uint64_t j = j0; j < j1; ++j) {
+            while ((uint64_t)coarse[p + 1] <= j) ++p;
+            if (j == (uint64_t)coarse[p]) continue;                    // first node of its bin
+            if (!key_lt<W>(file_key<W, I>(recs, j - 1), file_key<W, I>(recs, j))) {
+                const uint32_t bit = 1u << (p & 31);                   // look first: a bin that is all out of order would
+                if (!(__atomic_load_n(&irreg[p >> 5], __ATOMIC_RELAXED) & bit) &&   // otherwise queue one atomic per node
+                    !(atomicOr(&irreg[p >> 5], bit) & bit)) atomicAdd(&counters[0], 1ull);
+            }
         }
-        prev = cur;
     }
 }
 
@@ -81,22 +105,25 @@ template <typename IDX, typename T> __global__ void gather_k(const T *__restrict
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
 }
 
-// one thread per 24-bit bin: minimizer pieces of every node the bin table reaches (nodes [c0, cN))
+// minimizer pieces of every node the bin table reaches (nodes [c0, c0+m)); one thread per node, its bin by binary search
 template <int W, int I, typename OFF>
-__global__ void assign_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t c0,
+__global__ void assign_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t c0, uint64_t m,
                          uint32_t *__restrict__ H, uint64_t *__restrict__ K1, uint64_t *__restrict__ K2) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= UTREE_NUMBINS - 1) return;
-    const uint64_t s = coarse[p], e = coarse[p + 1];
-    for (uint64_t j = s; j < e; ++j) {
-        const Key<W> k = file_key<W, I>(recs, j);
-        uint64_t khi, klo;
-        if constexpr (W == 16) { khi = ((uint64_t)p << 40) | k.hi; klo = k.lo; } else { khi = 0; klo = ((uint64_t)p << 40) | k.lo; }
-        uint32_t h, pos, rh; uint64_t rl;
-        minimizer<W>(khi, klo, h, pos, rh, rl);
-        H[j - c0] = h;
-        if constexpr (W == 16) { K1[j - c0] = rl; K2[j - c0] = ((uint64_t)pos << 32) | rh; }
-        else K1[j - c0] = ((uint64_t)pos << 32) | rl;
+    for (uint64_t t0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * NODE_RUN; t0 < m; t0 += (uint64_t)gridDim.x * blockDim.x * NODE_RUN) {
+        uint64_t p = bin_of<OFF>(coarse, c0 + t0);
+        const uint64_t t1 = t0 + NODE_RUN < m ? t0 + NODE_RUN : m;
+        for (uint64_t t = t0; t < t1; ++t) {
+            const uint64_t j = c0 + t;
+            while ((uint64_t)coarse[p + 1] <= j) ++p;
+            const Key<W> k = file_key<W, I>(recs, j);
+            uint64_t khi, klo;
+            if constexpr (W == 16) { khi = (p << 40) | k.hi; klo = k.lo; } else { khi = 0; klo = (p << 40) | k.lo; }
+            uint32_t h, pos, rh; uint64_t rl;
+            minimizer<W>(khi, klo, h, pos, rh, rl);
+            H[t] = h;
+            if constexpr (W == 16) { K1[t] = rl; K2[t] = ((uint64_t)pos << 32) | rh; }
+            else K1[t] = ((uint64_t)pos << 32) | rl;
+        }
     }
 }
 
@@ -120,8 +147,10 @@ __global__ void emit_k(const uint64_t *__restrict__ recs, uint64_t c0, const IDX
 }
 
 template <int W, int I>
-__global__ void table_k(const uint32_t *__restrict__ Hs, const uint64_t *__restrict__ mrecs, uint64_t m, uint32_t B,
+__global__ void table_k(const uint32_t *__restrict__ Hs, const uint64_t *__restrict__ mrecs, uint64_t base, uint64_t m, uint32_t B,
                         uint64_t *__restrict__ table, unsigned long long *overflow) {
+    // Hs / mrecs: this part's sorted hashes and records (a part = a range of the top hash bits, so no slot straddles
+    // two parts); base = MIN records in earlier parts
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t b = (uint64_t)Hs[j] >> (32 - B);
@@ -136,7 +165,7 @@ __global__ void table_k(const uint32_t *__restrict__ Hs, const uint64_t *__restr
             if (n >= (1ull << 22)) { atomicAdd(overflow, 1ull); n = (1ull << 22) - 1; }
 #pragma unroll
             for (int x = 0; x < EW; ++x) o[x] = 0;
-            o[KW] = MFLAG_RUN | (n << 40) | (j & M40);
+            o[KW] = MFLAG_RUN | (n << 40) | ((base + j) & M40);
         }
     }
 }
@@ -184,7 +213,36 @@ int sort_pass32(const uint32_t *key_by_node, IDX *&idx, IDX *&idx_alt, uint32_t 
     return (int)hipGetLastError();
 }
 
-// the whole MIN structure for nodes [c0, c0+m): table (2^B slots, pre-filled here) and MIN records
+// Parts of the hash range [lo, hi) (hi as uint64: the last part ends at 2^32).  The minimizer hash is a MINIMUM of 17 or
+// 49 hashes, so it crowds towards 0: parts are cut at quantiles of a sample, rounded to table-slot boundaries.
+struct part_bounds { uint64_t cut[65]; uint32_t n; };                 // part q = [cut[q], cut[q+1])
+__global__ void part_hist_k(const uint32_t *__restrict__ H, uint64_t m, part_bounds pbnd, unsigned long long *__restrict__ counts) {
+    __shared__ unsigned int s[64];
+    if (threadIdx.x < 64) s[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = H[i];
+        uint32_t q = 0;
+        while (q + 1 < pbnd.n && h >= pbnd.cut[q + 1]) ++q;
+        atomicAdd(&s[q], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && s[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s[threadIdx.x]);
+}
+__global__ void sample_k(const uint32_t *__restrict__ H, uint64_t m, uint64_t stride, uint32_t n, uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = H[(uint64_t)i * stride < m ? (uint64_t)i * stride : m - 1];
+}
+constexpr uint64_t SEL_CHUNK = 1ull << 30;
+struct in_part {
+    uint64_t lo, hi;
+    __device__ bool operator()(uint32_t h) const { return h >= lo && h < hi; }
+};
+
+// The whole MIN structure for nodes [c0, c0+m): table (2^B slots, pre-filled here) and MIN records.
+// The (hash, position, rest) order is produced by stable LSD radix passes over node indices, which cost 32 bytes per
+// node on top of the 12-20 bytes of keys; when that does not fit beside the image (trees of billions of nodes) the
+// nodes are handled in 2^pb parts by the top bits of the hash -- parts are contiguous in the final order.
 template <int W, int I, typename OFF, typename IDX>
 int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, uint32_t B, uint64_t *table, uint64_t *mrecs,
               unsigned long long *d_overflow, hipStream_t st) {
@@ -195,38 +253,122 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
     uint32_t *H = nullptr, *Hg = nullptr, *Hg2 = nullptr;
     uint64_t *K1 = nullptr, *K2 = nullptr, *kg = nullptr, *kg2 = nullptr;
     IDX *idx = nullptr, *idx2 = nullptr;
+    unsigned long long *d_counts = nullptr;
     void *tmp = nullptr;
-    size_t t64 = 0, t32 = 0;
+    size_t t64 = 0, t32 = 0, tsel = 0;
     int rc = 0;
+    uint32_t nparts = 1;
+    part_bounds pbnd;
+    uint64_t cap = m, base = 0;
+    unsigned long long h_counts[65] = {0};
+    const bool chat = getenv("UTREE_TIMING") != nullptr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto done; } } while (0)
     CK(hipMalloc((void **)&H, m * 4)); CK(hipMalloc((void **)&K1, m * 8));
     if (W == 16) CK(hipMalloc((void **)&K2, m * 8));
-    CK(hipMalloc((void **)&idx, m * sizeof(IDX))); CK(hipMalloc((void **)&idx2, m * sizeof(IDX)));
-    CK(hipMalloc((void **)&kg, m * 8)); CK(hipMalloc((void **)&kg2, m * 8));
-    CK(rocprim::radix_sort_pairs(nullptr, t64, kg, kg2, idx, idx2, m, 0, 64, st));
-    CK(rocprim::radix_sort_pairs(nullptr, t32, (uint32_t *)kg, (uint32_t *)kg2, idx, idx2, m, 0, 32, st));
-    if (t32 > t64) t64 = t32;
-    CK(hipMalloc(&tmp, t64 ? t64 : 8));
-    assign_k<W, I, OFF><<<(UTREE_NUMBINS + 255) / 256, 256, 0, st>>>(coarse, recs, c0, H, K1, K2);
-    iota_k<IDX><<<grid_for(m), 256, 0, st>>>(idx, m);
-    // least significant key first; every pass is stable
-    if (W == 16) {
-        if ((rc = sort_pass<IDX>(K1, 64, idx, idx2, kg, kg2, m, tmp, t64, st))) goto done;      // rest, low 64 bits
-        if ((rc = sort_pass<IDX>(K2, 38, idx, idx2, kg, kg2, m, tmp, t64, st))) goto done;      // position | rest high 32
-    } else {
-        if ((rc = sort_pass<IDX>(K1, 37, idx, idx2, kg, kg2, m, tmp, t64, st))) goto done;      // position | rest
+    if (chat) { CK(hipStreamSynchronize(st)); fprintf(stderr, "[utree_amd] image: table cleared, key buffers allocated\n"); }
+    assign_k<W, I, OFF><<<grid_for(m), 256, 0, st>>>(coarse, recs, c0, m, H, K1, K2);
+    if (chat) { CK(hipStreamSynchronize(st)); fprintf(stderr, "[utree_amd] image: minimizers of %llu nodes assigned\n", (unsigned long long)m); }
+    {
+        // smallest number of parts whose sort buffers fit what is left of the HBM, each sort below 2^31 items
+        size_t free_b = 0, total_b = 0;
+        CK(hipMemGetInfo(&free_b, &total_b));
+        const char *env = getenv("UTREE_BUILD_PARTS");
+        const uint64_t per = 2 * sizeof(IDX) + 16;
+        for (nparts = 1; nparts < 64; ++nparts) {
+            const uint64_t c = m / nparts + m / (nparts * 8) + 4096;                   // 12 % slack for uneven parts
+            if (c < (1ull << 31) && c * per + (c >> 2) + ((uint64_t)1 << 30) <= free_b) break;
+        }
+        if (env && *env && atoi(env) >= 1 && atoi(env) <= 64) nparts = (uint32_t)atoi(env);
+        pbnd.n = nparts; pbnd.cut[0] = 0; pbnd.cut[nparts] = 1ull << 32;
+        if (nparts > 1) {
+            constexpr uint32_t NS = 1u << 18;
+            uint32_t *d_s = nullptr;
+            uint32_t *h_s = (uint32_t *)malloc(sizeof(uint32_t) * NS);
+            if (!h_s) { rc = (int)hipErrorOutOfMemory; goto done; }
+            const uint32_t ns = m < NS ? (uint32_t)m : NS;
+            if (hipMalloc((void **)&d_s, NS * 4) != hipSuccess) { free(h_s); rc = (int)hipErrorOutOfMemory; goto done; }
+            sample_k<<<(ns + 255) / 256, 256, 0, st>>>(H, m, m / ns, ns, d_s);
+            hipError_t e1 = hipMemcpyAsync(h_s, d_s, 4ull * ns, hipMemcpyDeviceToHost, st), e2 = hipStreamSynchronize(st);
+            (void)hipFree(d_s);
+            if (e1 != hipSuccess || e2 != hipSuccess) { free(h_s); rc = (int)(e1 != hipSuccess ? e1 : e2); goto done; }
+            std::sort(h_s, h_s + ns);
+            const uint64_t slot = 1ull << (32 - B);                                    // cuts fall on table-slot boundaries
+            for (uint32_t q = 1; q < nparts; ++q) {
+                uint64_t c = h_s[(uint64_t)ns * q / nparts];
+                c -= c % slot;
+                pbnd.cut[q] = c < pbnd.cut[q - 1] ? pbnd.cut[q - 1] : c;
+            }
+            free(h_s);
+            CK(hipMalloc((void **)&d_counts, 64 * 8));
+            CK(hipMemsetAsync(d_counts, 0, 64 * 8, st));
+            part_hist_k<<<(grid_for(m) > 4096 ? 4096 : grid_for(m)), 256, 0, st>>>(H, m, pbnd, d_counts);
+            CK(hipMemcpyAsync(h_counts, d_counts, 64 * 8, hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st));
+            cap = 0;
+            for (uint32_t q = 0; q < nparts; ++q) if (h_counts[q] > cap) cap = h_counts[q];
+            if (!cap) cap = 1;
+            if (chat) {
+                fprintf(stderr, "[utree_amd] image: %u parts, largest %llu nodes (free HBM %.1f GiB); cuts", nparts, (unsigned long long)cap, (double)free_b / 1073741824.0);
+                for (uint32_t q = 1; q < nparts && q < 8; ++q) fprintf(stderr, " %llx", (unsigned long long)pbnd.cut[q]);
+                fprintf(stderr, "; counts");
+                for (uint32_t q = 0; q < nparts && q < 8; ++q) fprintf(stderr, " %llu", h_counts[q]);
+                fprintf(stderr, "\n");
+            }
+        }
     }
-    Hg = (uint32_t *)kg; Hg2 = (uint32_t *)kg2;
-    if ((rc = sort_pass32<IDX>(H, idx, idx2, Hg, Hg2, m, tmp, t64, st))) goto done;             // minimizer hash
-    // Hg2 now holds the sorted hashes but emit_k recomputes them from H[idx]: reuse Hg as the sorted-hash array
-    emit_k<W, I, IDX><<<grid_for(m), 256, 0, st>>>(recs, c0, idx, H, K1, K2, B, m, mrecs, Hg);
-    table_k<W, I><<<grid_for(m), 256, 0, st>>>(Hg, mrecs, m, B, table, d_overflow);
-    CK(hipGetLastError());
+    CK(hipMalloc((void **)&idx, cap * sizeof(IDX))); CK(hipMalloc((void **)&idx2, cap * sizeof(IDX)));
+    CK(hipMalloc((void **)&kg, cap * 8)); CK(hipMalloc((void **)&kg2, cap * 8));
+    CK(rocprim::radix_sort_pairs(nullptr, t64, kg, kg2, idx, idx2, cap, 0, 64, st));
+    CK(rocprim::radix_sort_pairs(nullptr, t32, (uint32_t *)kg, (uint32_t *)kg2, idx, idx2, cap, 0, 32, st));
+    if (t32 > t64) t64 = t32;
+    if (nparts > 1) {
+        auto flags = rocprim::make_transform_iterator(H, in_part{0, 1});
+        CK(rocprim::select(nullptr, tsel, rocprim::counting_iterator<IDX>(0), flags, idx, d_counts, SEL_CHUNK < m ? SEL_CHUNK : m, st));
+        if (tsel > t64) t64 = tsel;
+    }
+    CK(hipMalloc(&tmp, t64 ? t64 : 8));
+    for (uint32_t q = 0; q < nparts; ++q) {
+        uint64_t mq = m;
+        if (nparts > 1) {
+            mq = h_counts[q];
+            if (!mq) continue;
+            // node indices of this part, ascending; the selection runs over 2^30 nodes at a time
+            uint64_t got = 0;
+            for (uint64_t a = 0; a < m; a += SEL_CHUNK) {
+                const uint64_t cnt = m - a < SEL_CHUNK ? m - a : SEL_CHUNK;
+                auto flags = rocprim::make_transform_iterator(H + a, in_part{pbnd.cut[q], pbnd.cut[q + 1]});
+                unsigned long long sel = 0;
+                CK(rocprim::select(tmp, t64, rocprim::counting_iterator<IDX>((IDX)a), flags, idx + got, d_counts, cnt, st));
+                CK(hipMemcpyAsync(&sel, d_counts, 8, hipMemcpyDeviceToHost, st));
+                CK(hipStreamSynchronize(st));
+                got += sel;
+                if (got > mq) { rc = (int)hipErrorUnknown; goto done; }
+            }
+            if (got != mq) { rc = (int)hipErrorUnknown; goto done; }
+            if (chat) fprintf(stderr, "[utree_amd] image: part %u of %u, %llu nodes selected\n", q + 1, nparts, (unsigned long long)mq);
+        } else iota_k<IDX><<<grid_for(m), 256, 0, st>>>(idx, m);
+        // least significant key first; every pass is stable
+        if (W == 16) {
+            if ((rc = sort_pass<IDX>(K1, 64, idx, idx2, kg, kg2, mq, tmp, t64, st))) goto done;      // rest, low 64 bits
+            if ((rc = sort_pass<IDX>(K2, 38, idx, idx2, kg, kg2, mq, tmp, t64, st))) goto done;      // position | rest high 32
+        } else {
+            if ((rc = sort_pass<IDX>(K1, 37, idx, idx2, kg, kg2, mq, tmp, t64, st))) goto done;      // position | rest
+        }
+        Hg = (uint32_t *)kg; Hg2 = (uint32_t *)kg2;
+        if ((rc = sort_pass32<IDX>(H, idx, idx2, Hg, Hg2, mq, tmp, t64, st))) goto done;             // minimizer hash
+        // Hg2 now holds the sorted hashes but emit_k recomputes them from H[idx]: reuse Hg as the sorted-hash array
+        emit_k<W, I, IDX><<<grid_for(mq), 256, 0, st>>>(recs, c0, idx, H, K1, K2, B, mq, mrecs + base * EW, Hg);
+        table_k<W, I><<<grid_for(mq), 256, 0, st>>>(Hg, mrecs + base * EW, base, mq, B, table, d_overflow);
+        CK(hipGetLastError());
+        if (chat) { CK(hipStreamSynchronize(st)); fprintf(stderr, "[utree_amd] image: part %u sorted and emitted\n", q + 1); }
+        base += mq;
+    }
     CK(hipStreamSynchronize(st));
+    if (base != m) rc = (int)hipErrorUnknown;
 done:
 #undef CK
     (void)hipFree(H); (void)hipFree(K1); (void)hipFree(K2); (void)hipFree(idx); (void)hipFree(idx2); (void)hipFree(kg);
-    (void)hipFree(kg2); (void)hipFree(tmp);
+    (void)hipFree(kg2); (void)hipFree(tmp); (void)hipFree(d_counts);
     return rc;
 }
 
@@ -251,12 +393,14 @@ int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_
 
 int utk_validate(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
                  uint32_t *d_irreg, unsigned long long *d_counters, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (off64) monotone_k<uint64_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, st>>>((const uint64_t *)d_coarse, n_nodes, d_counters);
+    else monotone_k<uint32_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, st>>>((const uint32_t *)d_coarse, n_nodes, d_counters);
+    const unsigned blocks = grid_for(n_nodes) > 65536 ? 65536 : grid_for(n_nodes);
     return dispatch_wi(W_, I_, [&](auto w, auto i) {
         constexpr int W = decltype(w)::value, I = decltype(i)::value;
-        if (off64) validate_k<W, I, uint64_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
-            (const uint64_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
-        else validate_k<W, I, uint32_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
-            (const uint32_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
+        if (off64) validate_k<W, I, uint64_t><<<dim3(blocks), dim3(256), 0, st>>>((const uint64_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
+        else validate_k<W, I, uint32_t><<<dim3(blocks), dim3(256), 0, st>>>((const uint32_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
     });
 }
 
