@@ -119,3 +119,18 @@ def test_build_cli_drop_in(gg, tmp_path):
     efa, emp = inputs("err_missing", tmp_path)
     r = subprocess.run([cli, efa, emp, ubt + "2", "0", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 4 and b"taxon map incomplete" in r.stdout
+
+
+@pytest.mark.parametrize("tag,limit", [("rel_buildGG_c0", 3000), ("rel_buildGG-k64_c1", 700), ("corner_buildGG_c0", 400),
+                                       ("rel_build_c1", 1000), ("rel_buildGG-ix32_c2", 100000)])
+def test_build_in_kmer_range_passes(tag, limit, tmp_path, monkeypatch):
+    """Large inputs are built in passes over ranges of k-mers (each sort below 2^31 items, buffers sized to the free HBM);
+    a hook forces many small passes here.  Label numbering must not notice: its clock is the position in the input."""
+    monkeypatch.setenv("UTREE_BUILD_PASS_KMERS", str(limit))
+    v = BUILDS[tag]
+    fa, mp = inputs(v["set"], tmp_path)
+    ubt = str(tmp_path / "o.ubt")
+    code, st = build(fa, mp, ubt, W=v["W"], I=v["I"], complevel=v["complevel"], gg=bool(v["gg"]))
+    assert code == lib.OK
+    assert ctrfile.sha256_file(ubt) == v["ubt_sha256"]
+    assert ctrfile.sha256_file(ubt + (".gg.log" if v["gg"] else ".log")) == v["log_sha256"]

@@ -242,17 +242,13 @@ int utree_build_file(const char *fasta_path, const char *map_path, const char *u
     st.n_kmers = res.n_occ; st.n_nodes = res.n_nodes;
     if (!res.n_occ) { rc = UTREE_E_BUILD; st.error_kind = UTREE_BUILD_E_NO_KMERS; goto done; }          /* 631: exit 2 */
     /* ---- label indices in the reference's order of creation: a reference's label when the reference is parsed (583),
-     *      a cut label at the collision that first produced it (297) ---- */
+     *      a cut label at the collision that first produced it (297); the clock is the position in the input ---- */
     {
         uint64_t nev = 0;
         ev = (event *)malloc(sizeof(event) * ((size_t)n_refs + U.n + 1));
         ix_of_u = (uint32_t *)malloc(sizeof(uint32_t) * (U.n + 1));
         if (!ev || !ix_of_u) { rc = UTREE_E_NOMEM; goto done; }
-        uint64_t next_base = res.n_occ;
-        for (uint32_t r = n_refs; r-- > 0;) {                                           /* references without positions: the next one's count */
-            if (res.h_ref_base[r] == ~0ull) res.h_ref_base[r] = next_base; else next_base = res.h_ref_base[r];
-        }
-        for (uint32_t r = 0; r < n_refs; ++r) { ev[nev].time = 2 * res.h_ref_base[r]; ev[nev].seq = r; ev[nev].u = ref_u[r]; ++nev; }
+        for (uint32_t r = 0; r < n_refs; ++r) { ev[nev].time = res.h_ref_time[r]; ev[nev].seq = r; ev[nev].u = ref_u[r]; ++nev; }
         for (uint32_t u = 0; u < U.n; ++u) if (res.h_first_time[u] != ~0ull) { ev[nev].time = res.h_first_time[u]; ev[nev].seq = 0; ev[nev].u = u; ++nev; }
         qsort(ev, nev, sizeof(event), by_time);
         memset(ix_of_u, 0xFF, sizeof(uint32_t) * (U.n + 1));
@@ -293,7 +289,7 @@ int utree_build_file(const char *fasta_path, const char *map_path, const char *u
 done:
     if (fd >= 0) close(fd);
     if (S) utk_build_free(S);
-    free(res.h_first_time); free(res.h_ref_base);
+    free(res.h_first_time); free(res.h_ref_time);
     free(ev); free(ix_of_u); free(per_label);
     free(seq_off); free(seq_len); free(ref_u); free(trunc_off); free(trunc_ids);
     st_free(&U);

@@ -22,8 +22,9 @@ typedef struct {
 
 typedef struct {
     uint64_t total_pos, n_occ, n_nodes;  /* positions examined, k-mers added (with repeats), nodes kept                 */
-    uint64_t *h_first_time;              /* [n_u] 2*ordinal+1 of the first collision that produced the label, or ~0     */
-    uint64_t *h_ref_base;                /* [n_refs] k-mers added before reference r (~0: the reference has no position) */
+    uint32_t n_passes;
+    uint64_t *h_first_time;              /* [n_u] 2*position+1 of the first collision that produced the label, or ~0    */
+    uint64_t *h_ref_time;                /* [n_refs] 2*(positions before reference r): when its own label is created    */
 } utk_build_result;
 
 typedef struct utk_build_state utk_build_state;
