@@ -40,4 +40,5 @@ if os.path.exists(ref) and not os.environ.get("SKIP_REFERENCE"):
     out["log_identical"] = ctrfile.sha256_file(d + "/ours.ubt.gg.log") == ctrfile.sha256_file(d + "/ref.ubt.gg.log")
     out["speedup"] = out["reference_seconds"] / out["ours_seconds"]
 print(json.dumps(out, indent=1))
-for f in os.listdir(d): os.remove(os.path.join(d, f))
+if not os.environ.get("KEEP_FILES"):
+    for f in os.listdir(d): os.remove(os.path.join(d, f))

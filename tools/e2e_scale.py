@@ -115,8 +115,9 @@ def main():
             sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
             out["parity_files_identical"] = (sha(ref) == sha(ours))
             print(json.dumps(out, indent=1))
-            for f in os.listdir(args.dir):
-                os.remove(os.path.join(args.dir, f))
+            if not os.environ.get("KEEP_FILES"):
+                for f in os.listdir(args.dir):
+                    os.remove(os.path.join(args.dir, f))
             return
         # ordered comparison on a prefix with ONE reference thread
         n = min(args.prefix_reads, args.reads)
@@ -138,8 +139,9 @@ def main():
                 sweep[str(t)] = args.reads / max(1e-9, secs - load_secs)
             out["reference_thread_sweep_reads_per_second"] = sweep
     print(json.dumps(out, indent=1))
-    for f in os.listdir(args.dir):
-        os.remove(os.path.join(args.dir, f))
+    if not os.environ.get("KEEP_FILES"):
+        for f in os.listdir(args.dir):
+            os.remove(os.path.join(args.dir, f))
 
 
 if __name__ == "__main__":
