@@ -173,6 +173,15 @@ size_t utree_format_records(const utree_ctr *ctr, const uint8_t *h_buf, const ui
                             const uint32_t *name_len, const utree_result *h_res, size_t n, char *h_out, size_t cap,
                             uint64_t *good_finds);
 
+/* Opt-in input formats the reference does not read.  UTREE_INPUT_REFERENCE is the reference's
+ * framing (utree_fasta_frame); the others frame complete records serially and, for multi-line FASTA, compact the sequence
+ * lines in place.  Error codes: 1 truncated record, 2 record does not start with '@' / '>', 3 FASTQ separator line is not
+ * '+', 5 sequence too long.  With a non-reference format the *_opts file functions also read gzip-compressed input. */
+enum { UTREE_INPUT_REFERENCE = 0, UTREE_INPUT_FASTQ = 1, UTREE_INPUT_FASTA_MULTILINE = 2, UTREE_INPUT_AUTO = 3 };
+int utree_reads_frame(uint8_t *h_buf, size_t n, int final, int format, size_t max_reads, uint64_t *seq_off,
+                      uint32_t *seq_len, uint64_t *name_off, uint32_t *name_len, size_t *n_reads, size_t *consumed,
+                      utree_fasta_error *err);
+
 /* ------------------------------------------------------------------------------------------------
  * Whole search = XT_doSearch32(utree, in, out, 8, speed, doRC) (itree.c:833-1108, GG branch), reads
  * sharded over `n_dev` device images, output lines in input order (= the reference with 1 thread).
@@ -186,6 +195,9 @@ typedef struct {
 
 int utree_search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path,
                       const char *out_path, int do_rc, int host_threads, utree_search_stats *stats);
+/* Same with an opt-in input format (UTREE_INPUT_*; AUTO looks at the first byte); gzip input is read through zlib. */
+int utree_search_file_opts(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *reads_path,
+                           const char *out_path, int do_rc, int host_threads, int input_format, utree_search_stats *stats);
 
 /* ------------------------------------------------------------------------------------------------
  * Rank-specific search = the `xtree-search` binary (itree.c -D SEARCH: XT_doSearch32 with doCollapse = 0,
@@ -221,6 +233,9 @@ size_t utree_format_rank_records(const utree_ctr *ctr, const uint8_t *h_buf, con
 /* Whole file on ONE device image (the reference runs this branch on one thread); resets the carried array first. */
 int utree_rank_search_file(const utree_ctr *ctr, utree_dev *dev, const char *fasta_path, const char *out_path,
                            int do_rc, const utree_rank_params *params, int host_threads, utree_search_stats *stats);
+int utree_rank_search_file_opts(const utree_ctr *ctr, utree_dev *dev, const char *reads_path, const char *out_path,
+                                int do_rc, const utree_rank_params *params, int host_threads, int input_format,
+                                utree_search_stats *stats);
 
 /* ------------------------------------------------------------------------------------------------
  * `.ubt` -> `.ctr` = XT_cmp32(filename, outfile) (itree.c:1234-1315; `xtree-compress`), SURVEY.md §8(f) rank 2.

@@ -284,3 +284,32 @@ def test_image_built_in_parts(torch_cuda, name, parts, monkeypatch):
     got = classify_fasta_bytes(db, tree, util.fixture_bytes(util.READS_OF.get(name, name) + "_reads.fa.gz"), rc=False)
     assert got == util.fixture_bytes(name + "_out.txt.gz")
     tree.close()
+
+
+@pytest.mark.parametrize("kind", ["fastq", "fastq_gz", "multiline", "multiline_gz", "auto_fastq", "auto_fasta_gz"])
+def test_opt_in_input_formats_give_the_reference_output(torch_cuda, kind, tmp_path):
+    """the toy reads rewritten as FASTQ / multi-line FASTA, plain or gzip, classify to exactly the
+    golden output of the reference on the two-line FASTA (opt-in: the default framing stays the reference's)."""
+    import gzip as gz
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    names, off, ln = util.parse_fasta(data)
+    reads = [(names[i], data[off[i]:off[i] + ln[i]]) for i in range(len(names))]
+    if "fastq" in kind:
+        blob = b"".join(b"@" + n + b" c\n" + s + b"\n+" + n + b"\n" + b"#" * len(s) + b"\n" for n, s in reads)
+    else:
+        blob = b"".join(b">" + n + b" c\n" + b"".join(s[a:a + 60] + b"\n" for a in range(0, len(s), 60)) for n, s in reads)
+    path = tmp_path / ("reads." + kind)
+    path.write_bytes(gz.compress(blob, 1) if kind.endswith("gz") else blob)
+    fmt = lib.INPUT_AUTO if kind.startswith("auto") else (lib.INPUT_FASTQ if "fastq" in kind else lib.INPUT_FASTA_MULTILINE)
+    db, tree = tree_for("toy")
+    for rc in (0, 1):
+        out = tmp_path / "o.txt"
+        code, st = search_gg(db, [tree], str(path), str(out), rc=bool(rc), threads=4, input_format=fmt)
+        assert code == lib.OK and st.n_reads == len(reads)
+        assert out.read_bytes() == util.fixture_bytes("toy_out%s.txt.gz" % ("_rc" if rc else ""))
+    # the command line: UTREE_INPUT
+    out = tmp_path / "cli.txt"
+    env = dict(os.environ, UTREE_INPUT="auto")
+    r = subprocess.run([lib.CLI_PATH, util.fixture_ctr("toy"), str(path), str(out), "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and out.read_bytes() == util.fixture_bytes("toy_out.txt.gz")

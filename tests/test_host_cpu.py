@@ -205,3 +205,53 @@ def test_parallel_framing_equals_serial_framing():
     # odd number of lines at the end: "can't read sequence"
     a, b = _frame_both(data + b">last\n", True)
     assert a["error_code"] == b["error_code"] == 1 and len(a["seq_off"]) == len(b["seq_off"]) == 150_000
+
+
+# ---- opt-in input formats: same reads as FASTQ / multi-line FASTA frame to the same sequences ----
+def _as_fastq(reads):
+    return b"".join(b"@" + n + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n" for n, s in reads)
+
+
+def _as_multiline(reads, width=37, crlf=False):
+    nl = b"\r\n" if crlf else b"\n"
+    out = []
+    for n, s in reads:
+        out.append(b">" + n + nl)
+        for a in range(0, max(len(s), 1), width):
+            out.append(s[a:a + width] + nl)
+    return b"".join(out)
+
+
+def test_fastq_and_multiline_fasta_frame_like_two_line_fasta():
+    from utree_amd import lib
+    from utree_amd.search import frame_reads
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    fr = frame_fasta(data, final=True)
+    reads = []
+    for i in range(0, len(fr["seq_off"]), 7):
+        s, l = int(fr["seq_off"][i]), int(fr["seq_len"][i])
+        no, nl = int(fr["name_off"][i]), int(fr["name_len"][i])
+        reads.append((data[no:no + nl] + b" some comment", data[s:s + l]))
+    for fmt, blob in ((lib.INPUT_FASTQ, _as_fastq(reads)), (lib.INPUT_FASTA_MULTILINE, _as_multiline(reads)),
+                      (lib.INPUT_FASTA_MULTILINE, _as_multiline(reads, 1000)), (lib.INPUT_FASTA_MULTILINE, _as_multiline(reads, 11, True))):
+        g = frame_reads(blob, fmt)
+        assert g["error_code"] == 0 and len(g["seq_off"]) == len(reads) and g["consumed"] == len(blob)
+        b = g["buf"].tobytes()
+        for i, (n, s) in enumerate(reads):
+            so, sl = int(g["seq_off"][i]), int(g["seq_len"][i])
+            no, nl = int(g["name_off"][i]), int(g["name_len"][i])
+            assert b[so:so + sl] == s and b[no:no + nl] == n.split(b" ")[0]
+    # chunked input: nothing is consumed past the last complete record, and the rest frames the same later
+    blob = _as_multiline(reads)
+    cut = len(blob) // 2
+    g = frame_reads(blob[:cut], lib.INPUT_FASTA_MULTILINE, final=False)
+    assert 0 < g["consumed"] <= cut and blob[g["consumed"]:g["consumed"] + 1] == b">"
+    g2 = frame_reads(blob[g["consumed"]:], lib.INPUT_FASTA_MULTILINE, final=True)
+    assert len(g["seq_off"]) + len(g2["seq_off"]) == len(reads)
+    q = _as_fastq(reads)
+    g = frame_reads(q[: len(q) // 3], lib.INPUT_FASTQ, final=False)
+    assert q[g["consumed"]:g["consumed"] + 1] == b"@"
+    # malformed
+    assert frame_reads(b"ACGT\nACGT\n", lib.INPUT_FASTQ)["error_code"] == 2
+    assert frame_reads(b"@r\nACGT\nACGT\nIIII\n", lib.INPUT_FASTQ)["error_code"] == 3
+    assert frame_reads(b"@r\nACGT\n", lib.INPUT_FASTQ)["error_code"] in (1, 3)

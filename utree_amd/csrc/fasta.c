@@ -166,6 +166,85 @@ int utree_fasta_frame(const uint8_t *buf, size_t n, int final, size_t max_reads,
     return rc;
 }
 
+/* ---- opt-in input formats the reference does not read: FASTQ and multi-line FASTA ----------
+ * Serial framing of complete records in h_buf[0..n).  Same outputs as utree_fasta_frame; multi-line FASTA sequences are
+ * compacted IN PLACE (line ends removed) so that the device sees contiguous bases.  Names follow the reference's rule
+ * (bytes after the first byte of the header up to the first space / newline / NUL, itree.c:881). */
+static size_t line_end(const uint8_t *buf, size_t n, size_t pos, int *complete) {
+    const uint8_t *nl = (const uint8_t *)memchr(buf + pos, '\n', n - pos);
+    if (nl) { *complete = 1; return (size_t)(nl - buf) + 1; }
+    *complete = 0;
+    return n;
+}
+static size_t strip_eol(const uint8_t *buf, size_t a, size_t b) {          /* [a,b) minus one trailing "\n" and one "\r" */
+    if (b > a && buf[b - 1] == '\n') --b;
+    if (b > a && buf[b - 1] == '\r') --b;
+    return b;
+}
+int utree_reads_frame(uint8_t *buf, size_t n, int final, int format, size_t max_reads, uint64_t *seq_off, uint32_t *seq_len,
+                      uint64_t *name_off, uint32_t *name_len, size_t *n_reads, size_t *consumed, utree_fasta_error *err) {
+    if (!buf || !seq_off || !seq_len || !name_off || !name_len || !n_reads || !consumed || !err) return UTREE_E_ARG;
+    if (format != UTREE_INPUT_FASTQ && format != UTREE_INPUT_FASTA_MULTILINE) return UTREE_E_ARG;
+    size_t pos = 0, nr = 0;
+    err->code = 0; err->read_index = 0;
+    const uint8_t lead = format == UTREE_INPUT_FASTQ ? '@' : '>';
+    while (pos < n && nr < max_reads) {
+        int c1;
+        size_t h_end = line_end(buf, n, pos, &c1);
+        if (!c1 && !final) break;                                       /* header continues in the next chunk */
+        if (buf[pos] != lead) { err->code = 2; err->read_index = nr + 1; *n_reads = nr; *consumed = pos; return UTREE_E_FASTA; }
+        size_t e = pos + 1;
+        while (e < h_end && buf[e] && buf[e] != ' ' && buf[e] != '\n') ++e;
+        size_t s0, s1, next;
+        if (format == UTREE_INPUT_FASTQ) {
+            int c2, c3, c4;
+            if (h_end >= n) { if (!final) break; err->code = 1; err->read_index = nr; *n_reads = nr; *consumed = pos; return UTREE_E_FASTA; }
+            size_t q_end = line_end(buf, n, h_end, &c2);               /* sequence line */
+            if (!c2 && !final) break;
+            size_t p_end = q_end < n ? line_end(buf, n, q_end, &c3) : n;   /* '+' line */
+            if ((q_end >= n || !c3) && !final) break;
+            size_t l_end = p_end < n ? line_end(buf, n, p_end, &c4) : n;   /* quality line */
+            if ((p_end >= n || !c4) && !final) break;
+            if (q_end >= n || buf[q_end] != '+') { err->code = 3; err->read_index = nr + 1; *n_reads = nr; *consumed = pos; return UTREE_E_FASTA; }
+            s0 = h_end; s1 = strip_eol(buf, h_end, q_end);
+            next = l_end;
+        } else {
+            /* sequence lines up to the next header line (or the end of the input) */
+            size_t p = h_end, w = h_end;
+            int closed = 0;
+            while (p < n) {
+                if (buf[p] == '>') { closed = 1; break; }
+                int cl;
+                size_t le = line_end(buf, n, p, &cl);
+                if (!cl && !final) { p = n + 1; break; }               /* line not complete yet */
+                p = le;
+            }
+            if (p == n + 1 || (!closed && !final)) break;               /* the record may go on in the next chunk */
+            /* compact in place */
+            size_t q = h_end;
+            while (q < p) {
+                int cl;
+                size_t le = line_end(buf, n, q, &cl);
+                if (le > p) le = p;
+                size_t b = strip_eol(buf, q, le);
+                if (w != q) memmove(buf + w, buf + q, b - q);
+                w += b - q;
+                q = le;
+            }
+            s0 = h_end; s1 = w;
+            next = p;
+        }
+        if (s1 - s0 > 0x3FFFFFFFu) { err->code = 5; err->read_index = nr + 1; *n_reads = nr; *consumed = pos; return UTREE_E_FASTA; }
+        seq_off[nr] = s0; seq_len[nr] = (uint32_t)(s1 - s0);
+        name_off[nr] = pos + 1; name_len[nr] = (uint32_t)(e - (pos + 1));
+        ++nr;
+        pos = next;
+    }
+    *n_reads = nr;
+    *consumed = pos;
+    return UTREE_OK;
+}
+
 static inline char *put_u32(char *o, uint32_t v) {
     char tmp[10];
     int n = 0;

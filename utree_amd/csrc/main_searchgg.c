@@ -11,6 +11,8 @@
  * environment variables so the command line stays bit-compatible:
  *     UTREE_GPUS=<n>        number of GPUs to use (default: all visible)
  *     UTREE_FINE_BITS=<F>   extra prefix bits of the device index (default: auto)
+ *     UTREE_INPUT=auto|fastq|fasta   opt-in: FASTQ / multi-line FASTA records, plain or gzip (default: the reference's
+ *                           two-lines-per-read framing, bit-compatible)
  * `threads` sizes the host formatting team (the GPU does the search).  `SPEED` is parsed and ignored, as
  * in the reference (itree.c:858, 907-918).
  */
@@ -95,15 +97,20 @@ int main(int argc, char *argv[]) {
     fflush(stdout);
 
     utree_search_stats st;
+    int fmt = UTREE_INPUT_REFERENCE;
+    const char *ei = getenv("UTREE_INPUT");
+    if (ei && !strcmp(ei, "auto")) fmt = UTREE_INPUT_AUTO;
+    else if (ei && !strcmp(ei, "fastq")) fmt = UTREE_INPUT_FASTQ;
+    else if (ei && !strcmp(ei, "fasta")) fmt = UTREE_INPUT_FASTA_MULTILINE;
 #ifdef UTREE_RANK_SPECIFIC
     utree_rank_params prm;
     utree_rank_params_default(&prm);
     if (getenv("UTREE_SLACK")) prm.slack = (uint32_t)atoi(getenv("UTREE_SLACK"));
     if (getenv("UTREE_SPARSITY")) prm.sparsity = (uint32_t)atoi(getenv("UTREE_SPARSITY"));
     if (getenv("UTREE_TOLERANCE")) prm.tolerance = (uint32_t)atoi(getenv("UTREE_TOLERANCE"));
-    rc = utree_rank_search_file(ctr, devs[0], argv[2], argv[3], doRC, &prm, threads, &st);
+    rc = utree_rank_search_file_opts(ctr, devs[0], argv[2], argv[3], doRC, &prm, threads, fmt, &st);
 #else
-    rc = utree_search_file(ctr, devs, n_dev, argv[2], argv[3], doRC, threads, &st);
+    rc = utree_search_file_opts(ctr, devs, n_dev, argv[2], argv[3], doRC, threads, fmt, &st);
 #endif
     if (rc == UTREE_E_IO) { puts("Invalid input files"); exit(1); }                      /* itree.c:835 */
     if (rc == UTREE_E_FASTA) {

@@ -19,6 +19,7 @@
 #include <string.h>
 #include <time.h>
 #include <unistd.h>
+#include <zlib.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -75,6 +76,8 @@ typedef struct {
     off_t out_pos;
     int do_rc, host_threads;
     const utree_rank_params *rank;              /* non-NULL: the rank-specific `xtree-search` (rank.c), one device  */
+    int input_format;                           /* UTREE_INPUT_*: opt-in FASTQ / multi-line FASTA (+ gzip via zlib)   */
+    gzFile gz;
     slot_t slot[NSLOTS];
     pthread_mutex_t mu; pthread_cond_t cv;
     int rc;                                     /* first error of any stage                                  */
@@ -123,7 +126,16 @@ static void *reader_main(void *arg) {
         if (carry) memmove(s->h_buf, carry_src, carry);
         size_t have = carry;
         double t0 = now_s();
-        if (!eof) {
+        if (!eof && P->gz) {                      /* opt-in formats: zlib reads plain and gzip input alike */
+            size_t want = CHUNK_BYTES - have, done = 0;
+            while (done < want) {
+                int r = gzread(P->gz, s->h_buf + have + done, (unsigned)(want - done > (1u << 30) ? (1u << 30) : want - done));
+                if (r < 0) { set_error(P, UTREE_E_IO); return NULL; }
+                if (r == 0) { eof = 1; break; }
+                done += (size_t)r;
+            }
+            have += done;
+        } else if (!eof) {
             /* parallel pread: the page-cache copy is the cost; several threads stream it */
             size_t want = CHUNK_BYTES - have;
             ssize_t got[READ_THREADS];
@@ -151,8 +163,13 @@ static void *reader_main(void *arg) {
         double t1 = now_s();
         s->have = have;
         s->nr = 0; s->used = 0; s->frame_rc = UTREE_OK; s->last = 0;
+        if (have && P->input_format == UTREE_INPUT_AUTO)
+            P->input_format = s->h_buf[0] == '@' ? UTREE_INPUT_FASTQ : UTREE_INPUT_FASTA_MULTILINE;
         if (have) {
-            s->frame_rc = utree_fasta_frame(s->h_buf, have, eof, MAX_READS_PER_BATCH, s->seq_off, s->seq_len, s->name_off,
+            s->frame_rc = P->input_format != UTREE_INPUT_REFERENCE
+                ? utree_reads_frame(s->h_buf, have, eof, P->input_format, MAX_READS_PER_BATCH, s->seq_off, s->seq_len, s->name_off,
+                                    s->name_len, &s->nr, &s->used, &s->ferr)
+                : utree_fasta_frame(s->h_buf, have, eof, MAX_READS_PER_BATCH, s->seq_off, s->seq_len, s->name_off,
                                             s->name_len, &s->nr, &s->used, &s->ferr);
             if (s->frame_rc != UTREE_OK && s->frame_rc != UTREE_E_FASTA) { set_error(P, s->frame_rc); return NULL; }
             if (s->frame_rc == UTREE_OK && !s->nr && !s->used && !eof) {
@@ -299,13 +316,13 @@ static void free_ctx(gpu_ctx *g) {
 #define HIPM(x) do { if ((x) != hipSuccess) { rc = UTREE_E_HIP; goto done; } } while (0)
 
 static int search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
-                       int do_rc, const utree_rank_params *rank, int host_threads, utree_search_stats *stats) {
-    if (!ctr || !devs || n_dev < 1 || !fasta_path || !out_path) return UTREE_E_ARG;
+                       int do_rc, const utree_rank_params *rank, int host_threads, int input_format, utree_search_stats *stats) {
+    if (!ctr || !devs || n_dev < 1 || !fasta_path || !out_path || input_format < 0 || input_format > UTREE_INPUT_AUTO) return UTREE_E_ARG;
     int rc = UTREE_OK;
     double t_start = now_s();
     pipe_t *P = (pipe_t *)calloc(1, sizeof *P);
     if (!P) return UTREE_E_NOMEM;
-    P->ctr = ctr; P->n_dev = n_dev; P->do_rc = do_rc; P->rank = rank;
+    P->ctr = ctr; P->n_dev = n_dev; P->do_rc = do_rc; P->rank = rank; P->input_format = input_format;
     P->fd = open(fasta_path, O_RDONLY);
     P->fo = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);                   /* fopen(outfile, "wb"), itree.c:834 */
     if (P->fd < 0 || P->fo < 0) {                                                 /* itree.c:835 */
@@ -313,6 +330,11 @@ static int search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const 
         if (P->fo >= 0) close(P->fo);
         free(P);
         return UTREE_E_IO;
+    }
+    if (input_format != UTREE_INPUT_REFERENCE) {
+        P->gz = gzdopen(dup(P->fd), "rb");
+        if (!P->gz) { close(P->fd); close(P->fo); free(P); return UTREE_E_IO; }
+        gzbuffer(P->gz, 1u << 20);
     }
 #ifdef _OPENMP
     if (host_threads <= 0) host_threads = omp_get_max_threads();
@@ -353,6 +375,7 @@ static int search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const 
         rc = P->rc;
     }
 done:
+    if (P->gz) gzclose(P->gz);
     if (P->fd >= 0) close(P->fd);
     if (P->fo >= 0) close(P->fo);
     if (P->G) { for (int g = 0; g < n_dev; ++g) free_ctx(&P->G[g]); free(P->G); }
@@ -378,15 +401,23 @@ done:
 
 int utree_search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
                       int do_rc, int host_threads, utree_search_stats *stats) {
-    return search_file(ctr, devs, n_dev, fasta_path, out_path, do_rc, NULL, host_threads, stats);
+    return search_file(ctr, devs, n_dev, fasta_path, out_path, do_rc, NULL, host_threads, UTREE_INPUT_REFERENCE, stats);
+}
+int utree_search_file_opts(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *reads_path, const char *out_path,
+                           int do_rc, int host_threads, int input_format, utree_search_stats *stats) {
+    return search_file(ctr, devs, n_dev, reads_path, out_path, do_rc, NULL, host_threads, input_format, stats);
 }
 
 /* XT_doSearch32(utree, in, out, 0, speed, doRC) (itree.c:1376 without DO_GG): the same three-stage pipeline; the
  * batches go to ONE device in file order because each read's vote depends on the reads before it (rank.c). */
 int utree_rank_search_file(const utree_ctr *ctr, utree_dev *dev, const char *fasta_path, const char *out_path, int do_rc,
                            const utree_rank_params *params, int host_threads, utree_search_stats *stats) {
+    return utree_rank_search_file_opts(ctr, dev, fasta_path, out_path, do_rc, params, host_threads, UTREE_INPUT_REFERENCE, stats);
+}
+int utree_rank_search_file_opts(const utree_ctr *ctr, utree_dev *dev, const char *reads_path, const char *out_path, int do_rc,
+                                const utree_rank_params *params, int host_threads, int input_format, utree_search_stats *stats) {
     if (!dev || !params) return UTREE_E_ARG;
     int rc = utree_rank_reset(dev);
     if (rc) return rc;
-    return search_file(ctr, &dev, 1, fasta_path, out_path, do_rc, params, host_threads, stats);
+    return search_file(ctr, &dev, 1, reads_path, out_path, do_rc, params, host_threads, input_format, stats);
 }

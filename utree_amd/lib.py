@@ -20,6 +20,7 @@ _LIB = None
 OK, E_IO, E_FORMAT, E_UNSUPPORTED, E_NOMEM, E_HIP, E_ARG, E_NOLABELS, E_FASTA, E_RCCL, E_BUILD = range(11)
 BUILD_E_MAP_EMPTY, BUILD_E_MAP, BUILD_E_FASTA, BUILD_E_NO_KMERS, BUILD_E_NAME = range(1, 6)
 FINE_AUTO = -1
+INPUT_REFERENCE, INPUT_FASTQ, INPUT_FASTA_MULTILINE, INPUT_AUTO = range(4)
 
 
 class CtrInfo(C.Structure):
@@ -103,6 +104,12 @@ SYMBOLS = {
                                                C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]),
     "utree_rank_search_file": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(RankParams),
                                          C.c_int, C.POINTER(SearchStats)]),
+    "utree_reads_frame": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(FastaError)]),
+    "utree_search_file_opts": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
+                                         C.c_int, C.POINTER(SearchStats)]),
+    "utree_rank_search_file_opts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(RankParams),
+                                              C.c_int, C.c_int, C.POINTER(SearchStats)]),
     "utree_build_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                    C.POINTER(BuildStats)]),
     "utree_search_file": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int,

@@ -121,6 +121,28 @@ def frame_fasta(data: bytes, final: bool = True):
                 consumed=used.value, error_code=err.code if rc else 0, error_read=err.read_index)
 
 
+def frame_reads(data: bytes, fmt: int, final: bool = True):
+    """Opt-in input formats (FASTQ, multi-line FASTA).  Returns the framing AND the buffer: multi-line
+    sequences are compacted in place, so offsets refer to the returned array, not to `data`."""
+    buf = np.frombuffer(data, dtype=np.uint8).copy()
+    cap = max(1, data.count(b"\n") + 2)
+    seq_off = np.zeros(cap, dtype=np.uint64)
+    seq_len = np.zeros(cap, dtype=np.uint32)
+    name_off = np.zeros(cap, dtype=np.uint64)
+    name_len = np.zeros(cap, dtype=np.uint32)
+    n = C.c_size_t(0)
+    used = C.c_size_t(0)
+    err = _lib.FastaError()
+    rc = _lib.load().utree_reads_frame(buf.ctypes.data if len(buf) else None, len(buf), int(final), fmt, cap,
+                                       seq_off.ctypes.data, seq_len.ctypes.data, name_off.ctypes.data,
+                                       name_len.ctypes.data, C.byref(n), C.byref(used), C.byref(err))
+    if rc not in (_lib.OK, _lib.E_FASTA):
+        _lib.check(rc, "utree_reads_frame")
+    k = n.value
+    return dict(buf=buf, seq_off=seq_off[:k], seq_len=seq_len[:k], name_off=name_off[:k], name_len=name_len[:k],
+                consumed=used.value, error_code=err.code if rc else 0, error_read=err.read_index)
+
+
 class DeviceTree:
     """The database resident in one GPU's HBM (device image)."""
 
@@ -264,23 +286,25 @@ class DeviceTree:
             pass
 
 
-def search_gg(db: CtrDB, trees: Sequence[DeviceTree], fasta: str, out: str, rc: bool = False, threads: int = 0):
-    """XT_doSearch32(utree, in, out, 8, speed, doRC) (itree.c:833): returns the stats struct; raises UtreeError
-    for the reference's exit(1)/exit(2) conditions (stats.fasta_error says which)."""
+def search_gg(db: CtrDB, trees: Sequence[DeviceTree], fasta: str, out: str, rc: bool = False, threads: int = 0,
+              input_format: int = _lib.INPUT_REFERENCE):
+    """XT_doSearch32(utree, in, out, 8, speed, doRC) (itree.c:833): returns (code, stats); stats.fasta_error says which of
+    the reference's exit(2) conditions a malformed read hit.  input_format != INPUT_REFERENCE opts into FASTQ / multi-line
+    FASTA / gzip input."""
     arr = (C.c_void_p * len(trees))(*[t._h for t in trees])
     st = _lib.SearchStats()
-    code = _lib.load().utree_search_file(db._h, arr, len(trees), fasta.encode(), out.encode(), int(rc), threads,
-                                         C.byref(st))
+    code = _lib.load().utree_search_file_opts(db._h, arr, len(trees), fasta.encode(), out.encode(), int(rc), threads,
+                                              input_format, C.byref(st))
     return code, st
 
 
 def search_rank(db: CtrDB, tree: DeviceTree, fasta: str, out: str, rc: bool = False, slack: int = 2, sparsity: int = 4,
-                tolerance: int = 2, threads: int = 0):
+                tolerance: int = 2, threads: int = 0, input_format: int = _lib.INPUT_REFERENCE):
     """XT_doSearch32(utree, in, out, 0, speed, doRC): the `xtree-search` binary (itree.c:1376 without DO_GG)."""
     st = _lib.SearchStats()
     prm = _lib.RankParams(slack, sparsity, tolerance)
-    code = _lib.load().utree_rank_search_file(db._h, tree._h, fasta.encode(), out.encode(), int(rc), C.byref(prm), threads,
-                                              C.byref(st))
+    code = _lib.load().utree_rank_search_file_opts(db._h, tree._h, fasta.encode(), out.encode(), int(rc), C.byref(prm),
+                                                   threads, input_format, C.byref(st))
     return code, st
 
 
