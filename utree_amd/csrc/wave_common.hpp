@@ -5,6 +5,10 @@
 #include <stdint.h>
 #include "device_common.hpp"
 
+#ifndef UTREE_RUN_HEAD
+#define UTREE_RUN_HEAD 2
+#endif
+
 namespace utk {
 
 // ------------------------------------------------------------------------------------------------
@@ -47,14 +51,23 @@ __device__ __forceinline__ uint32_t resolve_entry(const utk_image &im, const Ent
     if (flag == 0) return mkey_eq<W>(mrec_key<W, I>(t), mk) ? mrec_rank<W, I>(t) : INVALID;   // the slot's only node
     if (flag == 1) return INVALID;                                                            // empty slot
     const uint64_t d = t.w[RecTraits<W, I>::KW];
-    const uint64_t start = d & M40, end = start + ((d >> 40) & 0x3FFFFFull);
-    const Entry<W, I> r0 = load_entry<W, I>(im.mrecs, start), r1 = load_entry<W, I>(im.mrecs, start + 1);
-    const MinKey<W> k0 = mrec_key<W, I>(r0), k1 = mrec_key<W, I>(r1);
-    if (mkey_eq<W>(k0, mk)) return mrec_rank<W, I>(r0);
-    if (mkey_lt<W>(mk, k0)) return INVALID;
-    if (mkey_eq<W>(k1, mk)) return mrec_rank<W, I>(r1);
-    if (end - start == 2 || mkey_lt<W>(mk, k1)) return INVALID;
-    return min_find<W, I>(im.mrecs, start + 2, end, mk);
+    const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull, end = start + n;
+    // A run = the k-mers that share this minimizer.  Minimizers are minima, so most nodes sit in runs of 2-8 records (mean
+    // 3.5 at 0.28 nodes per slot).  The first RUN_HEAD records are fetched together, the rest by binary search.  Fetching
+    // 4 at once saves round trips but measured 3 % slower than 2 (5.33 vs 5.18 ms per 4 M reads, r01).
+    constexpr int RUN_HEAD = RecTraits<W, I>::EW == 1 ? UTREE_RUN_HEAD : 2;
+    Entry<W, I> r[RUN_HEAD];
+#pragma unroll
+    for (int i = 0; i < RUN_HEAD; ++i) r[i] = load_entry<W, I>(im.mrecs, start + i);
+#pragma unroll
+    for (int i = 0; i < RUN_HEAD; ++i) {
+        if ((uint64_t)i >= n) return INVALID;
+        const MinKey<W> k = mrec_key<W, I>(r[i]);
+        if (mkey_eq<W>(k, mk)) return mrec_rank<W, I>(r[i]);
+        if (mkey_lt<W>(mk, k)) return INVALID;                          // the run ascends by key
+    }
+    if (n <= (uint64_t)RUN_HEAD) return INVALID;
+    return min_find<W, I>(im.mrecs, start + RUN_HEAD, end, mk);
 }
 
 template <int W, int I, bool EXC, typename OFF>
