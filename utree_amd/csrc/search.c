@@ -1,12 +1,13 @@
 /* search.c -- whole-file search: XT_doSearch32's GG branch (itree.c:833-1108) over one or more device
- * images.  Host orchestration in C, three overlapped stages connected by a ring of chunk slots:
+ * images.  Host orchestration in C, four overlapped stages connected by a ring of chunk slots:
  *
  *   reader   : parallel pread of the next ~96 MiB of FASTA into pinned memory, frame the reads (fasta.c;
  *              the reference does this under `omp critical`, itree.c:867-874 -- its scaling limit)
  *   gpu      : shard the framed reads contiguously over the GPUs; per GPU copy the shard's byte span to HBM
  *              as it stands, run the batch kernels, copy the 24-byte results back
- *   writer   : format the lines with a thread team and write them in input order (= what the reference
- *              writes with one thread; with more threads it writes a permutation)
+ *   formatter: format the lines with a thread team
+ *   writer   : write them in input order (= what the reference writes with one thread; with more threads it
+ *              writes a permutation)
  */
 #define _FILE_OFFSET_BITS 64
 #define _GNU_SOURCE
@@ -29,7 +30,7 @@
 #define CHUNK_BYTES ((size_t)96 << 20)        /* must hold two maximal (16 MiB) lines                    */
 #define MAX_READS_PER_BATCH ((size_t)2 << 20)  /* more reads in a chunk (tiny reads) simply take another batch */
 #define LINELEN_MAX 16777216u                 /* itree.c:836 */
-#define NSLOTS 3
+#define NSLOTS 4
 #define READ_THREADS 4
 
 static double now_s(void) {
@@ -38,7 +39,8 @@ static double now_s(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-enum { S_EMPTY = 0, S_FRAMED, S_DONE };
+enum { S_EMPTY = 0, S_FRAMED, S_DONE, S_FORMATTED };
+#define FMT_MAX_THREADS 16
 
 typedef struct {
     uint8_t *h_buf;                            /* pinned: the chunk as read from the file                   */
@@ -50,6 +52,10 @@ typedef struct {
     int frame_rc, last;
     utree_fasta_error ferr;
     int state;
+    char *fmt_buf[FMT_MAX_THREADS];            /* formatted lines, one piece per formatting thread, in input order */
+    size_t fmt_cap[FMT_MAX_THREADS], fmt_len[FMT_MAX_THREADS];
+    int fmt_T;
+    uint64_t good;
 } slot_t;
 
 static int slot_alloc(slot_t *s) {
@@ -232,14 +238,10 @@ static void *gpu_main(void *arg) {
     }
 }
 
-/* ---- stage 3: format + write ------------------------------------------------------------------ */
-static void *writer_main(void *arg) {
+/* ---- stage 3: format ------------------------------------------------------------------------ */
+static void *format_main(void *arg) {
     pipe_t *P = (pipe_t *)arg;
     int T0 = P->host_threads;
-    char **fmt_buf = (char **)calloc((size_t)T0, sizeof(char *));
-    size_t *fmt_cap = (size_t *)calloc((size_t)T0, sizeof(size_t)), *fmt_len = (size_t *)calloc((size_t)T0, sizeof(size_t));
-    uint64_t next_progress = 1048576;
-    if (!fmt_buf || !fmt_cap || !fmt_len) { set_error(P, UTREE_E_NOMEM); goto out; }
     for (int i = 0;; ++i) {
         slot_t *s = &P->slot[i % NSLOTS];
         if (!wait_state(P, s, S_DONE)) break;
@@ -258,29 +260,46 @@ static void *writer_main(void *arg) {
                 uint32_t ll = q->label < P->ctr->info.n_labels ? P->ctr->label_len[q->label] : 0;
                 need += (size_t)s->name_len[r] + ll + 64;
             }
-            if (need > fmt_cap[t]) { free(fmt_buf[t]); fmt_buf[t] = (char *)malloc(need + need / 4); fmt_cap[t] = fmt_buf[t] ? need + need / 4 : 0; }
+            if (need > s->fmt_cap[t]) { free(s->fmt_buf[t]); s->fmt_buf[t] = (char *)malloc(need + need / 4); s->fmt_cap[t] = s->fmt_buf[t] ? need + need / 4 : 0; }
             uint64_t good = 0;
-            size_t L = !fmt_buf[t] ? (size_t)-1
+            size_t L = !s->fmt_buf[t] ? (size_t)-1
                        : P->rank ? utree_format_rank_records(P->ctr, s->h_buf, s->name_off + a, s->name_len + a, s->h_res + a, b - a,
-                                                             fmt_buf[t], fmt_cap[t], &good)
+                                                             s->fmt_buf[t], s->fmt_cap[t], &good)
                                  : utree_format_records(P->ctr, s->h_buf, s->name_off + a, s->name_len + a, s->h_res + a, b - a,
-                                                        fmt_buf[t], fmt_cap[t], &good);
-            if (L == (size_t)-1) { fail |= 1; fmt_len[t] = 0; } else { fmt_len[t] = L; good_total += good; }
+                                                        s->fmt_buf[t], s->fmt_cap[t], &good);
+            if (L == (size_t)-1) { fail |= 1; s->fmt_len[t] = 0; } else { s->fmt_len[t] = L; good_total += good; }
         }
-        double t1 = now_s();
+        P->t_format += now_s() - t0;
         if (fail) { set_error(P, UTREE_E_NOMEM); break; }
+        s->fmt_T = T; s->good = good_total;
+        int last = s->last;
+        set_state(P, s, S_FORMATTED);
+        if (last || s->frame_rc == UTREE_E_FASTA) break;
+    }
+    return NULL;
+}
+
+/* ---- stage 4: write -------------------------------------------------------------------------- */
+static void *writer_main(void *arg) {
+    pipe_t *P = (pipe_t *)arg;
+    uint64_t next_progress = 1048576;
+    for (int i = 0;; ++i) {
+        slot_t *s = &P->slot[i % NSLOTS];
+        if (!wait_state(P, s, S_FORMATTED)) break;
+        double t1 = now_s();
+        size_t nr = s->nr;
         /* pieces in input order; writes to one file serialise in the kernel anyway, so one thread issues them */
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < s->fmt_T; ++t) {
             size_t done = 0;
-            while (done < fmt_len[t]) {
-                ssize_t w = write(P->fo, fmt_buf[t] + done, fmt_len[t] - done);
-                if (w <= 0) { set_error(P, UTREE_E_IO); goto out; }
+            while (done < s->fmt_len[t]) {
+                ssize_t w = write(P->fo, s->fmt_buf[t] + done, s->fmt_len[t] - done);
+                if (w <= 0) { set_error(P, UTREE_E_IO); return NULL; }
                 done += (size_t)w;
             }
+            P->out_pos += (off_t)s->fmt_len[t];
         }
-        for (int t = 0; t < T; ++t) P->out_pos += (off_t)fmt_len[t];
-        P->t_format += t1 - t0; P->t_write += now_s() - t1;
-        P->st.good_finds += good_total;
+        P->t_write += now_s() - t1;
+        P->st.good_finds += s->good;
         P->st.n_reads += nr;
         while (P->st.n_reads >= next_progress) {                                  /* itree.c:878 */
             printf("Searched %llu queries...\n", (unsigned long long)next_progress);
@@ -296,9 +315,6 @@ static void *writer_main(void *arg) {
         set_state(P, s, S_EMPTY);
         if (last) break;
     }
-out:
-    if (fmt_buf) for (int t = 0; t < T0; ++t) free(fmt_buf[t]);
-    free(fmt_buf); free(fmt_cap); free(fmt_len);
     return NULL;
 }
 
@@ -363,15 +379,17 @@ static int search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const 
         HIPM(hipMalloc(&c->d_ws, c->ws_bytes));
     }
     {
-        pthread_t tr, tg, tw;
+        pthread_t tr, tg, tf, tw;
         pthread_create(&tr, NULL, reader_main, P);
         pthread_create(&tg, NULL, gpu_main, P);
+        pthread_create(&tf, NULL, format_main, P);
         pthread_create(&tw, NULL, writer_main, P);
         pthread_join(tw, NULL);
         /* the writer ends last on success; on error make sure the others leave their waits */
         pthread_mutex_lock(&P->mu); P->stop = 1; pthread_cond_broadcast(&P->cv); pthread_mutex_unlock(&P->mu);
         pthread_join(tr, NULL);
         pthread_join(tg, NULL);
+        pthread_join(tf, NULL);
         rc = P->rc;
     }
 done:
@@ -386,6 +404,7 @@ done:
         if (s->rel_off) hipHostFree(s->rel_off);
         if (s->seq_len) hipHostFree(s->seq_len);
         free(s->seq_off); free(s->name_off); free(s->name_len);
+        for (int t = 0; t < FMT_MAX_THREADS; ++t) free(s->fmt_buf[t]);
     }
     P->st.seconds_total = now_s() - t_start;
     P->st.seconds_kernels = P->t_gpu;
