@@ -313,3 +313,23 @@ def test_opt_in_input_formats_give_the_reference_output(torch_cuda, kind, tmp_pa
     r = subprocess.run([lib.CLI_PATH, util.fixture_ctr("toy"), str(path), str(out), "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        timeout=600, env=env)
     assert r.returncode == 0 and out.read_bytes() == util.fixture_bytes("toy_out.txt.gz")
+
+
+@pytest.mark.parametrize("rc", [0, 1])
+def test_more_long_reads_than_resident_workgroups(torch_cuda, rc, tmp_path):
+    """classify_long_k hands long reads out one at a time; with more long reads than workgroups that fit the chip a
+    workgroup takes a second, third ... read.  (A shared-memory slot reused between the work index and the vote made
+    that path lose reads; bench.py's 10 kb configuration found it.)"""
+    d = util.load_db_fixture("toy")
+    db, tree = tree_for("toy")
+    o = orc.OracleDB.load(util.fixture_ctr("toy"))
+    rng = np.random.default_rng(77 + rc)
+    reads = random_reads(rng, d, 2600, 2150, 2600, hit_frac=0.8) + random_reads(rng, d, 40, 5000, 9000, hit_frac=0.9)
+    data = fasta_bytes(reads)
+    got = classify_fasta_bytes(db, tree, data, rc=bool(rc))
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(data)
+    out = tmp_path / "o.txt"
+    code, nr, good, err = o.search_file(str(fa), str(out), threads=8, rc=bool(rc))
+    assert code == 0 and nr == len(reads)
+    assert got == out.read_bytes()

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
     __shared__ uint32_t s_touch[LONG_LDS_BITWORDS];
     __shared__ uint64_t s_keys[LONG_THREADS / 64][KEY_TILE + 128];
     __shared__ unsigned long long s_base;
-    __shared__ uint32_t s_first;
+    __shared__ uint32_t s_work, s_single;               // the read this workgroup took; the label of a one-label read
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = uni32(tid >> 6);
     uint8_t *sb = (uint8_t *)s_words;
     const uint32_t nl = im.n_labels, nbw = (nl + 31) >> 5;
@@ -367,10 +367,10 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
 
     for (;;) {
         // long reads differ in length by orders of magnitude: hand them out one at a time
-        if (tid == 0) s_first = (uint32_t)atomicAdd(&ws.cursors[UTREE_CUR_WORK_LONG], 1ull);
+        __syncthreads();                                  // everyone is done with the previous read (and with s_work)
+        if (tid == 0) s_work = (uint32_t)atomicAdd(&ws.cursors[UTREE_CUR_WORK_LONG], 1ull);
         __syncthreads();
-        const uint32_t li = s_first;
-        __syncthreads();
+        const uint32_t li = s_work;
         if (li >= n_long) break;
         const uint32_t r = ws.long_list[li];
         const uint64_t L64 = len[r];
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
         const uint64_t total = do_rc ? 2 * L64 + 1 : L64;
         const uint64_t nwin = total >= K ? total - K + 1 : 0;
         uint32_t my_hits = 0;
-        if (tid == 0) s_first = INVALID;
+        if (tid == 0) s_single = INVALID;
         for (uint64_t w0 = 0; w0 < nwin; w0 += LONG_TILE) {
             // stage bases [w0, w0+STAGE)
             for (uint32_t c = wv; c < STAGE / 64; c += LONG_THREADS / 64) {
@@ -442,13 +442,13 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
                 const uint32_t c = __hip_atomic_load(&hist[rk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&hist[rk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (uix > 1) ws.tally[base + pos] = (uint64_t)rk | ((uint64_t)c << 32);
-                else s_first = rk;
+                else s_single = rk;
                 ++pos;
             }
         }
         __syncthreads();
         if (tid == 0) {
-            if (uix == 1) store_result(&out[r], im.rank2ix[s_first], -2, F, 1, 0, 0);
+            if (uix == 1) store_result(&out[r], im.rank2ix[s_single], -2, F, 1, 0, 0);
             else store_result(&out[r], 0, CUT_PENDING, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
         }
         __syncthreads();
