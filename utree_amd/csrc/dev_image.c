@@ -381,6 +381,17 @@ int utree_dev_get_info(const utree_dev *d, utree_dev_info *info) {
 /* ---- batches --------------------------------------------------------------------------------- */
 #define LONG_BLOCKS_PER_CU 8
 
+/* reads of up to this many staged bases take the wave-per-read mid pass, longer ones classify_long_k */
+static uint32_t mid_limit(void) {
+    static uint32_t v = 0;
+    if (!v) {
+        const char *e = getenv("UTREE_MID_LIMIT");
+        v = UTREE_MID_DEFAULT;
+        if (e && atoi(e) >= (int)UTREE_SHORT_CAP && atoi(e) <= (int)UTREE_MID_CAP) v = (uint32_t)atoi(e);
+    }
+    return v;
+}
+
 static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc,
                   utk_workspace *w, size_t *bytes) {
     uint64_t off = 0;
@@ -394,7 +405,8 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
     uint64_t max_total = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
     w->long_blocks = 0; w->hist = NULL; w->touch = NULL;
     w->mid_reads = max_total > UTREE_SHORT_CAP;
-    if (max_total > UTREE_MID_CAP) {
+    w->mid_limit = mid_limit();
+    if (max_total > w->mid_limit) {
         w->long_blocks = (uint32_t)d->n_cu * LONG_BLOCKS_PER_CU;
         if (w->long_blocks > n_reads) w->long_blocks = n_reads;
         w->hist = (uint32_t *)(b + off); off = align_up(off + (uint64_t)w->long_blocks * d->hdr.n_labels * 4, 256);

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void route_k(const uint32_t *__restrict__ len,
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t total = 0;
     if (r < n_reads) total = do_rc ? 2 * (uint64_t)len[r] + 1 : len[r];
-    const bool mid = total > UTREE_SHORT_CAP && total <= UTREE_MID_CAP, lng = total > UTREE_MID_CAP;
+    const bool mid = total > UTREE_SHORT_CAP && total <= ws.mid_limit, lng = total > ws.mid_limit;
     const uint64_t mm = __ballot(mid), ml = __ballot(lng);
     const uint32_t lane = lane_id();
     if (mm) {
