@@ -387,7 +387,7 @@ static uint32_t mid_limit(void) {
     if (!v) {
         const char *e = getenv("UTREE_MID_LIMIT");
         v = UTREE_MID_DEFAULT;
-        if (e && atoi(e) >= (int)UTREE_SHORT_CAP && atoi(e) <= (int)UTREE_MID_CAP) v = (uint32_t)atoi(e);
+        if (e && atoi(e) >= (int)UTREE_SHORT2_CAP && atoi(e) <= (int)UTREE_MID_CAP) v = (uint32_t)atoi(e);
     }
     return v;
 }
@@ -404,7 +404,9 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
     w->mid_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
     uint64_t max_total = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
     w->long_blocks = 0; w->hist = NULL; w->touch = NULL;
-    w->mid_reads = max_total > UTREE_SHORT_CAP;
+    /* the main wave-per-read pass comes in two sizes; the larger one when the batch's longest read needs it */
+    w->short_cap = max_total > UTREE_SHORT_CAP ? UTREE_SHORT2_CAP : UTREE_SHORT_CAP;
+    w->mid_reads = max_total > w->short_cap;
     w->mid_limit = mid_limit();
     if (max_total > w->mid_limit) {
         w->long_blocks = (uint32_t)d->n_cu * LONG_BLOCKS_PER_CU;

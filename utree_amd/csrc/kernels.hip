@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void route_k(const uint32_t *__restrict__ len,
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t total = 0;
     if (r < n_reads) total = do_rc ? 2 * (uint64_t)len[r] + 1 : len[r];
-    const bool mid = total > UTREE_SHORT_CAP && total <= ws.mid_limit, lng = total > ws.mid_limit;
+    const bool mid = total > ws.short_cap && total <= ws.mid_limit, lng = total > ws.mid_limit;
     const uint64_t mm = __ballot(mid), ml = __ballot(lng);
     const uint32_t lane = lane_id();
     if (mm) {
@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void route_k(const uint32_t *__restrict__ len,
 // classify_short: one wavefront per read (reads whose staged length fits UTREE_SHORT_CAP bases)
 // ------------------------------------------------------------------------------------------------
 constexpr int SHORT_CAP = UTREE_SHORT_CAP;          // 150 bp + reverse strand fits
+constexpr int SHORT2_CAP = UTREE_SHORT2_CAP;        // 300 bp + reverse strand fits (used when a batch's longest read needs it)
 constexpr int MID_CAP = UTREE_MID_CAP;              // 1 kb + reverse strand fits; longer reads take classify_long_k
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr uint32_t WORK_GRAB = 64;                   // reads a wave takes per visit to the work counter
@@ -156,7 +157,7 @@ template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED>
 #ifndef UTREE_SHORT_MIN_WAVES
 #define UTREE_SHORT_MIN_WAVES 8
 #endif
-__global__ __launch_bounds__(256, CAP > SHORT_CAP ? (I == 2 ? 5 : 3) : ((W == 8 && I == 2) ? UTREE_SHORT_MIN_WAVES : 5))
+__global__ __launch_bounds__(256, CAP > SHORT2_CAP ? (I == 2 ? 5 : 3) : ((W == 8 && I == 2) ? (CAP > SHORT_CAP ? 7 : UTREE_SHORT_MIN_WAVES) : 5))
 void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
                       const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
                       utk_workspace ws) {
@@ -568,8 +569,12 @@ int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64
     uint32_t cap = (uint32_t)n_cu * 8u;
     if (blocks > cap) blocks = cap;
     return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
-        classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT_CAP, false>
-            <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+        if (ws->short_cap == UTREE_SHORT2_CAP)
+            classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT2_CAP, false>
+                <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+        else
+            classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT_CAP, false>
+                <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
     });
 }
 

@@ -20,6 +20,7 @@ extern "C" {
 #define UTREE_CUR_WORK_LONG 40                   /* ... of the next unclaimed long-list entry                    */
 #define UTREE_CUR_WORK_MID 56                    /* ... of the next unclaimed mid-list entry                     */
 #define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds      */
+#define UTREE_SHORT2_CAP 640u                    /* ... its second size: 250-300 bp reads with the reverse strand */
 #define UTREE_MID_DEFAULT 1536u                  /* measured cross-over to classify_long_k on hit-dense reads (UTREE_MID_LIMIT overrides) */
 #define UTREE_MID_CAP 2112u                      /* ... and its mid-length instantiation; longer: classify_long */
 
@@ -81,6 +82,7 @@ typedef struct {
     uint32_t *hist;                  /* long path: [long_blocks][n_labels]                                    */
     uint32_t *touch;                 /* long path: touched-label bitmap when it does not fit LDS              */
     uint32_t long_blocks, mid_reads; /* mid_reads != 0: the batch may hold mid-length reads                   */
+    uint32_t short_cap;              /* UTREE_SHORT_CAP or UTREE_SHORT2_CAP: what the batch's main wave-per-read pass holds */
     uint32_t mid_limit;              /* staged bases up to which the wave-per-read mid pass is used (<= UTREE_MID_CAP) */
 } utk_workspace;
 
