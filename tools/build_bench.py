@@ -29,10 +29,15 @@ with open(fa, "wb") as f, open(mp, "wb") as g:
 out = {"n_refs": n_refs, "ref_len": ref_len, "complevel": cl, "fasta_bytes": os.path.getsize(fa)}
 def run(cmd):
     t = time.time(); r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE); return time.time() - t, r
-t, r = run([lib.BUILD_GG_CLI_PATH, fa, mp, d + "/ours.ubt", "0", str(cl)])
+variant = os.environ.get("VARIANT", "")                   # "", "k64" or "ix32": the reference's -D PACKSIZE=64 / -D IXTYPE=uint32_t builds
+env = dict(os.environ)
+if variant == "k64": env["UTREE_PACKSIZE"] = "64"
+if variant == "ix32": env["UTREE_IXTYPE"] = "32"
+out["variant"] = variant or "default"
+t0_ = time.time(); r = subprocess.run([lib.BUILD_GG_CLI_PATH, fa, mp, d + "/ours.ubt", "0", str(cl)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env); t = time.time() - t0_
 out["ours_seconds"] = t; out["ours_exit"] = r.returncode
 out["ours_stderr"] = r.stderr.decode().strip().splitlines()[-1:]; out["ours_stdout"] = r.stdout.decode().strip().splitlines()[-2:]
-ref = os.path.join(os.path.dirname(lib.SO_PATH), "..", "oracle", "_ref", "utree-buildGG")
+ref = os.path.join(os.path.dirname(lib.SO_PATH), "..", "oracle", "_ref", "utree-buildGG" + ("-" + variant if variant else ""))
 if os.path.exists(ref) and not os.environ.get("SKIP_REFERENCE"):
     t, r = run([ref, fa, mp, d + "/ref.ubt", "0", str(cl)]); out["reference_seconds"] = t; out["reference_exit"] = r.returncode
     out["reference_stdout"] = r.stdout.decode().strip().splitlines()[-2:]
