@@ -401,10 +401,20 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
             const uint32_t a = wv * PER_WAVE < tile_n ? wv * PER_WAVE : tile_n;
             const uint32_t b = a + PER_WAVE < tile_n ? a + PER_WAVE : tile_n;
             wave_scan_windows<W, I, EXC, OFF>(im, s_words, s_bad, s_keys[wv], a, b - a, STAGE, 24 + im.fine_bits, lane, [&](uint32_t rank) {
-                if (rank != INVALID) {
-                    atomicAdd(&hist[rank], 1u);
-                    atomicOr(&touch[rank >> 5], 1u << (rank & 31u));
-                    ++my_hits;
+                // one atomic per DISTINCT label of the 64 windows, not per hit: a read's hits mostly share a few labels,
+                // and 64 atomics on one address serialise in L2
+                const bool hit = rank != INVALID;
+                uint64_t left = __ballot(hit);
+                my_hits += hit;
+                while (left) {
+                    const uint32_t lead = (uint32_t)__builtin_ctzll(left);
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)lead);
+                    const uint64_t m = __ballot(hit && rank == v) & left;
+                    if (lane == lead) {
+                        atomicAdd(&hist[v], (uint32_t)__popcll(m));
+                        atomicOr(&touch[v >> 5], 1u << (v & 31u));
+                    }
+                    left &= ~m;
                 }
             });
             __syncthreads();
