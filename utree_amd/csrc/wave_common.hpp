@@ -6,7 +6,10 @@
 #include "device_common.hpp"
 
 #ifndef UTREE_RUN_HEAD
-#define UTREE_RUN_HEAD 2
+#define UTREE_RUN_HEAD 7          /* records of a run fetched together, 8-byte records (<= 8: the image pads 8 records) */
+#endif
+#ifndef UTREE_RUN_HEAD2
+#define UTREE_RUN_HEAD2 3         /* ... 16- and 32-byte records */
 #endif
 
 namespace utk {
@@ -53,9 +56,10 @@ __device__ __forceinline__ uint32_t resolve_entry(const utk_image &im, const Ent
     const uint64_t d = t.w[RecTraits<W, I>::KW];
     const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull, end = start + n;
     // A run = the k-mers that share this minimizer.  Minimizers are minima, so most nodes sit in runs of 2-8 records (mean
-    // 3.5 at 0.28 nodes per slot).  The first RUN_HEAD records are fetched together, the rest by binary search.  Fetching
-    // 4 at once saves round trips but measured 3 % slower than 2 (5.33 vs 5.18 ms per 4 M reads, r01).
-    constexpr int RUN_HEAD = RecTraits<W, I>::EW == 1 ? UTREE_RUN_HEAD : 2;
+    // 3.5 at 0.28 nodes per slot; 98 % within 8).  The first RUN_HEAD records are fetched together -- contiguous, so the
+    // compiler emits 16-byte loads -- and only longer runs go on with a binary search, one round trip per step.  Measured
+    // on one box, 4 M x 150 bp reads: 2 records 5.78 ms, 4: 5.25, 6: 4.96, 7: 4.87, 8: 5.08 (r01).
+    constexpr int RUN_HEAD = RecTraits<W, I>::EW == 1 ? UTREE_RUN_HEAD : UTREE_RUN_HEAD2;
     Entry<W, I> r[RUN_HEAD];
 #pragma unroll
     for (int i = 0; i < RUN_HEAD; ++i) r[i] = load_entry<W, I>(im.mrecs, start + i);

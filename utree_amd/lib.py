@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libutree_amd.so")
+SO_PATH = os.environ.get("UTREE_AMD_SO") or os.path.join(_HERE, "libutree_amd.so")   # override: kernel experiments only
 CLI_PATH = os.path.join(_HERE, "xtree-searchGG")
 COMPRESS_CLI_PATH = os.path.join(_HERE, "xtree-compress")
 RANK_CLI_PATH = os.path.join(_HERE, "xtree-search")
