@@ -142,7 +142,7 @@ constexpr int SHORT_CAP = UTREE_SHORT_CAP;          // 150 bp + reverse strand f
 constexpr int SHORT2_CAP = UTREE_SHORT2_CAP;        // 300 bp + reverse strand fits (used when a batch's longest read needs it)
 constexpr int MID_CAP = UTREE_MID_CAP;              // 1 kb + reverse strand fits; longer reads take classify_long_k
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr uint32_t WORK_GRAB = 64;                   // reads a wave takes per visit to the work counter
+constexpr uint32_t WORK_GRAB = 32;                   // reads a wave takes per visit to the work counter (64: +3 %, 128: +7 % time)
 constexpr uint32_t TALLY_CHUNK = UTREE_TALLY_CHUNK;
 constexpr uint32_t TALLY_DIRECT = UTREE_TALLY_CHUNK / 16;   // hit lists this long get their own reservation
 constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read waits for vote_k
@@ -283,7 +283,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             uint32_t place = 0;
             for (uint32_t u = 0; u < nu; ++u) place += (uint32_t)__builtin_amdgcn_readlane((int)myv, (int)u) < myv;
             if (lane < nu) ws.tally[chunk_base + place] = (uint64_t)myv | ((uint64_t)myc << 32);
-            if (lane == 0) store_result(&out[r], im.rank2ix[h0], CUT_PENDING, F, nu, (uint32_t)chunk_base, (uint32_t)(chunk_base >> 32));
+            if (lane == 0) store_result(&out[r], 0, CUT_PENDING, F, nu, (uint32_t)chunk_base, (uint32_t)(chunk_base >> 32));
             chunk_base += nu; chunk_left -= nu;
             continue;
         }
@@ -329,7 +329,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         }
         if (!direct) { chunk_base += uix; chunk_left -= uix; }
         // vote_k finishes this read: cut = CUT_PENDING marks it, sl/ol carry the tally offset
-        if (lane == 0) store_result(&out[r], im.rank2ix[h0], CUT_PENDING, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
+        if (lane == 0) store_result(&out[r], 0, CUT_PENDING, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
     }
 }
 
