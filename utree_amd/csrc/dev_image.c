@@ -12,6 +12,8 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <fcntl.h>
+#include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,36 +37,55 @@ static int timing_on(void) { return getenv("UTREE_TIMING") != NULL || getenv("UT
 
 static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
+/* Bucket widths per hash region (utree_image_header.regions) for a tree of N nodes: a node's minimizer hash is the smallest of
+ * m = K-15 hashes, so with x = h / 2^32 there are about N/2^32 * m * (1-x)^(m-1) nodes per hash value.  A region takes the
+ * width 2^s (s <= 8: the record key has 8 bits for the hash bits a bucket does not imply) that brings a bucket closest to
+ * TARGET nodes, but not finer than 2^(8-F) (F = fine_bits: 8 = as fine as the density asks, 0 = 256 values per bucket). */
+#define UTREE_BUCKET_TARGET 2.0
+static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t F, uint64_t regions[256]) {
+    const double m = 4.0 * W - 15.0, lam0 = (double)n_nodes / 4294967296.0;
+    const uint32_t smin = F >= 8 ? 0 : 8 - F;
+    const char *te = getenv("UTREE_BUCKET_TARGET");                     /* experiments only */
+    const double target = te && atof(te) > 0 ? atof(te) : UTREE_BUCKET_TARGET;
+    uint64_t base = 0;
+    for (int r = 0; r < 256; ++r) {
+        const double x = (r + 0.5) / 256.0, dens = lam0 * m * pow(1.0 - x, m - 1.0);
+        uint32_t s = 0;
+        while (s < 8 && dens * (double)(2u << s) <= target * 1.5) ++s;     /* doubling the width still leaves <= 1.5 x TARGET */
+        if (s < smin) s = smin;
+        if (regions) regions[r] = (base << 8) | s;
+        base += 1ull << (24 - s);
+    }
+    return base;
+}
+
 int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
     const char *env = getenv("UTREE_FINE_BITS");
     if (fine_bits == UTREE_FINE_AUTO && env && *env) fine_bits = atoi(env);
     if (fine_bits == UTREE_FINE_AUTO) {
-        /* smallest F that leaves <= 0.35 records per table slot on average (then ~97 % of lookups end in the
-         * one line that holds their slot), within a memory cap for the table */
+        /* as fine as the density asks, within a memory cap for the table */
         const char *cap_env = getenv("UTREE_TABLE_MAX_GB");
         double cap = (cap_env && atof(cap_env) > 0 ? atof(cap_env) : 48.0) * 1073741824.0;
-        double slot_bytes = 8.0 * utree_rec_words(ctr->info.W, ctr->info.I);
-        int F = 0;
-        while (F < 12 && (double)ctr->info.n_nodes / (double)(1ull << (24 + F)) > 0.35 &&
-               (double)(1ull << (24 + F + 1)) * slot_bytes <= cap) ++F;
+        int F = 8;
+        while (F > 0 && (double)compute_regions(ctr->info.n_nodes, ctr->info.W, (uint32_t)F, NULL) * 64.0 > cap) --F;
         return F;
     }
     if (fine_bits < 0) fine_bits = 0;
-    if (fine_bits > 12) fine_bits = 12;
+    if (fine_bits > 8) fine_bits = 8;
     return fine_bits;
 }
 
 static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     memset(h, 0, sizeof *h);
-    h->magic = UTREE_IMG_MAGIC; h->version = 3;
+    h->magic = UTREE_IMG_MAGIC; h->version = 4;
     h->W = ctr->info.W; h->I = ctr->info.I; h->k = ctr->info.k;
     h->fine_bits = F; h->rec_words = utree_rec_words(h->W, h->I);
     h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
     /* UTREE_FORCE_OFF64: test hook that runs the 64-bit-offset instantiations (N >= 2^32-1 databases) on small files */
     h->flags = (ctr->info.binix_width == 8 || getenv("UTREE_FORCE_OFF64")) ? UTREE_F_OFF64 : 0;
-    h->n_slots = 1ull << (24 + F);
+    h->n_slots = compute_regions(h->n_nodes, h->W, F, h->regions);
     uint64_t off = UTREE_IMG_HEADER_BYTES;
-    h->off_table = off; off = align_up(off + h->n_slots * h->rec_words * 8, 4096);
+    h->off_table = off; off = align_up(off + h->n_slots * 64, 4096);
     h->off_mrecs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 4096);
     h->off_coarse = off; off = align_up(off + (uint64_t)UTREE_NUMBINS * ((h->flags & UTREE_F_OFF64) ? 8 : 4), 256);
     h->off_irreg = off; off = align_up(off + (1u << 24) / 8, 256);
@@ -89,6 +110,7 @@ size_t utree_dev_image_bytes(const utree_ctr *ctr, int fine_bits) {
 static void bind_image(utree_dev *d) {
     char *b = (char *)d->image;
     d->kimg.table = (const uint64_t *)(b + d->hdr.off_table);
+    d->kimg.regions = (const uint64_t *)(b + offsetof(utree_image_header, regions));
     d->kimg.mrecs = (const uint64_t *)(b + d->hdr.off_mrecs);
     d->kimg.recs = (const uint64_t *)(b + d->hdr.off_recs);
     d->kimg.coarse = b + d->hdr.off_coarse;
@@ -215,10 +237,8 @@ static int build_finish(builder *b, const void *d_binix_raw) {
          * reference does -- every bin takes the exact probe path over [BinIx[p], BinIx[p+1]) */
         d->hdr.flags |= UTREE_F_GENERIC;
         d->hdr.fine_bits = 0;
-        d->hdr.n_slots = 1ull << 24;
         d->hdr.n_min = 0;
-        HIPCHK(hipMemsetAsync(img + d->hdr.off_irreg, 0xFF, (1u << 24) / 8, st));
-        HIPCHK(hipMemsetAsync(img + d->hdr.off_table, 0, d->hdr.n_slots * d->hdr.rec_words * 8, st));
+        HIPCHK(hipMemsetAsync(img + d->hdr.off_irreg, 0xFF, (1u << 24) / 8, st));   /* the buckets are never read: every bin is "irregular" */
     } else {
         if (counters[0]) d->hdr.flags |= UTREE_F_IRREGULAR;
         /* a monotone table reaches the contiguous node range [BinIx[0], BinIx[2^24]) */
@@ -227,8 +247,9 @@ static int build_finish(builder *b, const void *d_binix_raw) {
         else { memcpy(&c0, ctr->binix_raw, 8); memcpy(&cN, (const char *)ctr->binix_raw + 8 * (size_t)(UTREE_NUMBINS - 1), 8); }
         d->hdr.n_min = cN - c0;
         HIPCHK(hipMemsetAsync(b->d_counters, 0, 16, st));
-        KCHK(utk_build_min(d->hdr.W, d->hdr.I, off64, coarse, recs, c0, d->hdr.n_min, 24 + d->hdr.fine_bits,
-                           (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs), b->d_counters, st));
+        HIPCHK(hipMemcpyAsync(img, &d->hdr, sizeof d->hdr, hipMemcpyHostToDevice, st));   /* the kernels read the region table there */
+        KCHK(utk_build_min(d->hdr.W, d->hdr.I, off64, coarse, recs, c0, d->hdr.n_min, (const uint64_t *)(img + offsetof(utree_image_header, regions)),
+                           d->hdr.n_slots, (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs), b->d_counters, st));
         KCHK(utk_fill_recs_pad((uint64_t *)(img + d->hdr.off_mrecs) + d->hdr.n_min * d->hdr.rec_words, 8 * d->hdr.rec_words, st));
         HIPCHK(hipMemcpyAsync(counters, b->d_counters, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -346,7 +367,7 @@ int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t byt
     if (!d) return UTREE_E_NOMEM;
     d->device = device; d->n_cu = n_cu; d->image = d_image; d->owns = 0;
     HIPCHK(hipMemcpy(&d->hdr, d_image, sizeof d->hdr, hipMemcpyDeviceToHost));
-    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 3 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
+    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 4 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
     if (ctr && (ctr->info.W != d->hdr.W || ctr->info.I != d->hdr.I || ctr->info.n_nodes != d->hdr.n_nodes ||
                 ctr->info.n_labels != d->hdr.n_labels)) { rc = UTREE_E_ARG; goto fail; }
     d->image_bytes = d->hdr.total_bytes;

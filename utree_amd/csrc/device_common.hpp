@@ -177,23 +177,33 @@ template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_
     min_rest<W>(khi, klo, pos, rest_hi32, rest_lo);
 }
 
-// table slot and MIN key from (h, pos) for a table of 2^B slots
-template <int W> __device__ __forceinline__ void min_finish(uint64_t khi, uint64_t klo, uint32_t h, uint32_t pos, uint32_t B,
-                                                           uint64_t &slot, MinKey<W> &mk) {
-    uint32_t rh; uint64_t rl;
+// Bucket of a minimizer hash and the hash bits the bucket does not imply (utree_image_header.regions).
+__device__ __forceinline__ void bucket_of(const uint64_t *__restrict__ regions, uint32_t h, uint64_t &bucket, uint32_t &hlow) {
+    const uint64_t e = regions[h >> 24];
+    const uint32_t s = (uint32_t)e & 0xFFu;
+    bucket = (e >> 8) + ((h & 0xFFFFFFu) >> s);
+    hlow = h & ((1u << s) - 1u);
+}
+
+// bucket and MIN key from (h, pos)
+template <int W> __device__ __forceinline__ void min_finish(uint64_t khi, uint64_t klo, uint32_t h, uint32_t pos,
+                                                           const uint64_t *__restrict__ regions, uint64_t &bucket, MinKey<W> &mk) {
+    uint32_t rh, hl; uint64_t rl;
     min_rest<W>(khi, klo, pos, rh, rl);
-    slot = (uint64_t)h >> (32 - B);
-    const uint64_t hlow = (uint64_t)h & ((1ull << (32 - B)) - 1);
+    bucket_of(regions, h, bucket, hl);
+    const uint64_t hlow = hl;
     if constexpr (W == 8) { mk.hi = 0; mk.lo = (hlow << 37) | ((uint64_t)pos << 32) | rl; }
     else { mk.lo = rl; mk.hi = (hlow << 38) | ((uint64_t)pos << 32) | rh; }
 }
-template <int W> __device__ __forceinline__ void min_split(uint64_t khi, uint64_t klo, uint32_t B, uint64_t &slot, MinKey<W> &mk) {
+template <int W> __device__ __forceinline__ void min_split(uint64_t khi, uint64_t klo, const uint64_t *__restrict__ regions,
+                                                          uint64_t &bucket, MinKey<W> &mk) {
     uint32_t h, pos, rh; uint64_t rl;
     minimizer<W>(khi, klo, h, pos, rh, rl);
-    min_finish<W>(khi, klo, h, pos, B, slot, mk);
+    min_finish<W>(khi, klo, h, pos, regions, bucket, mk);
 }
 
-// MIN records / table slots.  flag (top 2 bits of word KW): 0 record, 1 empty slot, 2 run {count22 | start40}
+// MIN records / bucket entries.  flag (top 2 bits of word KW): 0 record, 1 empty entry, 2 (a bucket's LAST entry only)
+// overflow: run {count22 | start40} of the bucket's remaining records in the sorted array
 //   W=8, I=2: {flag2 | 0 | key45 | rank16}                  W=8, I=4: {flag2 | 0 | key45 | 0}{rank32}
 //   W=16,I=2: {rest lo64}{flag2 | key_hi46 | rank16}        W=16,I=4: {rest lo64}{flag2 | key_hi46 | 0}{rank32}{0}
 constexpr uint64_t MFLAG_EMPTY = 1ull << 62, MFLAG_RUN = 2ull << 62;

@@ -6,7 +6,7 @@
 //   assign_k     per node: minimizer hash, position, rest, 24-bit prefix
 //   (rocprim radix sorts: nodes ordered by (hash, position, rest))
 //   emit_k       MIN records in that order
-//   table_k      direct-mapped table over the top B hash bits: empty / the single record inline / run descriptor
+//   bucket_k     64-byte buckets addressed by the minimizer hash through the region table: records inline, overflow descriptor
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <algorithm>
@@ -130,13 +130,15 @@ __global__ void assign_k(const OFF *__restrict__ coarse, const uint64_t *__restr
 // MIN record j = node idx[j] (relative to c0) in the final (hash, pos, rest) order
 template <int W, int I, typename IDX>
 __global__ void emit_k(const uint64_t *__restrict__ recs, uint64_t c0, const IDX *__restrict__ idx, const uint32_t *__restrict__ H,
-                       const uint64_t *__restrict__ K1, const uint64_t *__restrict__ K2, uint32_t B, uint64_t m,
+                       const uint64_t *__restrict__ K1, const uint64_t *__restrict__ K2, const uint64_t *__restrict__ regions, uint64_t m,
                        uint64_t *__restrict__ out, uint32_t *__restrict__ Hs) {
     constexpr int EW = RecTraits<W, I>::EW;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = idx[j];
         const uint32_t h = H[i];
-        const uint64_t hlow = (uint64_t)h & ((1ull << (32 - B)) - 1);
+        uint64_t bucket; uint32_t hl;
+        bucket_of(regions, h, bucket, hl);
+        const uint64_t hlow = hl;
         MinKey<W> mk;
         if constexpr (W == 16) { mk.lo = K1[i]; mk.hi = (hlow << 38) | K2[i]; } else { mk.hi = 0; mk.lo = (hlow << 37) | K1[i]; }
         const Entry<W, I> e = make_mrec<W, I>(mk, file_rank<W, I>(recs, c0 + i));
@@ -146,26 +148,35 @@ __global__ void emit_k(const uint64_t *__restrict__ recs, uint64_t c0, const IDX
     }
 }
 
+// Buckets from the sorted records: the first thread of every bucket's run copies up to CAP records into the bucket (the
+// rest of the bucket stays flagged empty); a longer run leaves CAP-1 records inline and an overflow descriptor last.
 template <int W, int I>
-__global__ void table_k(const uint32_t *__restrict__ Hs, const uint64_t *__restrict__ mrecs, uint64_t base, uint64_t m, uint32_t B,
-                        uint64_t *__restrict__ table, unsigned long long *overflow) {
-    // Hs / mrecs: this part's sorted hashes and records (a part = a range of the top hash bits, so no slot straddles
-    // two parts); base = MIN records in earlier parts
-    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+__global__ void bucket_k(const uint32_t *__restrict__ Hs, const uint64_t *__restrict__ mrecs, uint64_t base, uint64_t m,
+                         const uint64_t *__restrict__ regions, uint64_t *__restrict__ table, unsigned long long *overflow) {
+    // Hs / mrecs: this part's sorted hashes and records (a part = a range of whole buckets); base = MIN records in earlier parts
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = 8 / EW;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t b = (uint64_t)Hs[j] >> (32 - B);
-        if (j && ((uint64_t)Hs[j - 1] >> (32 - B)) == b) continue;          // not the first node of its slot
+        uint64_t b, bp; uint32_t hl;
+        bucket_of(regions, Hs[j], b, hl);
+        if (j) { bucket_of(regions, Hs[j - 1], bp, hl); if (bp == b) continue; }          // not the first node of its bucket
         uint64_t n = 1;
-        while (j + n < m && ((uint64_t)Hs[j + n] >> (32 - B)) == b) ++n;
-        uint64_t *o = table + b * EW;
-        if (n == 1) {
+        for (;;) {
+            if (j + n >= m) break;
+            bucket_of(regions, Hs[j + n], bp, hl);
+            if (bp != b) break;
+            ++n;
+        }
+        uint64_t *o = table + b * 8;                                                  // 64 bytes per bucket
+        const uint64_t inl = n <= (uint64_t)CAP ? n : (uint64_t)CAP - 1;
+        for (uint64_t q = 0; q < inl; ++q)
 #pragma unroll
-            for (int x = 0; x < EW; ++x) o[x] = mrecs[j * EW + x];            // flag bits of a record are 0
-        } else {
-            if (n >= (1ull << 22)) { atomicAdd(overflow, 1ull); n = (1ull << 22) - 1; }
+            for (int x = 0; x < EW; ++x) o[q * EW + x] = mrecs[(j + q) * EW + x];     // flag bits of a record are 0
+        if (n > (uint64_t)CAP) {
+            uint64_t rest = n - inl;
+            if (rest >= (1ull << 22)) { atomicAdd(overflow, 1ull); rest = (1ull << 22) - 1; }
 #pragma unroll
-            for (int x = 0; x < EW; ++x) o[x] = 0;
-            o[KW] = MFLAG_RUN | (n << 40) | ((base + j) & M40);
+            for (int x = 0; x < EW; ++x) o[inl * EW + x] = 0;
+            o[inl * EW + KW] = MFLAG_RUN | (rest << 40) | ((base + j + inl) & M40);
         }
     }
 }
@@ -244,10 +255,10 @@ struct in_part {
 // node on top of the 12-20 bytes of keys; when that does not fit beside the image (trees of billions of nodes) the
 // nodes are handled in 2^pb parts by the top bits of the hash -- parts are contiguous in the final order.
 template <int W, int I, typename OFF, typename IDX>
-int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, uint32_t B, uint64_t *table, uint64_t *mrecs,
-              unsigned long long *d_overflow, hipStream_t st) {
+int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, const uint64_t *regions, uint64_t n_buckets,
+              uint64_t *table, uint64_t *mrecs, unsigned long long *d_overflow, hipStream_t st) {
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
-    const uint64_t nslots = 1ull << B;
+    const uint64_t nslots = n_buckets * (8 / EW);                                      // entries, all flagged empty to begin with
     for (int x = 0; x < EW; ++x) fill_u64_k<<<grid_for(nslots), 256, 0, st>>>(table, nslots, x == KW ? MFLAG_EMPTY : 0ull, EW, x);
     if (!m) return (int)hipGetLastError();
     uint32_t *H = nullptr, *Hg = nullptr, *Hg2 = nullptr;
@@ -292,7 +303,7 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
             (void)hipFree(d_s);
             if (e1 != hipSuccess || e2 != hipSuccess) { free(h_s); rc = (int)(e1 != hipSuccess ? e1 : e2); goto done; }
             std::sort(h_s, h_s + ns);
-            const uint64_t slot = 1ull << (32 - B);                                    // cuts fall on table-slot boundaries
+            const uint64_t slot = 256;                                                 // cuts fall on bucket boundaries (a bucket spans <= 256 hash values, aligned)
             for (uint32_t q = 1; q < nparts; ++q) {
                 uint64_t c = h_s[(uint64_t)ns * q / nparts];
                 c -= c % slot;
@@ -357,8 +368,8 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
         Hg = (uint32_t *)kg; Hg2 = (uint32_t *)kg2;
         if ((rc = sort_pass32<IDX>(H, idx, idx2, Hg, Hg2, mq, tmp, t64, st))) goto done;             // minimizer hash
         // Hg2 now holds the sorted hashes but emit_k recomputes them from H[idx]: reuse Hg as the sorted-hash array
-        emit_k<W, I, IDX><<<grid_for(mq), 256, 0, st>>>(recs, c0, idx, H, K1, K2, B, mq, mrecs + base * EW, Hg);
-        table_k<W, I><<<grid_for(mq), 256, 0, st>>>(Hg, mrecs + base * EW, base, mq, B, table, d_overflow);
+        emit_k<W, I, IDX><<<grid_for(mq), 256, 0, st>>>(recs, c0, idx, H, K1, K2, regions, mq, mrecs + base * EW, Hg);
+        bucket_k<W, I><<<grid_for(mq), 256, 0, st>>>(Hg, mrecs + base * EW, base, mq, regions, table, d_overflow);
         CK(hipGetLastError());
         if (chat) { CK(hipStreamSynchronize(st)); fprintf(stderr, "[utree_amd] image: part %u sorted and emitted\n", q + 1); }
         base += mq;
@@ -420,15 +431,16 @@ int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream) {
 
 /* nodes [c0, c0+m) = what the (monotone) bin table reaches.  d_overflow[0] += slots with >= 2^22 nodes. */
 int utk_build_min(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
-                  uint32_t table_bits, uint64_t *d_table, uint64_t *d_mrecs, unsigned long long *d_overflow, void *stream) {
+                  const uint64_t *d_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, unsigned long long *d_overflow,
+                  void *stream) {
     int rc = 0;
     int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
         constexpr int W = decltype(w)::value, I = decltype(i)::value;
         hipStream_t st = (hipStream_t)stream;
         const bool idx64 = m >= 0xFFFFFFFFull;
-        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, table_bits, d_table, d_mrecs, d_overflow, st);
-        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, table_bits, d_table, d_mrecs, d_overflow, st);
-        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, table_bits, d_table, d_mrecs, d_overflow, st);
+        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_overflow, st);
+        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_overflow, st);
+        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_overflow, st);
     });
     return rc ? rc : drc;
 }

@@ -60,10 +60,12 @@ __device__ __forceinline__ void build_minkeys(const uint32_t *sw, uint64_t *Kk, 
 
 // One wave looks up the windows [w0, w0+n) of a staged buffer (sw = packed bases, sbad = bad-base bit words, both
 // indexed from the buffer's first base) and hands every lane's result to on_rank(rank) -- called by all lanes,
-// INVALID for lanes without a hit -- twice per 128 windows.  Two table slots are in flight per lane.
+// INVALID for lanes without a hit -- once per 64 windows.  One bucket (64 bytes) is in flight per lane: its records
+// arrive in one round trip, and two buckets in flight would not fit the registers.  `regions` = the image's region
+// table, copied to LDS by the caller.
 template <int W, int I, bool EXC, typename OFF, typename HitFn>
 __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const uint32_t *sw, const uint64_t *sbad, uint64_t *Kk,
-                                                  uint32_t w0, uint32_t n, uint32_t pos_cap, uint32_t TB, uint32_t lane,
+                                                  uint32_t w0, uint32_t n, uint32_t pos_cap, const uint64_t *regions, uint32_t lane,
                                                   HitFn &&on_rank) {
     constexpr uint32_t K = 4 * W;
     for (uint32_t wb = 0; wb < n; wb += KEY_TILE) {
@@ -72,36 +74,35 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const uin
 #if defined(UTREE_ABLATE) && UTREE_ABLATE == 2
         continue;
 #endif
-        for (uint32_t it = 0; it * 64 < tn; it += 2) {
-            bool ok[2]; uint64_t wh[2], wl[2]; MinKey<W> mk[2]; Entry<W, I> t[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t tw = (it + h) * 64 + lane, i = w0 + wb + tw;  // window index in the tile / in the buffer
-                ok[h] = false;
-                if (tw < tn) {
-                    const uint32_t ch = i >> 6, bit = i & 63u;
-                    const uint64_t b0 = sbad[ch], b1 = sbad[ch + 1];
-                    const uint64_t x = (b0 >> bit) | (bit ? (b1 << (64 - bit)) : 0ull);  // bad flags of bases i..i+63
-                    ok[h] = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
-                }
-                if (ok[h]) {
-                    uint64_t slot;
-                    window_word<W>(sw, i, wh[h], wl[h]);
-                    const uint64_t ka = Kk[tw], kb = Kk[tw + MinWin<W>::NEXT];
-                    const uint64_t km = kb < ka ? kb : ka;
-                    min_finish<W>(wh[h], wl[h], (uint32_t)(km >> 32), (uint32_t)km - i, TB, slot, mk[h]);
-                    t[h] = load_slot<W, I>(im.table, slot);
-                }
+        for (uint32_t it = 0; it * 64 < tn; ++it) {
+            const uint32_t tw = it * 64 + lane, i = w0 + wb + tw;            // window index in the tile / in the buffer
+            bool ok = false;
+            if (tw < tn) {
+                const uint32_t ch = i >> 6, bit = i & 63u;
+                const uint64_t b0 = sbad[ch], b1 = sbad[ch + 1];
+                const uint64_t x = (b0 >> bit) | (bit ? (b1 << (64 - bit)) : 0ull);      // bad flags of bases i..i+63
+                ok = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
             }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint32_t rank = INVALID;
-                if (ok[h]) rank = resolve_entry<W, I, EXC, OFF>(im, t[h], mk[h], wh[h], wl[h]);
-                on_rank(rank);                                               // itree.c:929-931
+            uint32_t rank = INVALID;
+            if (ok) {
+                uint64_t wh, wl, bucket; MinKey<W> mk;
+                window_word<W>(sw, i, wh, wl);
+                const uint64_t ka = Kk[tw], kb = Kk[tw + MinWin<W>::NEXT];
+                const uint64_t km = kb < ka ? kb : ka;
+                min_finish<W>(wh, wl, (uint32_t)(km >> 32), (uint32_t)km - i, regions, bucket, mk);
+                const Bucket<W, I> bk = load_bucket<W, I>(im.table, bucket);
+                rank = resolve_bucket<W, I, EXC, OFF>(im, bk, mk, wh, wl);
             }
+            on_rank(rank);                                                   // itree.c:929-931
         }
         wave_lds_fence();
     }
+}
+
+// the image's 2 KB region table -> LDS (all threads of the workgroup; followed by a barrier)
+__device__ __forceinline__ void stage_regions(const utk_image &im, uint64_t *s_regions) {
+    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) s_regions[x] = im.regions[x];
+    __syncthreads();
 }
 
 __device__ __forceinline__ void store_result(utree_result *out, uint32_t label, int32_t cut, uint32_t found,
@@ -157,7 +158,7 @@ template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED>
 #ifndef UTREE_SHORT_MIN_WAVES
 #define UTREE_SHORT_MIN_WAVES 8
 #endif
-__global__ __launch_bounds__(256, CAP > SHORT2_CAP ? (I == 2 ? 5 : 3) : ((W == 8 && I == 2) ? (CAP > SHORT_CAP ? 7 : UTREE_SHORT_MIN_WAVES) : 5))
+__global__ __launch_bounds__(256, CAP > SHORT2_CAP ? (I == 2 ? 4 : 3) : ((W == 8 && I == 2) ? (CAP > SHORT_CAP ? 7 : UTREE_SHORT_MIN_WAVES) : 5))
 void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
                       const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
                       utk_workspace ws) {
@@ -168,6 +169,8 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     using HIT = typename std::conditional<I == 2, uint16_t, uint32_t>::type;     // ranks of u16-label databases fit 16 bits
     __shared__ HIT s_hits[WAVES_PER_BLOCK][CAP];
     __shared__ uint64_t s_keys[WAVES_PER_BLOCK][KEY_TILE + 128];
+    __shared__ uint64_t s_regions[256];
+    stage_regions(im, s_regions);
     const uint32_t lane = lane_id();
     const uint32_t wv = uni32(threadIdx.x >> 6);
     uint32_t *sw = s_words[wv];
@@ -176,7 +179,6 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     HIT *hits = s_hits[wv];
     uint64_t *Kk = s_keys[wv];
     const uint32_t wave_gid = blockIdx.x * WAVES_PER_BLOCK + wv, n_waves = gridDim.x * WAVES_PER_BLOCK;
-    const uint32_t TB = 24 + im.fine_bits;                // table bits
     unsigned long long chunk_base = 0;
     uint32_t chunk_left = 0;
 
@@ -244,7 +246,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 #endif
         // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933); two rounds of table loads in flight ----
         uint32_t F = 0;
-        wave_scan_windows<W, I, EXC, OFF>(im, sw, sbad, Kk, 0u, nwin, (uint32_t)CAP, TB, lane, [&](uint32_t rank) {
+        wave_scan_windows<W, I, EXC, OFF>(im, sw, sbad, Kk, 0u, nwin, (uint32_t)CAP, s_regions, lane, [&](uint32_t rank) {
             const bool hit = rank != INVALID;
             const uint64_t hm = __ballot(hit);
             if (hit) hits[F + lanes_below(hm)] = (HIT)rank;
@@ -356,6 +358,7 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
     __shared__ uint32_t s_touch[LONG_LDS_BITWORDS];
     __shared__ uint64_t s_keys[LONG_THREADS / 64][KEY_TILE + 128];
     __shared__ unsigned long long s_base;
+    __shared__ uint64_t s_regions[256];
     __shared__ uint32_t s_work, s_single;               // the read this workgroup took; the label of a one-label read
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = uni32(tid >> 6);
     uint8_t *sb = (uint8_t *)s_words;
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
     uint32_t *touch = nbw <= LONG_LDS_BITWORDS ? s_touch : ws.touch + (size_t)blockIdx.x * nbw;   // all zero between reads
     const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
     if (nbw <= LONG_LDS_BITWORDS) for (uint32_t x = tid; x < nbw; x += LONG_THREADS) s_touch[x] = 0;
-    __syncthreads();
+    stage_regions(im, s_regions);
 
     for (;;) {
         // long reads differ in length by orders of magnitude: hand them out one at a time
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(LONG_THREADS) void classify_long_k(utk_image im, co
             constexpr uint32_t PER_WAVE = LONG_TILE / (LONG_THREADS / 64);
             const uint32_t a = wv * PER_WAVE < tile_n ? wv * PER_WAVE : tile_n;
             const uint32_t b = a + PER_WAVE < tile_n ? a + PER_WAVE : tile_n;
-            wave_scan_windows<W, I, EXC, OFF>(im, s_words, s_bad, s_keys[wv], a, b - a, STAGE, 24 + im.fine_bits, lane, [&](uint32_t rank) {
+            wave_scan_windows<W, I, EXC, OFF>(im, s_words, s_bad, s_keys[wv], a, b - a, STAGE, s_regions, lane, [&](uint32_t rank) {
                 // one atomic per DISTINCT label of the 64 windows, not per hit: a read's hits mostly share a few labels,
                 // and 64 atomics on one address serialise in L2
                 const bool hit = rank != INVALID;

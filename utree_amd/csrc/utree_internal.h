@@ -35,17 +35,22 @@ typedef struct {
     uint32_t version, W, I, k;
     uint32_t fine_bits, rec_words, n_labels, flags;
     uint64_t n_nodes;
-    uint64_t n_slots;                /* 2^(24+fine_bits) table slots                                        */
+    uint64_t n_slots;                /* 64-byte buckets in the table (sum over the 256 hash regions)        */
     uint64_t n_min;                  /* MIN records = nodes the bin table reaches                          */
     uint64_t off_table, off_mrecs, off_recs, off_coarse, off_irreg, off_label_off, off_label_blob, off_rank2ix;
     uint64_t label_blob_bytes;
     uint64_t n_irregular;
     uint64_t total_bytes;
+    /* Bucket addressing: region r = top 8 bits of the minimizer hash h; bucket = (regions[r] >> 8) + ((h & 0xFFFFFF) >> s)
+     * with s = regions[r] & 0xFF <= 8, and the low s bits of h go into the record key.  The hash is a MINIMUM of K-15
+     * hashes, so nodes crowd towards h = 0: low regions get one bucket per hash value, high regions up to 256. */
+    uint64_t regions[256];
 } utree_image_header;
 
 /* What kernels take by value. */
 typedef struct {
-    const uint64_t *table;           /* direct-mapped table over minimizer-hash bits, rec_words words per slot */
+    const uint64_t *table;           /* 64-byte buckets: 8 / rec_words entries each, ascending by key; see regions[] */
+    const uint64_t *regions;         /* [256] in the image header                                              */
     const uint64_t *mrecs;           /* MIN records: nodes ordered by (minimizer hash, position, rest)        */
     const uint64_t *recs;            /* FILE records: nodes as the file orders them (exact-probe path only)   */
     const void *coarse;              /* the file's bin table: uint32_t* or uint64_t* (UTREE_F_OFF64)         */
@@ -67,7 +72,8 @@ int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_
 int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
                  uint32_t *d_irreg, unsigned long long *d_counters, void *stream);
 int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
-                  uint32_t table_bits, uint64_t *d_table, uint64_t *d_mrecs, unsigned long long *d_overflow, void *stream);
+                  const uint64_t *d_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs,
+                  unsigned long long *d_overflow, void *stream);
 int utk_compress_chunk(uint32_t W, uint32_t I, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
                        void *d_out, void *stream);
 int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream);

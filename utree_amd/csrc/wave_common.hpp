@@ -5,13 +5,6 @@
 #include <stdint.h>
 #include "device_common.hpp"
 
-#ifndef UTREE_RUN_HEAD
-#define UTREE_RUN_HEAD 7          /* records of a run fetched together, 8-byte records (<= 8: the image pads 8 records) */
-#endif
-#ifndef UTREE_RUN_HEAD2
-#define UTREE_RUN_HEAD2 3         /* ... 16- and 32-byte records */
-#endif
-
 namespace utk {
 
 // ------------------------------------------------------------------------------------------------
@@ -35,12 +28,25 @@ template <int W, int I> static __device__ uint32_t min_find(const uint64_t *mrec
     return INVALID;
 }
 
-// Second half of a lookup, given the table slot of the word's minimizer.  Words whose 24-bit bin is not
-// strictly ascending (COMPRESS' first-bin quirk) or any word of a non-monotone table take the reference's own
-// probe sequence over the FILE records instead: only that reproduces its answers there.
+// A bucket = 64 bytes = BUCKET_CAP entries, ascending by key, unused ones flagged empty; when more nodes fall into a
+// bucket its last entry is an overflow descriptor instead (rare: ~1 % of buckets at the design load).
+template <int W, int I> struct BucketOf { static constexpr int CAP = 8 / RecTraits<W, I>::EW; };
+template <int W, int I> struct Bucket { Entry<W, I> e[BucketOf<W, I>::CAP]; };
+
+template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket(const uint64_t *__restrict__ table, uint64_t bucket) {
+    Bucket<W, I> b;
+    constexpr int CAP = BucketOf<W, I>::CAP;
+#pragma unroll
+    for (int i = 0; i < CAP; ++i) b.e[i] = load_slot<W, I>(table, bucket * CAP + i);      // contiguous: 16-byte non-temporal loads
+    return b;
+}
+
+// Second half of a lookup, given the bucket of the word's minimizer.  Words whose 24-bit bin is not strictly ascending
+// (COMPRESS' first-bin quirk) or any word of a non-monotone table take the reference's own probe sequence over the FILE
+// records instead: only that reproduces its answers there.
 template <int W, int I, bool EXC, typename OFF>
-__device__ __forceinline__ uint32_t resolve_entry(const utk_image &im, const Entry<W, I> &t, const MinKey<W> &mk, uint64_t khi,
-                                                  uint64_t klo) {
+__device__ __forceinline__ uint32_t resolve_bucket(const utk_image &im, const Bucket<W, I> &b, const MinKey<W> &mk, uint64_t khi,
+                                                   uint64_t klo) {
     if constexpr (EXC) {
         const uint32_t p = word_prefix<W>(khi, klo);
         if ((im.irreg[p >> 5] >> (p & 31)) & 1u) {
@@ -50,36 +56,29 @@ __device__ __forceinline__ uint32_t resolve_entry(const utk_image &im, const Ent
             return exact_probe<W, I>(im.recs, s, e, word_suffix<W>(khi, klo));
         }
     }
-    const uint32_t flag = mrec_flag<W, I>(t);
-    if (flag == 0) return mkey_eq<W>(mrec_key<W, I>(t), mk) ? mrec_rank<W, I>(t) : INVALID;   // the slot's only node
-    if (flag == 1) return INVALID;                                                            // empty slot
-    const uint64_t d = t.w[RecTraits<W, I>::KW];
-    const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull, end = start + n;
-    // A run = the k-mers that share this minimizer.  Minimizers are minima, so most nodes sit in runs of 2-8 records (mean
-    // 3.5 at 0.28 nodes per slot; 98 % within 8).  The first RUN_HEAD records are fetched together -- contiguous, so the
-    // compiler emits 16-byte loads -- and only longer runs go on with a binary search, one round trip per step.  Measured
-    // on one box, 4 M x 150 bp reads: 2 records 5.78 ms, 4: 5.25, 6: 4.96, 7: 4.87, 8: 5.08 (r01).
-    constexpr int RUN_HEAD = RecTraits<W, I>::EW == 1 ? UTREE_RUN_HEAD : UTREE_RUN_HEAD2;
-    Entry<W, I> r[RUN_HEAD];
+    constexpr int CAP = BucketOf<W, I>::CAP;
 #pragma unroll
-    for (int i = 0; i < RUN_HEAD; ++i) r[i] = load_entry<W, I>(im.mrecs, start + i);
-#pragma unroll
-    for (int i = 0; i < RUN_HEAD; ++i) {
-        if ((uint64_t)i >= n) return INVALID;
-        const MinKey<W> k = mrec_key<W, I>(r[i]);
-        if (mkey_eq<W>(k, mk)) return mrec_rank<W, I>(r[i]);
-        if (mkey_lt<W>(mk, k)) return INVALID;                          // the run ascends by key
+    for (int i = 0; i < CAP; ++i) {
+        const uint32_t flag = mrec_flag<W, I>(b.e[i]);
+        if (flag == 1) return INVALID;                                                   // no more nodes in this bucket
+        if (flag == 2) {                                                                  // the rest of the bucket's nodes
+            const uint64_t d = b.e[i].w[RecTraits<W, I>::KW];
+            const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull;
+            return min_find<W, I>(im.mrecs, start, start + n, mk);
+        }
+        const MinKey<W> k = mrec_key<W, I>(b.e[i]);
+        if (mkey_eq<W>(k, mk)) return mrec_rank<W, I>(b.e[i]);
+        if (mkey_lt<W>(mk, k)) return INVALID;                                           // entries ascend by key
     }
-    if (n <= (uint64_t)RUN_HEAD) return INVALID;
-    return min_find<W, I>(im.mrecs, start + RUN_HEAD, end, mk);
+    return INVALID;
 }
 
 template <int W, int I, bool EXC, typename OFF>
 __device__ __forceinline__ uint32_t lookup_word(const utk_image &im, uint64_t khi, uint64_t klo) {
-    uint64_t slot; MinKey<W> mk;
-    min_split<W>(khi, klo, 24 + im.fine_bits, slot, mk);
-    const Entry<W, I> t = load_slot<W, I>(im.table, slot);
-    return resolve_entry<W, I, EXC, OFF>(im, t, mk, khi, klo);
+    uint64_t bucket; MinKey<W> mk;
+    min_split<W>(khi, klo, im.regions, bucket, mk);
+    const Bucket<W, I> b = load_bucket<W, I>(im.table, bucket);
+    return resolve_bucket<W, I, EXC, OFF>(im, b, mk, khi, klo);
 }
 
 // ------------------------------------------------------------------------------------------------
