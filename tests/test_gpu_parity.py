@@ -333,3 +333,49 @@ def test_more_long_reads_than_resident_workgroups(torch_cuda, rc, tmp_path):
     code, nr, good, err = o.search_file(str(fa), str(out), threads=8, rc=bool(rc))
     assert code == 0 and nr == len(reads)
     assert got == out.read_bytes()
+
+
+def test_overflowing_buckets(torch_cuda, tmp_path):
+    """Hundreds of k-mers that share ONE minimizer land in one 64-byte bucket: 7 stay inline, the rest are reached through the
+    bucket's overflow descriptor (binary search in the sorted records).  Such buckets are ~1 % at the design load and never
+    occur in the small fixtures, so this database is made of them (k = 32 and k = 64)."""
+    def mix32(x):
+        x = np.uint32(x)
+        with np.errstate(over="ignore"):
+            x ^= x >> np.uint32(16); x *= np.uint32(0x85EBCA6B); x ^= x >> np.uint32(13); x *= np.uint32(0xC2B2AE35); x ^= x >> np.uint32(16)
+        return int(x)
+    rng = np.random.default_rng(5)
+    cand = rng.integers(0, 1 << 32, 6_000_000, dtype=np.uint64).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        h = cand.copy(); h ^= h >> np.uint32(16); h *= np.uint32(0x85EBCA6B); h ^= h >> np.uint32(13); h *= np.uint32(0xC2B2AE35); h ^= h >> np.uint32(16)
+    minis = [int(c) for c in cand[np.argsort(h)[:3]]]                 # three 16-mers with tiny hashes: minimizers wherever they occur
+    assert all(mix32(m) < 5000 for m in minis)
+    for W in (8, 16):
+        k = 4 * W
+        kmers = set()
+        for m in minis:
+            core = "".join("ACGT"[(m >> (30 - 2 * j)) & 3] for j in range(16))
+            for _ in range(150):
+                p = int(rng.integers(0, k - 15))
+                s = "".join("ACGT"[c] for c in rng.integers(0, 4, k))
+                kmers.add(s[:p] + core + s[p + 16:])
+        kmers = sorted(kmers)
+        hi, lo = ctrfile.encode_kmers(kmers)
+        ix = rng.integers(0, 12, len(kmers)).astype(np.uint32)
+        labels = ["k__A;p__B;c__L%d" % i for i in range(12)]
+        order = np.lexsort((lo, hi))
+        ctr = str(tmp_path / ("ovf%d.ctr" % k))
+        ctrfile.write_ctr(ctr, W, 2, hi[order], lo[order], ix[order], labels)
+        db = CtrDB.open(ctr)
+        tree = DeviceTree.upload(db, 0)
+        o = orc.OracleDB.load(ctr)
+        reads = [("h%d" % i, s) for i, s in enumerate(kmers)]
+        reads += [("m%d" % i, s[:-1] + "ACGT"[("ACGT".index(s[-1]) + 1) & 3]) for i, s in enumerate(kmers[::3])]   # near misses
+        reads += [("j%d" % i, "".join(kmers[int(a)] for a in rng.integers(0, len(kmers), 4))) for i in range(200)]   # several per read
+        data = "".join(">%s\n%s\n" % r for r in reads).encode()
+        fa = tmp_path / "r.fa"; fa.write_bytes(data)
+        out = tmp_path / "o.txt"
+        code, nr, good, err = o.search_file(str(fa), str(out), threads=4, rc=False)
+        assert code == 0 and good >= len(kmers)
+        assert classify_fasta_bytes(db, tree, data, rc=False) == out.read_bytes()
+        tree.close()
