@@ -57,20 +57,19 @@ __device__ __forceinline__ uint32_t resolve_bucket(const utk_image &im, const Bu
         }
     }
     constexpr int CAP = BucketOf<W, I>::CAP;
+    // straight-line scan: entries ascend by key, empty entries and the overflow descriptor never equal a key
+    uint32_t rank = INVALID;
 #pragma unroll
     for (int i = 0; i < CAP; ++i) {
-        const uint32_t flag = mrec_flag<W, I>(b.e[i]);
-        if (flag == 1) return INVALID;                                                   // no more nodes in this bucket
-        if (flag == 2) {                                                                  // the rest of the bucket's nodes
-            const uint64_t d = b.e[i].w[RecTraits<W, I>::KW];
-            const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull;
-            return min_find<W, I>(im.mrecs, start, start + n, mk);
-        }
-        const MinKey<W> k = mrec_key<W, I>(b.e[i]);
-        if (mkey_eq<W>(k, mk)) return mrec_rank<W, I>(b.e[i]);
-        if (mkey_lt<W>(mk, k)) return INVALID;                                           // entries ascend by key
+        const bool hit = mrec_flag<W, I>(b.e[i]) == 0 && mkey_eq<W>(mrec_key<W, I>(b.e[i]), mk);
+        rank = hit ? mrec_rank<W, I>(b.e[i]) : rank;
     }
-    return INVALID;
+    if (mrec_flag<W, I>(b.e[CAP - 1]) == 2 && rank == INVALID) {                          // the rest of the bucket's nodes
+        const uint64_t d = b.e[CAP - 1].w[RecTraits<W, I>::KW];
+        const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull;
+        rank = min_find<W, I>(im.mrecs, start, start + n, mk);
+    }
+    return rank;
 }
 
 template <int W, int I, bool EXC, typename OFF>
