@@ -487,6 +487,15 @@ __device__ __forceinline__ uint64_t label8(const char *s, uint32_t p) {
     return x;
 }
 
+// exact per-byte flags (0x80 in the byte): x1 byte == 0, x1 byte == ';', or x1 and x2 bytes differ; the lowest set flag is
+// the first place the reference's scan stops (itree.c:1060-1061)
+__device__ __forceinline__ uint64_t stop_flags(uint64_t x1, uint64_t x2) {
+    const uint64_t semi = x1 ^ 0x3B3B3B3B3B3B3B3Bull, d = x1 ^ x2;
+    uint64_t m = (((x1 - 0x0101010101010101ull) & ~x1) | ((semi - 0x0101010101010101ull) & ~semi)) & 0x8080808080808080ull;
+    m |= (((d & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | d) & 0x8080808080808080ull;
+    return m;
+}
+
 __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__restrict__ out, utk_workspace ws, uint32_t n_reads) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
@@ -506,28 +515,35 @@ __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__rest
         uint32_t c1 = run;
         const uint32_t probe = dv + (dv == 0xFFFFFFFFu);                      // 0 while nothing is agreed, else dv
         const bool skip0 = dv != 0xFFFFFFFFu;                                // then byte `probe` itself is not compared
+        // bytes probe..probe+15 of the entry before z: they were this entry's (x2, y2) one step earlier, so they are kept
+        uint64_t x1_first = label8(s1, probe), y1_first = label8(s1, probe + 8);
         for (uint32_t z = st + 1; z < ed; ++z) {
             const uint64_t tz = T[z];
             const uint32_t nz = (uint32_t)(tz >> 32);
             const char *s2 = blob + loff[(uint32_t)tz];
-            uint64_t x1 = label8(s1, probe);
+            uint64_t x1 = x1_first, y1 = y1_first;
+            const uint64_t x2_first = label8(s2, probe), y2_first = label8(s2, probe + 8);
             bool aside = false, stop = false;
             if (!(x1 & 0xFFull)) aside = true;                                // previous label exhausted: itree.c:1052
             else {
-                // itree.c:1060-1061: td = first index > dv where s1 ends, differs from s2, or is ';' -- eight bytes per step
-                uint64_t x2 = label8(s2, probe);
+                // itree.c:1060-1061: td = first index > dv where s1 ends, differs from s2, or is ';' -- sixteen bytes per
+                // step (two loads in flight; the blob is zero padded by 64 bytes, dev_image.c)
+                uint64_t x2 = x2_first, y2 = y2_first;
                 uint32_t base = probe, idx, prevlast = 0;
                 bool first = true;
                 for (;;) {
-                    const uint64_t semi = x1 ^ 0x3B3B3B3B3B3B3B3Bull, d = x1 ^ x2;
-                    // exact per-byte flags: x1 byte == 0, x1 byte == ';', bytes differ (lowest set flag is what we need)
-                    uint64_t m = (((x1 - 0x0101010101010101ull) & ~x1) | ((semi - 0x0101010101010101ull) & ~semi)) & 0x8080808080808080ull;
-                    m |= (((d & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | d) & 0x8080808080808080ull;
+                    uint64_t m = stop_flags(x1, x2);
                     if (first && skip0) m &= ~0xFFull;
                     if (m) { idx = (uint32_t)(__builtin_ctzll(m) >> 3); break; }
                     prevlast = (uint32_t)(x1 >> 56);
                     base += 8; first = false;
+                    m = stop_flags(y1, y2);
+                    x1 = y1; x2 = y2;
+                    if (m) { idx = (uint32_t)(__builtin_ctzll(m) >> 3); break; }
+                    prevlast = (uint32_t)(x1 >> 56);
+                    base += 8;
                     x1 = label8(s1, base); x2 = label8(s2, base);
+                    y1 = label8(s1, base + 8); y2 = label8(s2, base + 8);
                 }
                 td = base + idx;
                 const uint32_t a = (uint32_t)(x1 >> (8 * idx)) & 0xFFu, b = (uint32_t)(x2 >> (8 * idx)) & 0xFFu;
@@ -544,7 +560,7 @@ __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__rest
                 cutoff = cut_of(orun);
             }
             if (stop) break;
-            s1 = s2; c1 = nz;
+            s1 = s2; c1 = nz; x1_first = x2_first; y1_first = y2_first;
         }
         sl = run; ol = orun;                                                   // itree.c:1071
         if (run < cutoff) break;                                               // itree.c:1072
