@@ -57,13 +57,20 @@ __device__ __forceinline__ uint32_t resolve_bucket(const utk_image &im, const Bu
         }
     }
     constexpr int CAP = BucketOf<W, I>::CAP;
-    // straight-line scan: entries ascend by key, empty entries and the overflow descriptor never equal a key
-    uint32_t rank = INVALID;
+    // straight-line scan.  An entry is the record of `mk` exactly when its key word without the 16 label bits equals
+    // {flag 0 | mk} (an empty entry or the overflow descriptor has a non-zero flag, so neither can): one AND and one
+    // 64-bit compare per entry; the label bits of the matching entry are picked up raw and decoded once at the end.
+    constexpr int KW = RecTraits<W, I>::KW;
+    const uint64_t want = (W == 16 ? mk.hi : mk.lo) << 16;
+    uint32_t raw = INVALID;
 #pragma unroll
     for (int i = 0; i < CAP; ++i) {
-        const bool hit = mrec_flag<W, I>(b.e[i]) == 0 && mkey_eq<W>(mrec_key<W, I>(b.e[i]), mk);
-        rank = hit ? mrec_rank<W, I>(b.e[i]) : rank;
+        bool hit = (b.e[i].w[KW] & ~0xFFFFull) == want;
+        if constexpr (W == 16) hit = hit && b.e[i].w[0] == mk.lo;
+        raw = hit ? (uint32_t)b.e[i].w[I == 4 ? KW + 1 : KW] : raw;
     }
+    uint32_t rank = raw;
+    if constexpr (I == 2) { rank = raw & 0xFFFFu; rank = rank == 0xFFFFu ? INVALID : rank; }
     if (mrec_flag<W, I>(b.e[CAP - 1]) == 2 && rank == INVALID) {                          // the rest of the bucket's nodes
         const uint64_t d = b.e[CAP - 1].w[RecTraits<W, I>::KW];
         const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull;
