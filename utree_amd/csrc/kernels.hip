@@ -137,6 +137,85 @@ __global__ __launch_bounds__(256) void route_k(const uint32_t *__restrict__ len,
 }
 
 // ------------------------------------------------------------------------------------------------
+// stage_read: a read's bases -> 2-bit codes packed big-endian in LDS (sb: one byte per 4 bases) and one "bad base" bit per
+// base (sbadb: bit j%8 of byte j/8), FOUR bases per lane.  With do_rc the staged sequence is the read, one separator
+// (a bad base: itree.c:1005-1012 never lets a window span both strands) and the reverse complement: staged base j > L is
+// the complement of source base 2L - j.
+//
+// A lane owns the group of staged bases 4g..4g+3.  Source bytes are fetched as ALIGNED dwords (one per lane and strand;
+// a dword is only touched when it holds at least one byte of the read, so no load leaves the caller's buffer) and the
+// lane's four unaligned bytes come from its own dword and its neighbour's (lane + 1) through v_alignbyte.  Lanes 62 and
+// 63 of a round only fetch for their neighbours: a round covers 62 groups = 248 bases.
+// Coding is byte-parallel: (b >> 1) & 3 maps A C T G (either case) to 0 1 2 3 and everything else somewhere; v_perm
+// turns that back into the letter it stands for, and a base is bad when that is not the (upper-cased) input byte
+// (itree.c:110-121).  code = g ^ (g >> 1) gives A=0 C=1 G=2 T=3; the four codes of a group are gathered into one byte
+// by a multiplication whose partial products do not overlap.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t STAGE_STEP = 62;
+
+__device__ __forceinline__ uint32_t low_bytes(uint32_t n) {            // 0xFF in the n lowest bytes, n clamped to 0..4
+    return n >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n)) - 1u);
+}
+
+template <int CAP>
+__device__ __forceinline__ void stage_read(const uint8_t *__restrict__ bases, uint64_t o, uint32_t L, uint32_t total, int do_rc,
+                                           uint8_t *sb, uint8_t *sbadb, uint32_t lane) {
+    constexpr uint32_t ROUNDS = (CAP / 4 + STAGE_STEP - 1) / STAGE_STEP;
+    constexpr uint32_t B = ROUNDS > 1 ? 2 : 1;                         // rounds whose loads are issued before the first is used
+    const uint32_t ngroups = (total + 3u) >> 2;
+    const uint32_t mf = (uint32_t)o & 3u;                              // forward: source byte s sits in aligned dword (s + mf) / 4
+    const uint32_t mr = (uint32_t)(o + 2ull * L - 3ull) & 3u;          // reverse: misalignment of a group's lowest source byte
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += B * STAGE_STEP) {
+        uint32_t df[B], dr[B];
+#pragma unroll
+        for (uint32_t k = 0; k < B; ++k) {
+            const uint32_t g = g0 + k * STAGE_STEP + lane;
+            df[k] = 0; dr[k] = 0;
+            if (k && g0 + k * STAGE_STEP >= ngroups) break;                      // (wave-uniform) nothing left for this round
+            // forward dword g holds source bytes 4g - mf .. 4g - mf + 3
+            if (lane < 63u && 4u * g < L + mf) df[k] = *(const uint32_t *)(bases + (o - mf) + 4ull * g);
+            if (do_rc) {
+                // the group's source bytes are q .. q+3 (q = 2L - 3 - 4g, staged in reverse); this lane fetches the UPPER aligned
+                // dword of the two they may touch, source bytes s .. s+3 with s = q - mr + 4, lane + 1 fetches the lower one
+                const int32_t sidx = (int32_t)(2u * L) - 3 - (int32_t)(4u * g) - (int32_t)mr + 4;
+                if (lane < 63u && sidx < (int32_t)L && sidx + 3 >= 0) dr[k] = *(const uint32_t *)(bases + (int64_t)o + sidx);
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < B; ++k) {
+            const uint32_t g = g0 + k * STAGE_STEP + lane;
+            if (k && g0 + k * STAGE_STEP >= ngroups) break;
+            const uint32_t fn = (uint32_t)__shfl_down((int)df[k], 1);
+            const uint32_t fm = low_bytes(4u * g < L ? L - 4u * g : 0u);                   // staged bytes with j < L
+            uint32_t word = __builtin_amdgcn_alignbyte(fn, df[k], mf) & fm;
+            uint32_t rm = 0;
+            if (do_rc) {
+                const uint32_t rl = (uint32_t)__shfl_down((int)dr[k], 1);
+                const uint32_t w = __builtin_amdgcn_alignbyte(dr[k], rl, mr);            // source bytes q .. q+3
+                const uint32_t rev = __builtin_amdgcn_perm(0u, w, 0x00010203u);           // staged order
+                // staged bytes with L < j <= 2L
+                const uint32_t from = L + 1u > 4u * g ? L + 1u - 4u * g : 0u, to = 2u * L + 1u > 4u * g ? 2u * L + 1u - 4u * g : 0u;
+                rm = low_bytes(to) & ~low_bytes(from);
+                word |= rev & rm;
+            }
+            const uint32_t g2 = (word >> 1) & 0x03030303u;
+            const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, g2);            // 0 1 2 3 -> A C T G
+            const uint32_t z = (word & 0xDFDFDFDFu) ^ letter;                              // non-zero byte = bad base
+            const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+            const uint32_t nib = (nz * 0x00204081u) >> 28;                                 // bits 7,15,23,31 -> 0..3
+            const uint32_t nib_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nib, 0x101, 0xF, 0xF, true);   // row_shl:1 = lane + 1
+            uint32_t code = g2 ^ ((g2 >> 1) & 0x01010101u);
+            code ^= rm & 0x03030303u;                                                      // complement on the reverse strand
+            const uint32_t packed = (code * 0x40100401u) >> 24;                            // c0<<6 | c1<<4 | c2<<2 | c3
+            if (lane < STAGE_STEP && g < ngroups) {
+                sb[g ^ 3u] = (uint8_t)packed;
+                if (!(lane & 1u)) sbadb[g >> 1] = (uint8_t)(nib | (nib_next << 4));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // classify_short: one wavefront per read (reads whose staged length fits UTREE_SHORT_CAP bases)
 // ------------------------------------------------------------------------------------------------
 constexpr int SHORT_CAP = UTREE_SHORT_CAP;          // 150 bp + reverse strand fits
@@ -211,33 +290,8 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         }
         const uint32_t nwin = total - K + 1;
         const uint32_t nch = (total + 63) >> 6;
-        // ---- stage: bytes -> 2-bit codes packed big-endian in LDS, bad-base ballots ----
-        // byte loads are issued in groups (the whole read for CAP = SHORT_CAP) before the first one is consumed
-        constexpr int G = NCH <= 5 ? NCH : 4;
-        for (uint32_t c0 = 0; c0 < nch; c0 += G) {
-            uint32_t raw[G];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const uint32_t j = (c0 + g) * 64 + lane;
-                raw[g] = 0;
-                if (j < L) raw[g] = bases[o + j];
-                else if (j > L && j < total) raw[g] = 0x100u | bases[o + (2 * L - j)];      // reverse strand: complement
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const uint32_t c = c0 + g;
-                if (c < nch) {
-                    uint32_t code; bool bad;
-                    base_code(raw[g] & 0xFFu, code, bad);
-                    code ^= (raw[g] >> 8) * 3u;
-                    uint64_t bm = __ballot(bad);
-                    uint32_t t = (code << 2) | (uint32_t)__shfl_down((int)code, 1);
-                    uint32_t u = (t << 4) | (uint32_t)__shfl_down((int)t, 2);
-                    if ((lane & 3u) == 0) sb[(c * 16 + (lane >> 2)) ^ 3u] = (uint8_t)u;
-                    if (lane == 0) sbad[c] = bm;
-                }
-            }
-        }
+        // ---- stage: bytes -> 2-bit codes packed big-endian in LDS, bad-base bits ----
+        stage_read<CAP>(bases, o, L, total, do_rc, sb, (uint8_t *)sbad, lane);
         if (lane == 0) sbad[nch] = ~0ull;
         wave_lds_fence();
 #if defined(UTREE_ABLATE) && UTREE_ABLATE == 1
