@@ -21,7 +21,7 @@ using namespace utk;
 namespace {
 
 
-constexpr uint32_t KEY_TILE = 256;                    // windows per sliding-minimizer tile
+constexpr uint32_t KEY_TILE = 128;                    // windows per sliding-minimizer tile
 
 // 32 bits (16 bases) of the packed stream starting at base j
 __device__ __forceinline__ uint32_t mmer_at(const uint32_t *sw, uint32_t j) {
@@ -137,80 +137,82 @@ __global__ __launch_bounds__(256) void route_k(const uint32_t *__restrict__ len,
 }
 
 // ------------------------------------------------------------------------------------------------
-// stage_read: a read's bases -> 2-bit codes packed big-endian in LDS (sb: one byte per 4 bases) and one "bad base" bit per
-// base (sbadb: bit j%8 of byte j/8), FOUR bases per lane.  With do_rc the staged sequence is the read, one separator
-// (a bad base: itree.c:1005-1012 never lets a window span both strands) and the reverse complement: staged base j > L is
-// the complement of source base 2L - j.
+// fetch_raw / stage_read: a read's bytes -> LDS as they are (global_load_lds: no registers are held while they fly, so the
+// NEXT read's bytes travel during the current read's window lookups), then -> 2-bit codes packed big-endian in LDS (sb:
+// one byte per 4 bases) and one "bad base" bit per base (sbadb: bit j%8 of byte j/8), FOUR bases per lane.  With do_rc
+// the staged sequence is the read, one separator (a bad base: itree.c:1005-1012 never lets a window span both strands)
+// and the reverse complement: staged base j > L is the complement of source base 2L - j -- both strands come from the
+// same raw bytes.
 //
-// A lane owns the group of staged bases 4g..4g+3.  Source bytes are fetched as ALIGNED dwords (one per lane and strand;
-// a dword is only touched when it holds at least one byte of the read, so no load leaves the caller's buffer) and the
-// lane's four unaligned bytes come from its own dword and its neighbour's (lane + 1) through v_alignbyte.  Lanes 62 and
-// 63 of a round only fetch for their neighbours: a round covers 62 groups = 248 bases.
-// Coding is byte-parallel: (b >> 1) & 3 maps A C T G (either case) to 0 1 2 3 and everything else somewhere; v_perm
-// turns that back into the letter it stands for, and a base is bad when that is not the (upper-cased) input byte
-// (itree.c:110-121).  code = g ^ (g >> 1) gives A=0 C=1 G=2 T=3; the four codes of a group are gathered into one byte
-// by a multiplication whose partial products do not overlap.
+// fetch_raw copies the ALIGNED dwords that hold the read (a dword is only touched when it holds at least one byte of the
+// read, so no load leaves the caller's buffer): raw[1 + d] = dword d, source byte s is raw byte 4 + mf + s with
+// mf = address & 3; raw[0] is a dummy so that the reverse strand's last group may reach "before" the read.
+// stage_read: a lane owns the staged bases 4g..4g+3; its four unaligned source bytes come from two raw dwords through
+// v_alignbyte.  Coding is byte-parallel: (b >> 1) & 3 maps A C T G (either case) to 0 1 2 3 and everything else
+// somewhere; v_perm turns that back into the letter it stands for, and a base is bad when that is not the (upper-cased)
+// input byte (itree.c:110-121).  code = g ^ (g >> 1) gives A=0 C=1 G=2 T=3; the four codes of a group are gathered into
+// one byte by a multiplication whose partial products do not overlap.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t STAGE_STEP = 62;
+template <int CAP> struct RawBuf { static constexpr uint32_t DW = ((CAP / 4 + 1 + 63) / 64) * 64; };   // dwords a read may span, per 64 lanes
 
 __device__ __forceinline__ uint32_t low_bytes(uint32_t n) {            // 0xFF in the n lowest bytes, n clamped to 0..4
     return n >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n)) - 1u);
 }
 
 template <int CAP>
-__device__ __forceinline__ void stage_read(const uint8_t *__restrict__ bases, uint64_t o, uint32_t L, uint32_t total, int do_rc,
-                                           uint8_t *sb, uint8_t *sbadb, uint32_t lane) {
-    constexpr uint32_t ROUNDS = (CAP / 4 + STAGE_STEP - 1) / STAGE_STEP;
-    constexpr uint32_t B = ROUNDS > 1 ? 2 : 1;                         // rounds whose loads are issued before the first is used
-    const uint32_t ngroups = (total + 3u) >> 2;
-    const uint32_t mf = (uint32_t)o & 3u;                              // forward: source byte s sits in aligned dword (s + mf) / 4
-    const uint32_t mr = (uint32_t)(o + 2ull * L - 3ull) & 3u;          // reverse: misalignment of a group's lowest source byte
-    for (uint32_t g0 = 0; g0 < ngroups; g0 += B * STAGE_STEP) {
-        uint32_t df[B], dr[B];
-#pragma unroll
-        for (uint32_t k = 0; k < B; ++k) {
-            const uint32_t g = g0 + k * STAGE_STEP + lane;
-            df[k] = 0; dr[k] = 0;
-            if (k && g0 + k * STAGE_STEP >= ngroups) break;                      // (wave-uniform) nothing left for this round
-            // forward dword g holds source bytes 4g - mf .. 4g - mf + 3
-            if (lane < 63u && 4u * g < L + mf) df[k] = *(const uint32_t *)(bases + (o - mf) + 4ull * g);
-            if (do_rc) {
-                // the group's source bytes are q .. q+3 (q = 2L - 3 - 4g, staged in reverse); this lane fetches the UPPER aligned
-                // dword of the two they may touch, source bytes s .. s+3 with s = q - mr + 4, lane + 1 fetches the lower one
-                const int32_t sidx = (int32_t)(2u * L) - 3 - (int32_t)(4u * g) - (int32_t)mr + 4;
-                if (lane < 63u && sidx < (int32_t)L && sidx + 3 >= 0) dr[k] = *(const uint32_t *)(bases + (int64_t)o + sidx);
-            }
+__device__ __forceinline__ void fetch_raw(const uint8_t *__restrict__ bases, uint64_t o, uint32_t L, uint32_t *raw, uint32_t lane) {
+    const uint32_t mf = (uint32_t)o & 3u;
+    const uint32_t nd = (L + mf + 3u) >> 2;                            // <= CAP/4 + 1
+    const uint8_t *p = bases + (o - mf);
+    for (uint32_t d0 = 0; d0 < nd; d0 += 64) {
+        const uint32_t d = d0 + lane;
+        if (d < nd) {
+            // Written as assembly on purpose: the compiler makes every later LDS access wait for an LDS-DMA load it knows
+            // about (it cannot tell which LDS bytes the load writes), which would stall the window phase at its first LDS
+            // read.  This load is invisible to its counters; the consumer waits explicitly (s_waitcnt vmcnt(0) before
+            // stage_read).  Memory operations retire in order, so the compiler's own vmcnt waits stay sufficient.
+            const uint8_t *src = p + 4ull * d;
+            const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(raw + 1 + d0);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src), "s"(dst) : "memory");   // m0: reserved, nothing else in this file uses it
         }
-#pragma unroll
-        for (uint32_t k = 0; k < B; ++k) {
-            const uint32_t g = g0 + k * STAGE_STEP + lane;
-            if (k && g0 + k * STAGE_STEP >= ngroups) break;
-            const uint32_t fn = (uint32_t)__shfl_down((int)df[k], 1);
-            const uint32_t fm = low_bytes(4u * g < L ? L - 4u * g : 0u);                   // staged bytes with j < L
-            uint32_t word = __builtin_amdgcn_alignbyte(fn, df[k], mf) & fm;
-            uint32_t rm = 0;
-            if (do_rc) {
-                const uint32_t rl = (uint32_t)__shfl_down((int)dr[k], 1);
-                const uint32_t w = __builtin_amdgcn_alignbyte(dr[k], rl, mr);            // source bytes q .. q+3
-                const uint32_t rev = __builtin_amdgcn_perm(0u, w, 0x00010203u);           // staged order
-                // staged bytes with L < j <= 2L
-                const uint32_t from = L + 1u > 4u * g ? L + 1u - 4u * g : 0u, to = 2u * L + 1u > 4u * g ? 2u * L + 1u - 4u * g : 0u;
-                rm = low_bytes(to) & ~low_bytes(from);
-                word |= rev & rm;
-            }
-            const uint32_t g2 = (word >> 1) & 0x03030303u;
-            const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, g2);            // 0 1 2 3 -> A C T G
-            const uint32_t z = (word & 0xDFDFDFDFu) ^ letter;                              // non-zero byte = bad base
-            const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
-            const uint32_t nib = (nz * 0x00204081u) >> 28;                                 // bits 7,15,23,31 -> 0..3
-            const uint32_t nib_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nib, 0x101, 0xF, 0xF, true);   // row_shl:1 = lane + 1
-            uint32_t code = g2 ^ ((g2 >> 1) & 0x01010101u);
-            code ^= rm & 0x03030303u;                                                      // complement on the reverse strand
-            const uint32_t packed = (code * 0x40100401u) >> 24;                            // c0<<6 | c1<<4 | c2<<2 | c3
-            if (lane < STAGE_STEP && g < ngroups) {
-                sb[g ^ 3u] = (uint8_t)packed;
-                if (!(lane & 1u)) sbadb[g >> 1] = (uint8_t)(nib | (nib_next << 4));
-            }
+    }
+}
+
+template <int CAP>
+__device__ __forceinline__ void stage_read(const uint32_t *raw, uint32_t mf, uint32_t L, uint32_t total, int do_rc,
+                                           uint8_t *sb, uint8_t *sbadb, uint32_t lane) {
+    constexpr uint32_t DW = RawBuf<CAP>::DW;
+    const uint32_t ngroups = (total + 3u) >> 2;
+    const uint32_t mr = (mf + 2u * L + 1u) & 3u;                       // reverse: misalignment of a group's lowest source byte (2L - 3 - 4g)
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += 64) {
+        const uint32_t g = g0 + lane;
+        const uint32_t gi = g < DW ? g : DW - 1u;
+        const uint32_t fm = low_bytes(4u * g < L ? L - 4u * g : 0u);                       // staged bytes with j < L
+        uint32_t word = __builtin_amdgcn_alignbyte(raw[2u + gi], raw[1u + gi], mf) & fm;    // source bytes 4g .. 4g+3
+        uint32_t rm = 0;
+        if (do_rc) {
+            // source bytes q .. q+3 with q = 2L - 3 - 4g >= -4, staged in reverse order
+            int32_t i4 = ((int32_t)(mf + 2u * L) - 3 - (int32_t)(4u * g)) >> 2;
+            i4 = i4 < -1 ? -1 : (i4 > (int32_t)DW - 1 ? (int32_t)DW - 1 : i4);
+            const uint32_t w = __builtin_amdgcn_alignbyte(raw[2 + i4], raw[1 + i4], mr);
+            const uint32_t rev = __builtin_amdgcn_perm(0u, w, 0x00010203u);
+            // staged bytes with L < j <= 2L
+            const uint32_t from = L + 1u > 4u * g ? L + 1u - 4u * g : 0u, to = 2u * L + 1u > 4u * g ? 2u * L + 1u - 4u * g : 0u;
+            rm = low_bytes(to) & ~low_bytes(from);
+            word |= rev & rm;
+        }
+        const uint32_t g2 = (word >> 1) & 0x03030303u;
+        const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, g2);            // 0 1 2 3 -> A C T G
+        const uint32_t z = (word & 0xDFDFDFDFu) ^ letter;                              // non-zero byte = bad base
+        const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+        const uint32_t nib = (nz * 0x00204081u) >> 28;                                 // bits 7,15,23,31 -> 0..3
+        const uint32_t nib_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nib, 0x101, 0xF, 0xF, true);   // row_shl:1 = lane + 1
+        uint32_t code = g2 ^ ((g2 >> 1) & 0x01010101u);
+        code ^= rm & 0x03030303u;                                                      // complement on the reverse strand
+        const uint32_t packed = (code * 0x40100401u) >> 24;                            // c0<<6 | c1<<4 | c2<<2 | c3
+        if (g < ngroups) {
+            sb[g ^ 3u] = (uint8_t)packed;
+            if (!(lane & 1u)) sbadb[g >> 1] = (uint8_t)(nib | (nib_next << 4));
         }
     }
 }
@@ -249,9 +251,15 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     __shared__ HIT s_hits[WAVES_PER_BLOCK][CAP];
     __shared__ uint64_t s_keys[WAVES_PER_BLOCK][KEY_TILE + 128];
     __shared__ uint64_t s_regions[256];
+    // the mid-length pass has no room for a raw buffer of its own and less to gain: its raw bytes pass through the hit
+    // list's space (consumed by stage_read before the first hit is written) and are not requested ahead
+    constexpr bool PREFETCH = CAP <= SHORT2_CAP;
+    static_assert(PREFETCH || sizeof(HIT) * CAP >= 4 * (RawBuf<CAP>::DW + 4), "raw bytes must fit the hit list");
+    __shared__ uint32_t s_raw[PREFETCH ? WAVES_PER_BLOCK : 1][PREFETCH ? RawBuf<CAP>::DW + 4 : 1];
     stage_regions(im, s_regions);
     const uint32_t lane = lane_id();
     const uint32_t wv = uni32(threadIdx.x >> 6);
+    uint32_t *raw = PREFETCH ? s_raw[wv] : (uint32_t *)s_hits[wv];
     uint32_t *sw = s_words[wv];
     uint8_t *sb = (uint8_t *)sw;
     uint64_t *sbad = s_bad[wv];
@@ -266,7 +274,13 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     const uint32_t n_items = LISTED ? (uint32_t)ws.cursors[UTREE_CUR_MID] : n_reads;
     unsigned long long *work = &ws.cursors[LISTED ? UTREE_CUR_WORK_MID : UTREE_CUR_WORK];
     (void)wave_gid; (void)n_waves;
+    // A read's bytes are requested one read ahead (fetch_raw, into LDS): while this read's windows wait for their table
+    // lines, the next read's bytes are already on their way.  The pipeline restarts at every grab.
+    auto stageable = [&](uint32_t len_) { const uint64_t t = do_rc ? 2 * (uint64_t)len_ + 1 : len_; return t <= (uint64_t)CAP && t >= K; };
     uint32_t item = 0, item_end = 0;
+    bool primed = false;
+    uint32_t L_next = 0;
+    uint64_t o_next = 0;
     for (;;) {
         if (item == item_end) {
             unsigned long long g = 0;
@@ -274,24 +288,41 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             item = uni32((uint32_t)g);
             if (item >= n_items) break;
             item_end = item + WORK_GRAB < n_items ? item + WORK_GRAB : n_items;
+            primed = false;
         }
         const uint32_t cur_item = item++;
         const uint32_t r = LISTED ? uni32(ws.mid_list[cur_item]) : cur_item;
-        const uint32_t L = uni32(len[r]);
-        const uint64_t o = uni64(off[r]);
+        uint32_t L; uint64_t o;
+        if (primed) { L = L_next; o = o_next; }
+        else {
+            L = uni32(len[r]); o = uni64(off[r]);
+            if (stageable(L)) fetch_raw<CAP>(bases, o, L, raw, lane);
+        }
+        primed = PREFETCH && item < item_end;
+        if (primed) {
+            const uint32_t rn = LISTED ? uni32(ws.mid_list[item]) : item;
+            L_next = uni32(len[rn]); o_next = uni64(off[rn]);
+        }
         const uint64_t total64 = do_rc ? 2 * (uint64_t)L + 1 : L;
+        const uint32_t total = (uint32_t)total64;
+        const bool staged = stageable(L);
+        if (staged) {
+            // ---- stage: raw bytes -> 2-bit codes packed big-endian in LDS, bad-base bits ----
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_fence();
+            stage_read<CAP>(raw, (uint32_t)o & 3u, L, total, do_rc, sb, (uint8_t *)sbad, lane);
+            wave_lds_fence();
+        }
+        if (primed && stageable(L_next)) fetch_raw<CAP>(bases, o_next, L_next, raw, lane);   // the raw buffer is free again
         if (total64 > (uint64_t)CAP) {                     // route_k listed it for the mid-length pass or classify_long_k
             continue;
         }
-        const uint32_t total = (uint32_t)total64;
         if (total < K) {                                   // no window: no hit, no output line
             if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0);
             continue;
         }
         const uint32_t nwin = total - K + 1;
         const uint32_t nch = (total + 63) >> 6;
-        // ---- stage: bytes -> 2-bit codes packed big-endian in LDS, bad-base bits ----
-        stage_read<CAP>(bases, o, L, total, do_rc, sb, (uint8_t *)sbad, lane);
         if (lane == 0) sbad[nch] = ~0ull;
         wave_lds_fence();
 #if defined(UTREE_ABLATE) && UTREE_ABLATE == 1
