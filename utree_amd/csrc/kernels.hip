@@ -228,6 +228,8 @@ constexpr uint32_t WORK_GRAB = 32;                   // reads a wave takes per v
 constexpr uint32_t TALLY_CHUNK = UTREE_TALLY_CHUNK;
 constexpr uint32_t TALLY_DIRECT = UTREE_TALLY_CHUNK / 16;   // hit lists this long get their own reservation
 constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read waits for vote_k
+constexpr int32_t RANK_PENDING = -4;                // one distinct label: result.label holds its RANK until vote_k looks up the
+                                                    // label index (a dependent load classify_short_k would otherwise wait for)
 
 // 8 waves/SIMD for the default record format measured 4 % faster than 5 (r01: 325 vs 313 M reads/s) even with a
 // few spilled dwords; the wider formats keep their registers.  (Voting inside this kernel, 64 parked reads per
@@ -345,7 +347,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // ---- tally (itree.c:1028-1040): unique labels with counts, ascending rank = strcmp order ----
         if (F == 0) { if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); continue; }
         const uint32_t h0 = hits[0];
-        if (F == 1) { if (lane == 0) store_result(&out[r], im.rank2ix[h0], -2, 1, 1, 0, 0); continue; }
+        if (F == 1) { if (lane == 0) store_result(&out[r], h0, RANK_PENDING, 1, 1, 0, 0); continue; }
         if (F <= 64) {
             // Up to one hit per lane: peel off distinct labels with readlane + ballot (no LDS shuffles).
             const bool mine = lane < F;
@@ -359,7 +361,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 if (lane == nu) { myv = v; myc = (uint32_t)__popcll(m); }
                 ++nu; left &= ~m;
             }
-            if (nu == 1) { if (lane == 0) store_result(&out[r], im.rank2ix[h0], -2, F, 1, 0, 0); continue; }
+            if (nu == 1) { if (lane == 0) store_result(&out[r], h0, RANK_PENDING, F, 1, 0, 0); continue; }
             if (nu > chunk_left) {
                 unsigned long long nb = 0;
                 if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)TALLY_CHUNK);
@@ -379,7 +381,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         for (uint32_t j = lane; j < F; j += 64) { uint32_t h = hits[j]; mn = h < mn ? h : mn; mx = h > mx ? h : mx; }
         mn = wave_min_u32(mn);
         mx = ~wave_min_u32(~mx);
-        if (mn == mx) { if (lane == 0) store_result(&out[r], im.rank2ix[h0], -2, F, 1, 0, 0); continue; }
+        if (mn == mx) { if (lane == 0) store_result(&out[r], h0, RANK_PENDING, F, 1, 0, 0); continue; }
         // (rank,count) list space: every wave sub-allocates from TALLY_CHUNK-entry chunks it reserves with ONE atomic
         // (a per-read atomic on one address serialises the whole chip).  A refill abandons < TALLY_DIRECT entries of
         // the old chunk; reads with more hits than that take their space directly, so the workspace bound
@@ -585,7 +587,12 @@ __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__rest
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const uint32_t *res = (const uint32_t *)&out[r];
-    if ((int32_t)res[1] != CUT_PENDING) return;            // finished by the classify kernel (0 or 1 distinct label)
+    if ((int32_t)res[1] == RANK_PENDING) {                 // one distinct label: only its file-order index is missing
+        uint32_t *o = (uint32_t *)&out[r];
+        o[0] = im.rank2ix[res[0]]; o[1] = (uint32_t)-2;
+        return;
+    }
+    if ((int32_t)res[1] != CUT_PENDING) return;            // finished by the classify kernel (no hit, or classify_long_k)
     const uint32_t F = res[2], uix = res[3];
     const uint64_t *T = ws.tally + ((uint64_t)res[4] | ((uint64_t)res[5] << 32));
     const char *blob = im.label_blob;
