@@ -276,13 +276,101 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     const uint32_t n_items = LISTED ? (uint32_t)ws.cursors[UTREE_CUR_MID] : n_reads;
     unsigned long long *work = &ws.cursors[LISTED ? UTREE_CUR_WORK_MID : UTREE_CUR_WORK];
     (void)wave_gid; (void)n_waves;
-    // A read's bytes are requested one read ahead (fetch_raw, into LDS): while this read's windows wait for their table
-    // lines, the next read's bytes are already on their way.  The pipeline restarts at every grab.
+    // Software pipeline over the reads of a grab.  A read's bytes are requested one read ahead (fetch_raw, into LDS) and
+    // become its packed form (stage_read) right after the PREVIOUS read's window lookups, before that read's tally and
+    // stores: at that point every load of the wave has been waited for anyway, so the bytes are there without a further
+    // wait -- in particular without waiting for the previous read's stores to be acknowledged.  The pipeline restarts at
+    // every grab.
     auto stageable = [&](uint32_t len_) { const uint64_t t = do_rc ? 2 * (uint64_t)len_ + 1 : len_; return t <= (uint64_t)CAP && t >= K; };
+    auto stage = [&](uint64_t o_, uint32_t L_) {           // raw bytes -> 2-bit codes packed big-endian in LDS, bad-base bits
+        const uint32_t total_ = do_rc ? 2 * L_ + 1 : L_;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_lds_fence();
+        stage_read<CAP>(raw, (uint32_t)o_ & 3u, L_, total_, do_rc, sb, (uint8_t *)sbad, lane);
+        if (lane == 0) sbad[(total_ + 63) >> 6] = ~0ull;
+        wave_lds_fence();
+    };
+    // ---- tally (itree.c:1028-1040) of a read with F hits in hits[]: unique labels with counts, ascending rank = strcmp order ----
+    auto finish = [&](uint32_t r, uint32_t F) {
+            if (F == 0) { if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); return; }
+            const uint32_t h0 = hits[0];
+            if (F == 1) { if (lane == 0) store_result(&out[r], h0, RANK_PENDING, 1, 1, 0, 0); return; }
+            if (F <= 64) {
+                // Up to one hit per lane: peel off distinct labels with readlane + ballot (no LDS shuffles).
+                const bool mine = lane < F;
+                const uint32_t hv = mine ? hits[lane] : 0u;
+                uint64_t left = __ballot(mine);
+                uint32_t nu = 0, myv = 0, myc = 0;                   // lane u keeps distinct label u and its count
+                while (left) {
+                    const uint32_t lead = (uint32_t)__builtin_ctzll(left);
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)hv, (int)lead);
+                    const uint64_t m = __ballot(mine && hv == v) & left;
+                    if (lane == nu) { myv = v; myc = (uint32_t)__popcll(m); }
+                    ++nu; left &= ~m;
+                }
+                if (nu == 1) { if (lane == 0) store_result(&out[r], h0, RANK_PENDING, F, 1, 0, 0); return; }
+                if (nu > chunk_left) {
+                    unsigned long long nb = 0;
+                    if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)TALLY_CHUNK);
+                    chunk_base = uni64(nb);
+                    chunk_left = TALLY_CHUNK;
+                }
+                // ascending rank = strcmp order (itree.c:1041): lane u's place = distinct labels smaller than its own
+                uint32_t place = 0;
+                for (uint32_t u = 0; u < nu; ++u) place += (uint32_t)__builtin_amdgcn_readlane((int)myv, (int)u) < myv;
+                if (lane < nu) ws.tally[chunk_base + place] = (uint64_t)myv | ((uint64_t)myc << 32);
+                if (lane == 0) store_result(&out[r], 0, CUT_PENDING, F, nu, (uint32_t)chunk_base, (uint32_t)(chunk_base >> 32));
+                chunk_base += nu; chunk_left -= nu;
+                return;
+            }
+            // many hits (long or densely covered reads): distinct labels by repeated wave-min over the LDS list
+            uint32_t mn = INVALID, mx = 0;
+            for (uint32_t j = lane; j < F; j += 64) { uint32_t h = hits[j]; mn = h < mn ? h : mn; mx = h > mx ? h : mx; }
+            mn = wave_min_u32(mn);
+            mx = ~wave_min_u32(~mx);
+            if (mn == mx) { if (lane == 0) store_result(&out[r], h0, RANK_PENDING, F, 1, 0, 0); return; }
+            // (rank,count) list space: every wave sub-allocates from TALLY_CHUNK-entry chunks it reserves with ONE atomic
+            // (a per-read atomic on one address serialises the whole chip).  A refill abandons < TALLY_DIRECT entries of
+            // the old chunk; reads with more hits than that take their space directly, so the workspace bound
+            // windows * 9/8 + waves * TALLY_CHUNK (dev_image.c) always holds.
+            unsigned long long base;
+            const bool direct = F >= TALLY_DIRECT;
+            if (direct) {
+                unsigned long long nb = 0;
+                if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)F);
+                base = uni64(nb);
+            } else {
+                if (F > chunk_left) {
+                    unsigned long long nb = 0;
+                    if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)TALLY_CHUNK);
+                    chunk_base = uni64(nb);
+                    chunk_left = TALLY_CHUNK;
+                }
+                base = chunk_base;
+            }
+            uint32_t uix = 0, cur = mn;
+            for (;;) {
+                uint32_t c = 0, nxt = INVALID;
+                for (uint32_t j = lane; j < F; j += 64) {
+                    uint32_t h = hits[j];
+                    c += h == cur;
+                    if (h > cur && h < nxt) nxt = h;
+                }
+                c = wave_sum_u32(c);
+                nxt = wave_min_u32(nxt);
+                if (lane == 0) ws.tally[base + uix] = (uint64_t)cur | ((uint64_t)c << 32);
+                ++uix;
+                if (nxt == INVALID) break;
+                cur = nxt;
+            }
+            if (!direct) { chunk_base += uix; chunk_left -= uix; }
+            // vote_k finishes this read: cut = CUT_PENDING marks it, sl/ol carry the tally offset
+            if (lane == 0) store_result(&out[r], 0, CUT_PENDING, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
+    };
     uint32_t item = 0, item_end = 0;
-    bool primed = false;
-    uint32_t L_next = 0;
-    uint64_t o_next = 0;
+    bool ahead = false;                                    // the current read's parameters are known and, if stageable, it is staged
+    uint32_t r = 0, L = 0;
+    uint64_t o = 0;
     for (;;) {
         if (item == item_end) {
             unsigned long long g = 0;
@@ -290,135 +378,43 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             item = uni32((uint32_t)g);
             if (item >= n_items) break;
             item_end = item + WORK_GRAB < n_items ? item + WORK_GRAB : n_items;
-            primed = false;
+            ahead = false;
         }
-        const uint32_t cur_item = item++;
-        const uint32_t r = LISTED ? uni32(ws.mid_list[cur_item]) : cur_item;
-        uint32_t L; uint64_t o;
-        if (primed) { L = L_next; o = o_next; }
-        else {
+        if (!ahead) {
+            r = LISTED ? uni32(ws.mid_list[item]) : item;
             L = uni32(len[r]); o = uni64(off[r]);
-            if (stageable(L)) fetch_raw<CAP>(bases, o, L, raw, lane);
+            if (stageable(L)) { fetch_raw<CAP>(bases, o, L, raw, lane); stage(o, L); }
         }
-        primed = PREFETCH && item < item_end;
-        if (primed) {
-            const uint32_t rn = LISTED ? uni32(ws.mid_list[item]) : item;
-            L_next = uni32(len[rn]); o_next = uni64(off[rn]);
+        ++item;
+        ahead = PREFETCH && item < item_end;
+        uint32_t r_next = 0, L_next = 0;
+        uint64_t o_next = 0;
+        bool stage_next = false;
+        if (ahead) {
+            r_next = LISTED ? uni32(ws.mid_list[item]) : item;
+            L_next = uni32(len[r_next]); o_next = uni64(off[r_next]);
+            stage_next = stageable(L_next);
+            if (stage_next) fetch_raw<CAP>(bases, o_next, L_next, raw, lane);     // the raw buffer is free: this read is staged
         }
         const uint64_t total64 = do_rc ? 2 * (uint64_t)L + 1 : L;
-        const uint32_t total = (uint32_t)total64;
-        const bool staged = stageable(L);
-        if (staged) {
-            // ---- stage: raw bytes -> 2-bit codes packed big-endian in LDS, bad-base bits ----
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            wave_lds_fence();
-            stage_read<CAP>(raw, (uint32_t)o & 3u, L, total, do_rc, sb, (uint8_t *)sbad, lane);
-            wave_lds_fence();
-        }
-        if (primed && stageable(L_next)) fetch_raw<CAP>(bases, o_next, L_next, raw, lane);   // the raw buffer is free again
-        if (total64 > (uint64_t)CAP) {                     // route_k listed it for the mid-length pass or classify_long_k
-            continue;
-        }
-        if (total < K) {                                   // no window: no hit, no output line
-            if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0);
-            continue;
-        }
-        const uint32_t nwin = total - K + 1;
-        const uint32_t nch = (total + 63) >> 6;
-        if (lane == 0) sbad[nch] = ~0ull;
-        wave_lds_fence();
-#if defined(UTREE_ABLATE) && UTREE_ABLATE == 1
-        if (lane == 0) store_result(&out[r], sw[lane], -2, 0, 0, 0, 0);
-        continue;
-#endif
-        // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933); two rounds of table loads in flight ----
-        uint32_t F = 0;
-        wave_scan_windows<W, I, EXC, OFF>(im, sw, sbad, Kk, 0u, nwin, (uint32_t)CAP, s_regions, lane, [&](uint32_t rank) {
-            const bool hit = rank != INVALID;
-            const uint64_t hm = __ballot(hit);
-            if (hit) hits[F + lanes_below(hm)] = (HIT)rank;
-            F += (uint32_t)__popcll(hm);
-        });
-        wave_lds_fence();
-#if defined(UTREE_ABLATE) && UTREE_ABLATE == 3
-        if (lane == 0) store_result(&out[r], hits[0], -2, F, 0, 0, 0);
-        continue;
-#endif
-        // ---- tally (itree.c:1028-1040): unique labels with counts, ascending rank = strcmp order ----
-        if (F == 0) { if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); continue; }
-        const uint32_t h0 = hits[0];
-        if (F == 1) { if (lane == 0) store_result(&out[r], h0, RANK_PENDING, 1, 1, 0, 0); continue; }
-        if (F <= 64) {
-            // Up to one hit per lane: peel off distinct labels with readlane + ballot (no LDS shuffles).
-            const bool mine = lane < F;
-            const uint32_t hv = mine ? hits[lane] : 0u;
-            uint64_t left = __ballot(mine);
-            uint32_t nu = 0, myv = 0, myc = 0;                   // lane u keeps distinct label u and its count
-            while (left) {
-                const uint32_t lead = (uint32_t)__builtin_ctzll(left);
-                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)hv, (int)lead);
-                const uint64_t m = __ballot(mine && hv == v) & left;
-                if (lane == nu) { myv = v; myc = (uint32_t)__popcll(m); }
-                ++nu; left &= ~m;
+        // total64 > CAP: route_k listed it for the mid-length pass or classify_long_k, nothing to do here
+        if (total64 <= (uint64_t)CAP) {
+            const uint32_t total = (uint32_t)total64;
+            uint32_t F = 0;
+            if (total >= K) {
+                // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933) ----
+                wave_scan_windows<W, I, EXC, OFF>(im, sw, sbad, Kk, 0u, total - K + 1, (uint32_t)CAP, s_regions, lane, [&](uint32_t rank) {
+                    const bool hit = rank != INVALID;
+                    const uint64_t hm = __ballot(hit);
+                    if (hit) hits[F + lanes_below(hm)] = (HIT)rank;
+                    F += (uint32_t)__popcll(hm);
+                });
+                wave_lds_fence();
             }
-            if (nu == 1) { if (lane == 0) store_result(&out[r], h0, RANK_PENDING, F, 1, 0, 0); continue; }
-            if (nu > chunk_left) {
-                unsigned long long nb = 0;
-                if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)TALLY_CHUNK);
-                chunk_base = uni64(nb);
-                chunk_left = TALLY_CHUNK;
-            }
-            // ascending rank = strcmp order (itree.c:1041): lane u's place = distinct labels smaller than its own
-            uint32_t place = 0;
-            for (uint32_t u = 0; u < nu; ++u) place += (uint32_t)__builtin_amdgcn_readlane((int)myv, (int)u) < myv;
-            if (lane < nu) ws.tally[chunk_base + place] = (uint64_t)myv | ((uint64_t)myc << 32);
-            if (lane == 0) store_result(&out[r], 0, CUT_PENDING, F, nu, (uint32_t)chunk_base, (uint32_t)(chunk_base >> 32));
-            chunk_base += nu; chunk_left -= nu;
-            continue;
-        }
-        // many hits (long or densely covered reads): distinct labels by repeated wave-min over the LDS list
-        uint32_t mn = INVALID, mx = 0;
-        for (uint32_t j = lane; j < F; j += 64) { uint32_t h = hits[j]; mn = h < mn ? h : mn; mx = h > mx ? h : mx; }
-        mn = wave_min_u32(mn);
-        mx = ~wave_min_u32(~mx);
-        if (mn == mx) { if (lane == 0) store_result(&out[r], h0, RANK_PENDING, F, 1, 0, 0); continue; }
-        // (rank,count) list space: every wave sub-allocates from TALLY_CHUNK-entry chunks it reserves with ONE atomic
-        // (a per-read atomic on one address serialises the whole chip).  A refill abandons < TALLY_DIRECT entries of
-        // the old chunk; reads with more hits than that take their space directly, so the workspace bound
-        // windows * 9/8 + waves * TALLY_CHUNK (dev_image.c) always holds.
-        unsigned long long base;
-        const bool direct = F >= TALLY_DIRECT;
-        if (direct) {
-            unsigned long long nb = 0;
-            if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)F);
-            base = uni64(nb);
-        } else {
-            if (F > chunk_left) {
-                unsigned long long nb = 0;
-                if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)TALLY_CHUNK);
-                chunk_base = uni64(nb);
-                chunk_left = TALLY_CHUNK;
-            }
-            base = chunk_base;
-        }
-        uint32_t uix = 0, cur = mn;
-        for (;;) {
-            uint32_t c = 0, nxt = INVALID;
-            for (uint32_t j = lane; j < F; j += 64) {
-                uint32_t h = hits[j];
-                c += h == cur;
-                if (h > cur && h < nxt) nxt = h;
-            }
-            c = wave_sum_u32(c);
-            nxt = wave_min_u32(nxt);
-            if (lane == 0) ws.tally[base + uix] = (uint64_t)cur | ((uint64_t)c << 32);
-            ++uix;
-            if (nxt == INVALID) break;
-            cur = nxt;
-        }
-        if (!direct) { chunk_base += uix; chunk_left -= uix; }
-        // vote_k finishes this read: cut = CUT_PENDING marks it, sl/ol carry the tally offset
-        if (lane == 0) store_result(&out[r], 0, CUT_PENDING, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
+            if (stage_next) stage(o_next, L_next);          // sw / sbad now belong to the next read; hits[] to this one
+            finish(r, F);                                  // F == 0 (no window: no hit, no output line) included
+        } else if (stage_next) stage(o_next, L_next);
+        r = r_next; L = L_next; o = o_next;
     }
 }
 
