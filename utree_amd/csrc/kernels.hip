@@ -563,11 +563,11 @@ __device__ __forceinline__ uint32_t cut_of(uint32_t x) {          // itree.c:104
     return c;
 }
 
-// bytes 0..7 of a label at byte offset p (labels are NUL-terminated inside a zero-padded blob)
-__device__ __forceinline__ uint64_t label8(const char *s, uint32_t p) {
-    uint64_t x;
-    __builtin_memcpy(&x, s + p, 8);
-    return x;
+// bytes p .. p+15 of a label with ONE 16-byte request (labels are byte strings: the load is unaligned)
+__device__ __forceinline__ void label16(const char *s, uint32_t p, uint64_t &x, uint64_t &y) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2), aligned(1)));
+    const u64x2 v = *(const u64x2 *)(s + p);
+    x = v.x; y = v.y;
 }
 
 // exact per-byte flags (0x80 in the byte): x1 byte == 0, x1 byte == ';', or x1 and x2 bytes differ; the lowest set flag is
@@ -604,13 +604,15 @@ __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__rest
         const uint32_t probe = dv + (dv == 0xFFFFFFFFu);                      // 0 while nothing is agreed, else dv
         const bool skip0 = dv != 0xFFFFFFFFu;                                // then byte `probe` itself is not compared
         // bytes probe..probe+15 of the entry before z: they were this entry's (x2, y2) one step earlier, so they are kept
-        uint64_t x1_first = label8(s1, probe), y1_first = label8(s1, probe + 8);
+        uint64_t x1_first, y1_first;
+        label16(s1, probe, x1_first, y1_first);
         for (uint32_t z = st + 1; z < ed; ++z) {
             const uint64_t tz = T[z];
             const uint32_t nz = (uint32_t)(tz >> 32);
             const char *s2 = blob + loff[(uint32_t)tz];
             uint64_t x1 = x1_first, y1 = y1_first;
-            const uint64_t x2_first = label8(s2, probe), y2_first = label8(s2, probe + 8);
+            uint64_t x2_first, y2_first;
+            label16(s2, probe, x2_first, y2_first);
             bool aside = false, stop = false;
             if (!(x1 & 0xFFull)) aside = true;                                // previous label exhausted: itree.c:1052
             else {
@@ -630,8 +632,7 @@ __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__rest
                     if (m) { idx = (uint32_t)(__builtin_ctzll(m) >> 3); break; }
                     prevlast = (uint32_t)(x1 >> 56);
                     base += 8;
-                    x1 = label8(s1, base); x2 = label8(s2, base);
-                    y1 = label8(s1, base + 8); y2 = label8(s2, base + 8);
+                    label16(s1, base, x1, y1); label16(s2, base, x2, y2);
                 }
                 td = base + idx;
                 const uint32_t a = (uint32_t)(x1 >> (8 * idx)) & 0xFFu, b = (uint32_t)(x2 >> (8 * idx)) & 0xFFu;
