@@ -175,6 +175,27 @@ def test_result_records_match_oracle_records(torch_cuda):
         assert np.array_equal(got[multi, 4], want["sl"][multi]) and np.array_equal(got[multi, 5], want["ol"][multi])
 
 
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_unaligned_caller_buffer(torch_cuda, shift):
+    """The kernels fetch aligned dwords around the read's bytes: a bases pointer at any byte offset of an allocation, with
+    the first read at the allocation's first byte and the last read ending at its last byte, gives the same records."""
+    torch = torch_cuda
+    db, tree = tree_for("toy")
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    fr = frame_fasta(data)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    lo, hi = int(fr["seq_off"][0]), int(fr["seq_off"][-1] + fr["seq_len"][-1])
+    off = torch.from_numpy((fr["seq_off"] - lo).astype(np.int64)).cuda()
+    ln = torch.from_numpy(fr["seq_len"].astype(np.int32)).cuda()
+    for rc in (False, True):
+        base = torch.from_numpy(buf[lo:hi].copy()).cuda()
+        want = tree.classify(base, off, ln, rc=rc).cpu().numpy()
+        big = torch.zeros(shift + hi - lo, dtype=torch.uint8, device="cuda")
+        big[shift:] = base
+        got = tree.classify(big[shift:], off, ln, rc=rc).cpu().numpy()
+        assert np.array_equal(got, want)
+
+
 def test_edge_case_files_through_search_file(torch_cuda, tmp_path):
     """Whole-file path (framing, sharding, formatting, exit conditions) on the parser edge cases."""
     cases = json.load(open(os.path.join(util.GOLD, "edge_cases.json")))

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void route_k(const uint32_t *__restrict__ len,
 //
 // fetch_raw copies the ALIGNED dwords that hold the read (a dword is only touched when it holds at least one byte of the
 // read, so no load leaves the caller's buffer): raw[1 + d] = dword d, source byte s is raw byte 4 + mf + s with
-// mf = address & 3; raw[0] is a dummy so that the reverse strand's last group may reach "before" the read.
+// mf = (address of the read's first byte) & 3; raw[0] is a dummy so that the reverse strand's last group may reach "before" the read.
 // stage_read: a lane owns the staged bases 4g..4g+3; its four unaligned source bytes come from two raw dwords through
 // v_alignbyte.  Coding is byte-parallel: (b >> 1) & 3 maps A C T G (either case) to 0 1 2 3 and everything else
 // somewhere; v_perm turns that back into the letter it stands for, and a base is bad when that is not the (upper-cased)
@@ -161,9 +161,9 @@ __device__ __forceinline__ uint32_t low_bytes(uint32_t n) {            // 0xFF i
 
 template <int CAP>
 __device__ __forceinline__ void fetch_raw(const uint8_t *__restrict__ bases, uint64_t o, uint32_t L, uint32_t *raw, uint32_t lane) {
-    const uint32_t mf = (uint32_t)o & 3u;
+    const uint32_t mf = (uint32_t)(uintptr_t)(bases + o) & 3u;         // the caller's buffer itself need not be aligned
     const uint32_t nd = (L + mf + 3u) >> 2;                            // <= CAP/4 + 1
-    const uint8_t *p = bases + (o - mf);
+    const uint8_t *p = bases + o - mf;
     for (uint32_t d0 = 0; d0 < nd; d0 += 64) {
         const uint32_t d = d0 + lane;
         if (d < nd) {
@@ -286,7 +286,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         const uint32_t total_ = do_rc ? 2 * L_ + 1 : L_;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_fence();
-        stage_read<CAP>(raw, (uint32_t)o_ & 3u, L_, total_, do_rc, sb, (uint8_t *)sbad, lane);
+        stage_read<CAP>(raw, (uint32_t)(uintptr_t)(bases + o_) & 3u, L_, total_, do_rc, sb, (uint8_t *)sbad, lane);
         if (lane == 0) sbad[(total_ + 63) >> 6] = ~0ull;
         wave_lds_fence();
     };
