@@ -401,7 +401,8 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         if (total64 <= (uint64_t)CAP) {
             const uint32_t total = (uint32_t)total64;
             uint32_t F = 0;
-            if (total >= K) {
+#if !(defined(UTREE_ABLATE) && UTREE_ABLATE == 1)            /* ablation builds (profiles/run_pmc_variants.sh): 1 = staging only, */
+            if (total >= K) {                                      /* 2 = + sliding minimizers, 3 = + window lookups, no tally        */
                 // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933) ----
                 wave_scan_windows<W, I, EXC, OFF>(im, sw, sbad, Kk, 0u, total - K + 1, (uint32_t)CAP, s_regions, lane, [&](uint32_t rank) {
                     const bool hit = rank != INVALID;
@@ -411,8 +412,13 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 });
                 wave_lds_fence();
             }
+#endif
             if (stage_next) stage(o_next, L_next);          // sw / sbad now belong to the next read; hits[] to this one
+#if defined(UTREE_ABLATE)
+            if (lane == 0) store_result(&out[r], sw[0] + hits[0], -2, F, 0, 0, 0);
+#else
             finish(r, F);                                  // F == 0 (no window: no hit, no output line) included
+#endif
         } else if (stage_next) stage(o_next, L_next);
         r = r_next; L = L_next; o = o_next;
     }
