@@ -417,7 +417,7 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
                   utk_workspace *w, size_t *bytes) {
     uint64_t off = 0;
     char *b = (char *)ws;
-    w->cursors = (unsigned long long *)(b + off); off = align_up(off + 512, 256);
+    w->cursors = (unsigned long long *)(b + off); off = align_up(off + UTREE_CURSOR_BYTES, 256);
     /* every wave wastes < one read's windows per chunk refill and may leave one chunk part-used */
     w->tally_cap = ((do_rc ? 2 : 1) * total_bases + (uint64_t)n_reads) * 9 / 8 + (uint64_t)d->n_cu * 32 * UTREE_TALLY_CHUNK + 4096;
     w->tally = (uint64_t *)(b + off); off = align_up(off + w->tally_cap * 8, 256);
@@ -457,7 +457,7 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     carve(d, d_workspace, n_reads, total_bases, max_len, do_rc, &w, &need);
     if (workspace_bytes < need) return UTREE_E_ARG;
     HIPCHK(hipSetDevice(d->device));
-    HIPCHK(hipMemsetAsync(w.cursors, 0, 512, st));
+    HIPCHK(hipMemsetAsync(w.cursors, 0, UTREE_CURSOR_BYTES, st));
     if (w.long_blocks) {
         HIPCHK(hipMemsetAsync(w.hist, 0, (size_t)w.long_blocks * d->hdr.n_labels * 4, st));
         HIPCHK(hipMemsetAsync(w.touch, 0, (size_t)w.long_blocks * ((d->hdr.n_labels + 31) / 32) * 4, st));

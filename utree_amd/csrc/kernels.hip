@@ -224,7 +224,10 @@ constexpr int SHORT_CAP = UTREE_SHORT_CAP;          // 150 bp + reverse strand f
 constexpr int SHORT2_CAP = UTREE_SHORT2_CAP;        // 300 bp + reverse strand fits (used when a batch's longest read needs it)
 constexpr int MID_CAP = UTREE_MID_CAP;              // 1 kb + reverse strand fits; longer reads take classify_long_k
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr uint32_t WORK_GRAB = 32;                   // reads a wave takes per visit to the work counter (64: +3 %, 128: +7 % time)
+#ifndef UTREE_WORK_GRAB
+#define UTREE_WORK_GRAB 32
+#endif
+constexpr uint32_t WORK_GRAB = UTREE_WORK_GRAB;                   // reads a wave takes per visit to a work counter (16: +0.3 %, 64: +2 %, 128: +7 % time)
 constexpr uint32_t TALLY_CHUNK = UTREE_TALLY_CHUNK;
 constexpr uint32_t TALLY_DIRECT = UTREE_TALLY_CHUNK / 16;   // hit lists this long get their own reservation
 constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read waits for vote_k
@@ -274,8 +277,11 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     // Reads are handed out dynamically, WORK_GRAB at a time per wave (one atomic per grab): the grid need not match
     // the kernel's residency and long and short reads balance out.
     const uint32_t n_items = LISTED ? (uint32_t)ws.cursors[UTREE_CUR_MID] : n_reads;
-    unsigned long long *work = &ws.cursors[LISTED ? UTREE_CUR_WORK_MID : UTREE_CUR_WORK];
-    (void)wave_gid; (void)n_waves;
+    // work counters: one per contiguous part of the items (utree_internal.h); this wave starts at its own part
+    unsigned long long *parts = ws.cursors + 64 + (LISTED ? UTREE_WORK_PARTS * UTREE_WORK_STRIDE : 0);
+    const uint32_t part_len = ((n_items + UTREE_WORK_PARTS - 1) / UTREE_WORK_PARTS + WORK_GRAB - 1) / WORK_GRAB * WORK_GRAB;
+    uint32_t part = wave_gid % UTREE_WORK_PARTS, parts_left = UTREE_WORK_PARTS;
+    (void)n_waves;
     // Software pipeline over the reads of a grab.  A read's bytes are requested one read ahead (fetch_raw, into LDS) and
     // become its packed form (stage_read) right after the PREVIOUS read's window lookups, before that read's tally and
     // stores: at that point every load of the wave has been waited for anyway, so the bytes are there without a further
@@ -373,11 +379,26 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     uint64_t o = 0;
     for (;;) {
         if (item == item_end) {
-            unsigned long long g = 0;
-            if (lane == 0) g = atomicAdd(work, (unsigned long long)WORK_GRAB);
-            item = uni32((uint32_t)g);
-            if (item >= n_items) break;
-            item_end = item + WORK_GRAB < n_items ? item + WORK_GRAB : n_items;
+            // next grab: from this wave's current part; a part that is used up (a plain load tells, no atomic) is left for good
+            bool got = false;
+            while (parts_left) {
+                unsigned long long *ctr = parts + part * UTREE_WORK_STRIDE;
+                const uint64_t lo = (uint64_t)part * part_len;
+                const uint32_t avail = lo >= n_items ? 0u : (uint32_t)(n_items - lo < part_len ? n_items - lo : part_len);
+                unsigned long long g = ~0ull;
+                if (lane == 0 && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < avail)
+                    g = atomicAdd(ctr, (unsigned long long)WORK_GRAB);
+                const uint32_t taken = uni32((uint32_t)(g > 0xFFFFFFFFull ? 0xFFFFFFFFull : g));
+                if (taken < avail) {
+                    item = (uint32_t)lo + taken;
+                    item_end = taken + WORK_GRAB < avail ? item + WORK_GRAB : (uint32_t)lo + avail;
+                    got = true;
+                    break;
+                }
+                part = part + 1 == UTREE_WORK_PARTS ? 0 : part + 1;
+                --parts_left;
+            }
+            if (!got) break;
             ahead = false;
         }
         if (!ahead) {

@@ -19,6 +19,12 @@ extern "C" {
 #define UTREE_CUR_WORK 48                        /* ... of the next unclaimed read (150-bp-class pass)           */
 #define UTREE_CUR_WORK_LONG 40                   /* ... of the next unclaimed long-list entry                    */
 #define UTREE_CUR_WORK_MID 56                    /* ... of the next unclaimed mid-list entry                     */
+/* The reads of the wave-per-read passes are handed out from UTREE_WORK_PARTS counters, each on its own 128-byte line, one
+ * per contiguous part of the batch: 8192 resident waves on ONE counter queue up at its L2 channel (a grab of 32 reads then
+ * costs a wave ~14 us, measured); a wave starts at part (its index mod PARTS) and moves on when a part is used up. */
+#define UTREE_WORK_PARTS 64
+#define UTREE_WORK_STRIDE 16                     /* 8-byte words between two counters                            */
+#define UTREE_CURSOR_BYTES (512 + 2 * UTREE_WORK_PARTS * UTREE_WORK_STRIDE * 8)   /* cursors[] + part counters (main, mid) */
 #define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds      */
 #define UTREE_SHORT2_CAP 640u                    /* ... its second size: 250-300 bp reads with the reverse strand */
 #define UTREE_MID_DEFAULT 1536u                  /* measured cross-over to classify_long_k on hit-dense reads (UTREE_MID_LIMIT overrides) */
@@ -80,7 +86,8 @@ int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream);
 
 /* workspace layout for one batch */
 typedef struct {
-    unsigned long long *cursors;     /* [0] tally bump, [UTREE_CUR_LONG] long-read count; 512 B, zeroed per batch */
+    unsigned long long *cursors;     /* [0] tally bump, [UTREE_CUR_LONG] long-read count; then the work-part counters:
+                                      * UTREE_CURSOR_BYTES, zeroed per batch */
     uint64_t *tally;                 /* (rank, count) pairs packed as rank | count<<32                        */
     uint64_t tally_cap;
     uint32_t *long_list;             /* [n_reads]                                                             */
