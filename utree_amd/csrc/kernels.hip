@@ -4,13 +4,13 @@
 // its algorithmic bytes and the HBM layout are in DESIGN.md; the reference behaviour each kernel
 // reproduces is cited as itree.c:line.
 //
-//   repack_k        on-disk SZ-byte records -> 8-byte-aligned {suffix,rank} records   (load time)
-//   validate_k      per-bin ascending check, irregular-bin bitmap                      (load time)
-//   build_fine_k    24+F-bit prefix index by lower_bound inside each 24-bit bin        (load time)
-//   classify_short  one wavefront per read: stage through LDS, roll k-mers, look up, tally
+//   route_k         lists the reads the main pass cannot hold (mid-length pass / classify_long_k)
+//   classify_short  one wavefront per read, software-pipelined over a grab of reads: raw bytes -> LDS (LDS-DMA, one
+//                   read ahead), 2-bit staging, sliding minimizers, bucket lookups, tally of distinct labels
 //   classify_long   one workgroup per read for reads that do not fit a wavefront's LDS slice
 //   vote_k          one lane per read: rank-wise LCA descent on the sorted unique label list
 //   lookup_k        XT_getIX32 alone (tests, micro-benchmarks)
+// (the load-time kernels that build the device image live in image_build.hip)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "device_common.hpp"
@@ -447,7 +447,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 
 // ------------------------------------------------------------------------------------------------
 // classify_long: one workgroup per read, any length (itree.c:836: lines up to 16 MiB).  The read is walked in
-// tiles staged through LDS (two table slots in flight per lane); hits go to a per-workgroup label histogram in
+// tiles staged through LDS (one bucket in flight per lane); hits go to a per-workgroup label histogram in
 // HBM and set a bit in a touched-label bitmap; the bitmap is then swept in rank order, which yields the same
 // sorted (rank,count) list the wave kernel emits, and only touched histogram entries are read and cleared.
 // ------------------------------------------------------------------------------------------------
