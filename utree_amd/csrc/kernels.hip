@@ -624,6 +624,35 @@ __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__rest
     uint32_t st = 0, ed = uix, dv = 0xFFFFFFFFu, orun = F, sl, ol;
     for (;;) {
         const uint64_t t_st = T[st];
+        {
+            // Levels at which every label of the group [st, ed) carries the same token change nothing but dv (each pair
+            // stops at the token's ';' with equal bytes: run ends up as orun, st / ed / cutoff stay): dv moves to that
+            // ';'.  The list is in strcmp order, so a prefix the group's first and last label share is shared by all of
+            // them: ONE scan of those two labels finds the last ';' they share beyond dv, instead of a pass over all
+            // pairs per level.  The level that follows is the first one with something to decide.
+            const char *sa = blob + loff[(uint32_t)t_st], *sz = blob + loff[(uint32_t)T[ed - 1]];
+            uint32_t base = dv + (dv == 0xFFFFFFFFu), q = 0xFFFFFFFFu;
+            bool first = dv != 0xFFFFFFFFu;                                   // then byte `base` (= dv) itself does not count
+            for (;;) {
+                uint64_t a[2], b[2];
+                label16(sa, base, a[0], a[1]); label16(sz, base, b[0], b[1]);
+                bool stop = false;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint64_t x = a[h], d = a[h] ^ b[h], sx = a[h] ^ 0x3B3B3B3B3B3B3B3Bull;
+                    uint64_t end = ((x - 0x0101010101010101ull) & ~x) & 0x8080808080808080ull;               // label ends
+                    end |= (((d & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | d) & 0x8080808080808080ull;   // or differs
+                    uint64_t semi = ~(((sx & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | sx) & 0x8080808080808080ull;   // ';'
+                    if (h == 0 && first) { end &= ~0xFFull; semi &= ~0xFFull; }
+                    if (end) semi &= (end & (0ull - end)) - 1ull;             // only those before the first end / difference
+                    if (semi) q = base + 8u * (uint32_t)h + ((63u - (uint32_t)__builtin_clzll(semi)) >> 3);
+                    if (end) { stop = true; break; }
+                }
+                if (stop) break;
+                base += 16; first = false;
+            }
+            if (q != 0xFFFFFFFFu) dv = q;
+        }
         uint32_t run = (uint32_t)(t_st >> 32), td = dv;
         // (s1, c1) = label text and count of the list entry just before z; it moves along with z
         const char *s1 = blob + loff[(uint32_t)t_st];
