@@ -400,3 +400,21 @@ def test_overflowing_buckets(torch_cuda, tmp_path):
         assert code == 0 and good >= len(kmers)
         assert classify_fasta_bytes(db, tree, data, rc=False) == out.read_bytes()
         tree.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_vote_on_adversarial_label_sets(torch_cuda, seed, tmp_path):
+    """vote_k skips the levels a whole group of labels shares with ONE scan of the group's first and last label; this
+    checks it (and the level loop behind it) on label sets built to sit on the vote's edges (util.adversarial_vote_case).
+    Oracle = the CPU restatement, itself held against the genuine reference on the same cases
+    (test_oracle_golden.py::test_vote_adversarial_cases_oracle_vs_reference)."""
+    ctr_path, data, n_reads = util.adversarial_vote_case(seed, str(tmp_path))
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(data)
+    o = orc.OracleDB.load(ctr_path)
+    out = tmp_path / "o.txt"
+    code, nr, good, err = o.search_file(str(fa), str(out), threads=8, rc=False)
+    assert code == 0 and nr == n_reads and good > 0
+    db = CtrDB.open(ctr_path)
+    tree = DeviceTree.upload(db, 0)
+    assert classify_fasta_bytes(db, tree, data, rc=False) == out.read_bytes()

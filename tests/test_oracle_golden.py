@@ -176,3 +176,23 @@ def test_build_matches_reference(tag, tmpdir_mod):
         assert ctrfile.sha256_file(ubt) == v["ubt_sha256"]
         assert ctrfile.sha256_file(ubt + (".gg.log" if v["gg"] else ".log")) == v["log_sha256"]
         assert ("Total nodes in tree: %d [%d labels]" % (nn, nl)) in v["stdout_tail"]
+
+
+@pytest.mark.skipif(not util.have_ref(), reason="needs oracle/_ref (the genuine reference, built from /root/reference by `make -C oracle ref`)")
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_vote_adversarial_cases_oracle_vs_reference(seed, tmp_path):
+    """The label sets the GPU vote is stressed with (util.adversarial_vote_case) go beyond the committed vote fixture, so
+    the oracle is first held against the genuine reference binary on them, where that binary exists."""
+    import subprocess
+    ctr_path, data, n_reads = util.adversarial_vote_case(seed, str(tmp_path))
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(data)
+    want = tmp_path / "ref.txt"
+    r = subprocess.run([os.path.join(util.REF_DIR, "xtree-searchGG"), ctr_path, str(fa), str(want), "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    o = orc.OracleDB.load(ctr_path)
+    got = tmp_path / "orc.txt"
+    code, nr, good, err = o.search_file(str(fa), str(got), threads=4, rc=False)
+    assert code == 0 and nr == n_reads
+    assert got.read_bytes() == want.read_bytes() and good > 1000
