@@ -418,3 +418,21 @@ def test_vote_on_adversarial_label_sets(torch_cuda, seed, tmp_path):
     db = CtrDB.open(ctr_path)
     tree = DeviceTree.upload(db, 0)
     assert classify_fasta_bytes(db, tree, data, rc=False) == out.read_bytes()
+
+
+@pytest.mark.parametrize("name,with_gt", [("toy", False), ("toy", True), ("k64", False), ("ix32", False), ("vote", False)])
+def test_byte_fuzz_vs_oracle(torch_cuda, name, with_gt, tmp_path):
+    """Sequence lines with arbitrary 7-bit bytes (util.byte_fuzz_reads: the staging's byte-parallel base coding must call
+    exactly the reference's eight letters good), both strands, whole-file path: output file and exit code equal the
+    oracle's, which equals the genuine reference's on the same data (test_oracle_golden.py::test_byte_fuzz_oracle_vs_reference)."""
+    data = util.byte_fuzz_reads(name, 21, with_gt)
+    fa = tmp_path / "f.fa"
+    fa.write_bytes(data)
+    db, tree = tree_for(name)
+    o = orc.OracleDB.load(util.fixture_ctr(name))
+    for rc in (False, True):
+        want, got = tmp_path / "orc.txt", tmp_path / "gpu.txt"
+        code, nr, good, err = o.search_file(str(fa), str(want), threads=8, rc=rc)
+        gcode, st = search_gg(db, [tree], str(fa), str(got), rc=rc, threads=2)
+        assert {lib.OK: 0, lib.E_FASTA: 2, lib.E_IO: 1}[gcode] == code
+        assert got.read_bytes() == want.read_bytes()

@@ -195,3 +195,20 @@ def test_rank_bad_parameters_are_refused(torch_cuda):
     for bad in (dict(sparsity=0), dict(sparsity=33)):          # PACKSIZE/SPARSITY must be >= 1 window
         with pytest.raises(lib.UtreeError):
             tree.rank_search(z, off, ln, **bad)
+
+
+def test_rank_search_on_adversarial_label_set(torch_cuda, tmp_path):
+    """The hostile label set of the GG vote test through the rank-specific search: GPU file == oracle file (the oracle is
+    held against the genuine reference on this case in test_oracle_golden.py)."""
+    ctr_path, data, n_reads = util.adversarial_vote_case(2, str(tmp_path))
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(data)
+    want = tmp_path / "w.txt"
+    code, nr, good, err = orc.rank_search_file(orc.OracleDB.load(ctr_path), str(fa), str(want))
+    assert code == 0 and nr == n_reads
+    db = CtrDB.open(ctr_path)
+    tree = DeviceTree.upload(db, 0)
+    out = tmp_path / "g.txt"
+    code, st = search_rank(db, tree, str(fa), str(out), threads=4)
+    assert code == lib.OK and st.n_reads == n_reads
+    assert out.read_bytes() == want.read_bytes()

@@ -196,3 +196,40 @@ def test_vote_adversarial_cases_oracle_vs_reference(seed, tmp_path):
     code, nr, good, err = o.search_file(str(fa), str(got), threads=4, rc=False)
     assert code == 0 and nr == n_reads
     assert got.read_bytes() == want.read_bytes() and good > 1000
+
+
+@pytest.mark.skipif(not util.have_ref(), reason="needs oracle/_ref (the genuine reference, built from /root/reference by `make -C oracle ref`)")
+def test_rank_search_adversarial_case_oracle_vs_reference(tmp_path):
+    """Same hostile label set through the rank-specific search (`xtree-search`): whole output files identical."""
+    import subprocess
+    ctr_path, data, n_reads = util.adversarial_vote_case(2, str(tmp_path))
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(data)
+    want = tmp_path / "ref.txt"
+    r = subprocess.run([os.path.join(util.REF_DIR, "xtree-search"), ctr_path, str(fa), str(want), "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()
+    got = tmp_path / "orc.txt"
+    code, nr, good, err = orc.rank_search_file(orc.OracleDB.load(ctr_path), str(fa), str(got))
+    assert code == 0 and nr == n_reads and good > 100
+    assert got.read_bytes() == want.read_bytes()
+
+
+@pytest.mark.skipif(not util.have_ref(), reason="needs oracle/_ref (the genuine reference, built from /root/reference by `make -C oracle ref`)")
+@pytest.mark.parametrize("name,with_gt", [("toy", False), ("toy", True), ("k64", False), ("ix32", False), ("vote", False)])
+def test_byte_fuzz_oracle_vs_reference(name, with_gt, tmp_path):
+    """Sequence lines with arbitrary 7-bit bytes, both strands: output file AND exit code of the oracle equal the genuine
+    reference's (with '>' allowed, both stop at the same record with the format error)."""
+    import subprocess
+    data = util.byte_fuzz_reads(name, 21, with_gt)
+    fa = tmp_path / "f.fa"
+    fa.write_bytes(data)
+    exe = "xtree-searchGG" + {"k64": "-k64", "ix32": "-ix32"}.get(name, "")
+    o = orc.OracleDB.load(util.fixture_ctr(name))
+    for rc in (False, True):
+        want, got = tmp_path / "ref.txt", tmp_path / "orc.txt"
+        r = subprocess.run([os.path.join(util.REF_DIR, exe), util.fixture_ctr(name), str(fa), str(want), "1"] + (["RC"] if rc else []),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        code, nr, good, err = o.search_file(str(fa), str(got), threads=4, rc=rc)
+        assert code == r.returncode and (code == 2) == with_gt
+        assert got.read_bytes() == want.read_bytes() and good > 10
