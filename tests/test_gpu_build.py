@@ -134,3 +134,22 @@ def test_build_in_kmer_range_passes(tag, limit, tmp_path, monkeypatch):
     assert code == lib.OK
     assert ctrfile.sha256_file(ubt) == v["ubt_sha256"]
     assert ctrfile.sha256_file(ubt + (".gg.log" if v["gg"] else ".log")) == v["log_sha256"]
+
+
+@pytest.mark.parametrize("W,gg", [(8, 1), (8, 0), (16, 1)])
+def test_build_hostile_labels_vs_oracle(W, gg, tmp_path):
+    """Hostile label sets through the GPU BUILD (util.hostile_build_case; the oracle is held against the genuine reference on
+    them in test_oracle_golden.py): `.ubt` and log identical at every compression level."""
+    for seed in (1, 2):
+        fa_b, mp_b = util.hostile_build_case(seed)
+        fa = tmp_path / "i.fa"; mp = tmp_path / "i.map"
+        fa.write_bytes(fa_b); mp.write_bytes(mp_b)
+        for cl in (0, 1, 2):
+            want, got = str(tmp_path / "w.ubt"), str(tmp_path / "g.ubt")
+            code, ns, nn, nl, err = orc.build_file(str(fa), str(mp), want, W=W, I=2, complevel=cl, gg=bool(gg))
+            assert code == 0, err
+            gcode, st = build(str(fa), str(mp), got, W=W, I=2, complevel=cl, gg=bool(gg))
+            assert gcode == lib.OK and (st.n_seqs, st.n_nodes, st.n_labels) == (ns, nn, nl)
+            ext = ".gg.log" if gg else ".log"
+            assert open(got, "rb").read() == open(want, "rb").read()
+            assert open(got + ext, "rb").read() == open(want + ext, "rb").read()

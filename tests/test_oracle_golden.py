@@ -233,3 +233,25 @@ def test_byte_fuzz_oracle_vs_reference(name, with_gt, tmp_path):
         code, nr, good, err = o.search_file(str(fa), str(got), threads=4, rc=rc)
         assert code == r.returncode and (code == 2) == with_gt
         assert got.read_bytes() == want.read_bytes() and good > 10
+
+
+@pytest.mark.skipif(not util.have_ref(), reason="needs oracle/_ref (the genuine reference, built from /root/reference by `make -C oracle ref`)")
+@pytest.mark.parametrize("exe,W,gg", [("utree-buildGG", 8, 1), ("utree-build", 8, 0), ("utree-buildGG-k64", 16, 1)])
+def test_build_hostile_labels_oracle_vs_reference(exe, W, gg, tmp_path):
+    """BUILD / BUILD_GG with hostile labels (util.hostile_build_case): `.ubt` and log of the oracle equal the genuine reference's
+    at every compression level."""
+    import subprocess
+    for seed in (1, 2):
+        fa_b, mp_b = util.hostile_build_case(seed)
+        fa = tmp_path / "i.fa"; mp = tmp_path / "i.map"
+        fa.write_bytes(fa_b); mp.write_bytes(mp_b)
+        for cl in (0, 1, 2):
+            want, got = str(tmp_path / "r.ubt"), str(tmp_path / "o.ubt")
+            r = subprocess.run([os.path.join(util.REF_DIR, exe), str(fa), str(mp), want, "1", str(cl)], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=600)
+            assert r.returncode == 0
+            code, ns, nn, nl, err = orc.build_file(str(fa), str(mp), got, W=W, I=2, complevel=cl, gg=bool(gg))
+            assert code == 0, err
+            ext = ".gg.log" if gg else ".log"
+            assert open(got, "rb").read() == open(want, "rb").read()
+            assert open(got + ext, "rb").read() == open(want + ext, "rb").read()
