@@ -21,7 +21,7 @@ using namespace utk;
 namespace {
 
 
-constexpr uint32_t KEY_TILE = 128;                    // windows per sliding-minimizer tile
+constexpr uint32_t KEY_TILE = 128;                    // windows per sliding-minimizer tile (256 where the LDS budget allows)
 
 // 32 bits (16 bases) of the packed stream starting at base j
 __device__ __forceinline__ uint32_t mmer_at(const uint32_t *sw, uint32_t j) {
@@ -63,13 +63,13 @@ __device__ __forceinline__ void build_minkeys(const uint32_t *sw, uint64_t *Kk, 
 // INVALID for lanes without a hit -- once per 64 windows.  One bucket (64 bytes) is in flight per lane: its records
 // arrive in one round trip, and two buckets in flight would not fit the registers.  `regions` = the image's region
 // table, copied to LDS by the caller.
-template <int W, int I, bool EXC, typename OFF, typename HitFn>
+template <int W, int I, bool EXC, typename OFF, uint32_t TILE = KEY_TILE, typename HitFn>
 __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const uint32_t *sw, const uint64_t *sbad, uint64_t *Kk,
                                                   uint32_t w0, uint32_t n, uint32_t pos_cap, const uint64_t *regions, uint32_t lane,
                                                   HitFn &&on_rank) {
     constexpr uint32_t K = 4 * W;
-    for (uint32_t wb = 0; wb < n; wb += KEY_TILE) {
-        const uint32_t tn = n - wb < KEY_TILE ? n - wb : KEY_TILE;
+    for (uint32_t wb = 0; wb < n; wb += TILE) {
+        const uint32_t tn = n - wb < TILE ? n - wb : TILE;
         build_minkeys<W>(sw, Kk, w0 + wb, tn + K - 16, pos_cap, lane);      // 16-mers of windows w0+wb .. w0+wb+tn-1
 #if defined(UTREE_ABLATE) && UTREE_ABLATE == 2
         continue;
@@ -254,7 +254,9 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     __shared__ uint64_t s_bad[WAVES_PER_BLOCK][NCH + 2];
     using HIT = typename std::conditional<I == 2, uint16_t, uint32_t>::type;     // ranks of u16-label databases fit 16 bits
     __shared__ HIT s_hits[WAVES_PER_BLOCK][CAP];
-    __shared__ uint64_t s_keys[WAVES_PER_BLOCK][KEY_TILE + 128];
+    // a 150 bp read with its reverse strand (270 windows) is two tiles of 256 instead of three of 128
+    constexpr uint32_t TILE = CAP <= SHORT_CAP ? 256u : KEY_TILE;
+    __shared__ uint64_t s_keys[WAVES_PER_BLOCK][TILE + 128];
     __shared__ uint64_t s_regions[256];
     // the mid-length pass has no room for a raw buffer of its own and less to gain: its raw bytes pass through the hit
     // list's space (consumed by stage_read before the first hit is written) and are not requested ahead
@@ -425,7 +427,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 #if !(defined(UTREE_ABLATE) && UTREE_ABLATE == 1)            /* ablation builds (profiles/run_pmc_variants.sh): 1 = staging only, */
             if (total >= K) {                                      /* 2 = + sliding minimizers, 3 = + window lookups, no tally        */
                 // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933) ----
-                wave_scan_windows<W, I, EXC, OFF>(im, sw, sbad, Kk, 0u, total - K + 1, (uint32_t)CAP, s_regions, lane, [&](uint32_t rank) {
+                wave_scan_windows<W, I, EXC, OFF, TILE>(im, sw, sbad, Kk, 0u, total - K + 1, (uint32_t)CAP, s_regions, lane, [&](uint32_t rank) {
                     const bool hit = rank != INVALID;
                     const uint64_t hm = __ballot(hit);
                     if (hit) hits[F + lanes_below(hm)] = (HIT)rank;
