@@ -112,7 +112,7 @@ template <int W, int I> __device__ uint32_t exact_probe(const uint64_t *recs, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// Minimizers.  m = 16 bases (32 bits); the minimizer of a k-mer is its 16-mer with the smallest mix32()
+// Minimizers.  m = 16 bases (32 bits); the minimizer of a k-mer is its 16-mer with the smallest mix32() >> MIN_LOW_BITS
 // (leftmost on ties).  mix32 is a bijection on 32 bits, so a table slot of B <= 32 hash bits plus the
 // remaining 32-B bits identify the minimizer exactly, and {position, the other k-16 bases} the k-mer.
 // ------------------------------------------------------------------------------------------------
@@ -120,6 +120,10 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
+// 16-mers are ordered by their hash WITHOUT its MIN_LOW_BITS low bits (leftmost on ties): the search kernels then fit
+// { hash bits | position in the tile } into 32 bits and slide the minimum with one v_min_u32 per step.  The bucket is still
+// addressed by the chosen 16-mer's full hash.
+constexpr uint32_t MIN_LOW_BITS = 9;
 
 // MIN key: W=8: lo = {hlow8 | pos5 | rest32} (45 bits), hi unused.  W=16: lo = low 64 bits of the 96-bit rest,
 // hi = {hlow8 | pos6 | rest_hi32} (46 bits).
@@ -162,7 +166,7 @@ template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_
 #pragma unroll
         for (uint32_t j = 1; j <= 16; ++j) {
             const uint32_t hh = mix32((uint32_t)(klo >> (32 - 2 * j)));
-            if (hh < best) { best = hh; bj = j; }
+            if ((hh >> MIN_LOW_BITS) < (best >> MIN_LOW_BITS)) { best = hh; bj = j; }
         }
         h = best; pos = bj;
     } else {
@@ -170,7 +174,7 @@ template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_
         uint32_t best = mix32((uint32_t)(w >> 96)), bj = 0;
         for (uint32_t j = 1; j <= 48; ++j) {
             const uint32_t hh = mix32((uint32_t)(w >> (96 - 2 * j)));
-            if (hh < best) { best = hh; bj = j; }
+            if ((hh >> MIN_LOW_BITS) < (best >> MIN_LOW_BITS)) { best = hh; bj = j; }
         }
         h = best; pos = bj;
     }

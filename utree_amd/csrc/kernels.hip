@@ -30,27 +30,31 @@ __device__ __forceinline__ uint32_t mmer_at(const uint32_t *sw, uint32_t j) {
 }
 
 // Sliding minimizers for a tile of windows, shared by the lanes of one wave (each 16-mer is hashed ONCE instead of
-// once per window that contains it).  After the call, for a window starting at position pos0 + t:
-//     min(Kk[t], Kk[t + NEXT])  =  { hash << 32 | absolute position } of its minimizer (leftmost on ties),
-// the same (h, pos) minimizer<W>() computes from the word.  Kk needs (nch + 1) * 64 entries.
+// once per window that contains it).  The order among 16-mers is that of minimizer<W>() (device_common.hpp): the hash
+// without its MIN_LOW_BITS low bits, leftmost on ties -- which makes a 32-bit key { hash bits | position in the tile }
+// enough, and the sliding minimum one v_min_u32 per step.  After the call, for the window that starts at tile position t:
+//     p = min(Kk[t], Kk[t + NEXT]) & MIN_POS_MASK  =  tile position of its minimizer,  Hh[p] = that 16-mer's full hash,
+// the same (h, pos) minimizer<W>() computes from the word.  Kk and Hh need (nch + 1) * 64 entries.
 // In place: step s replaces K[t] by min(K[t], K[t+s]); chunks ascend, so chunk c still sees chunk c+1's old values.
+constexpr uint32_t MIN_POS_MASK = (1u << MIN_LOW_BITS) - 1u;       // a tile has < 2^MIN_LOW_BITS positions
 template <int W> struct MinWin { static constexpr uint32_t NEXT = (W == 16) ? 17u : 1u; };   // [t,t+16)+[t+1,t+17) / [t,t+32)+[t+17,t+49)
 template <int W>
-__device__ __forceinline__ void build_minkeys(const uint32_t *sw, uint64_t *Kk, uint32_t pos0, uint32_t npos, uint32_t pos_cap, uint32_t lane) {
+__device__ __forceinline__ void build_minkeys(const uint32_t *sw, uint32_t *Kk, uint32_t *Hh, uint32_t pos0, uint32_t npos,
+                                              uint32_t pos_cap, uint32_t lane) {
     const uint32_t nch = (npos + 63) >> 6;
     for (uint32_t c = 0; c < nch; ++c) {
-        const uint32_t j = pos0 + c * 64 + lane;
-        uint64_t key = ~0ull;
-        if (j < pos_cap) key = ((uint64_t)mix32(mmer_at(sw, j)) << 32) | j;
-        Kk[c * 64 + lane] = key;
+        const uint32_t t = c * 64 + lane, j = pos0 + t;
+        uint32_t key = ~0u, h = 0;
+        if (j < pos_cap) { h = mix32(mmer_at(sw, j)); key = (h & ~MIN_POS_MASK) | t; }
+        Kk[t] = key; Hh[t] = h;
     }
-    Kk[nch * 64 + lane] = ~0ull;
+    Kk[nch * 64 + lane] = ~0u;
     wave_lds_fence();
 #pragma unroll
     for (uint32_t s = 1; s <= ((W == 16) ? 16u : 8u); s <<= 1) {
         for (uint32_t c = 0; c < nch; ++c) {
             const uint32_t t = c * 64 + lane;
-            const uint64_t a = Kk[t], b = Kk[t + s];
+            const uint32_t a = Kk[t], b = Kk[t + s];
             wave_lds_fence();
             Kk[t] = b < a ? b : a;
             wave_lds_fence();
@@ -68,9 +72,11 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const uin
                                                   uint32_t w0, uint32_t n, uint32_t pos_cap, const uint64_t *regions, uint32_t lane,
                                                   HitFn &&on_rank) {
     constexpr uint32_t K = 4 * W;
+    static_assert(TILE + 64 <= (1u << MIN_LOW_BITS), "tile positions must fit the key's position field");
+    uint32_t *Kp = (uint32_t *)Kk, *Hh = Kp + (TILE + 128);              // the wave's 8 * (TILE + 128) bytes: keys, then hashes
     for (uint32_t wb = 0; wb < n; wb += TILE) {
         const uint32_t tn = n - wb < TILE ? n - wb : TILE;
-        build_minkeys<W>(sw, Kk, w0 + wb, tn + K - 16, pos_cap, lane);      // 16-mers of windows w0+wb .. w0+wb+tn-1
+        build_minkeys<W>(sw, Kp, Hh, w0 + wb, tn + K - 16, pos_cap, lane);  // 16-mers of windows w0+wb .. w0+wb+tn-1
 #if defined(UTREE_ABLATE) && UTREE_ABLATE == 2
         continue;
 #endif
@@ -87,9 +93,9 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const uin
             if (ok) {
                 uint64_t wh, wl, bucket; MinKey<W> mk;
                 window_word<W>(sw, i, wh, wl);
-                const uint64_t ka = Kk[tw], kb = Kk[tw + MinWin<W>::NEXT];
-                const uint64_t km = kb < ka ? kb : ka;
-                min_finish<W>(wh, wl, (uint32_t)(km >> 32), (uint32_t)km - i, regions, bucket, mk);
+                const uint32_t ka = Kp[tw], kb = Kp[tw + MinWin<W>::NEXT];
+                const uint32_t p = (kb < ka ? kb : ka) & MIN_POS_MASK;
+                min_finish<W>(wh, wl, Hh[p], p - tw, regions, bucket, mk);
                 const Bucket<W, I> bk = load_bucket<W, I>(im.table, bucket);
                 rank = resolve_bucket<W, I, EXC, OFF>(im, bk, mk, wh, wl);
             }
