@@ -76,8 +76,8 @@ int utree_ctr_get_info(const utree_ctr *ctr, utree_ctr_info *info);
 const char *utree_ctr_label(const utree_ctr *ctr, uint32_t ix, uint32_t *len);
 
 /* ------------------------------------------------------------------------------------------------
- * Device image: one flat HBM allocation holding the fine prefix index, the 8-byte-aligned records, the
- * labels in strcmp order and the rank tables (layout: DESIGN.md §3).  It replaces UTree.Dump / UTree.BinIx
+ * Device image: one flat HBM allocation holding the table of 64-byte buckets addressed by minimizer hash, the
+ * 8-byte-aligned records, the labels in strcmp order and the rank tables (layout: DESIGN.md §3).  It replaces UTree.Dump / UTree.BinIx
  * (itree.c:140-141) as seen by XT_getIX32.  Because it is flat and position independent, ONE RCCL
  * broadcast replicates a database to the other GPUs of a node.
  * ---------------------------------------------------------------------------------------------- */
@@ -85,8 +85,8 @@ typedef struct utree_dev utree_dev;
 
 #define UTREE_FINE_AUTO (-1)
 
-/* Bytes of HBM the image needs for `ctr` with `fine_bits` extra prefix bits (UTREE_FINE_AUTO: chosen so
- * that a fine bin holds about one record). */
+/* Bytes of HBM the image needs for `ctr`.  `fine_bits` (0..8) bounds the width of a bucket from below, 2^(8-fine_bits)
+ * hash values: UTREE_FINE_AUTO = 8 unless the table would exceed UTREE_TABLE_MAX_GB (then the largest value that fits). */
 size_t utree_dev_image_bytes(const utree_ctr *ctr, int fine_bits);
 /* Stream the node dump (from the .ctr file or the host copy given to utree_ctr_from_memory) to `device`
  * and build the image there. */
