@@ -240,8 +240,8 @@ constexpr int32_t CUT_PENDING = -3;                 // result.cut while a read w
 constexpr int32_t RANK_PENDING = -4;                // one distinct label: result.label holds its RANK until vote_k looks up the
                                                     // label index (a dependent load classify_short_k would otherwise wait for)
 
-// 8 waves/SIMD for the default record format measured 4 % faster than 5 (r01: 325 vs 313 M reads/s) even with a
-// few spilled dwords; the wider formats keep their registers.  (Voting inside this kernel, 64 parked reads per
+// 8 waves/SIMD for u16-label databases measured faster than 5 even with a few spilled dwords (k = 32: +4 % in r01;
+// k = 64: 932 -> 1020 M reads/s, same-box); with u32 labels the hit list's LDS caps the occupancy at 5-6 anyway.  (Voting inside this kernel, 64 parked reads per
 // wave, was tried and measured slower at every occupancy: 295-331 vs 343 M reads/s with the separate vote_k.)
 // CAP = staged bases a wavefront's LDS slice holds.  CAP = SHORT_CAP walks all reads of the batch and routes the
 // longer ones to the mid / long lists; CAP = MID_CAP (LISTED) walks the mid list.  Its 37 KB of LDS per
@@ -250,7 +250,7 @@ template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED>
 #ifndef UTREE_SHORT_MIN_WAVES
 #define UTREE_SHORT_MIN_WAVES 8
 #endif
-__global__ __launch_bounds__(256, CAP > SHORT2_CAP ? (I == 2 ? 4 : 3) : ((W == 8 && I == 2) ? (CAP > SHORT_CAP ? 7 : UTREE_SHORT_MIN_WAVES) : 5))
+__global__ __launch_bounds__(256, CAP > SHORT2_CAP ? (I == 2 ? 4 : 3) : (I == 2 ? (CAP > SHORT_CAP ? 7 : UTREE_SHORT_MIN_WAVES) : 5))
 void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
                       const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
                       utk_workspace ws) {
