@@ -250,7 +250,7 @@ template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED>
 #ifndef UTREE_SHORT_MIN_WAVES
 #define UTREE_SHORT_MIN_WAVES 8
 #endif
-__global__ __launch_bounds__(256, CAP > SHORT2_CAP ? (I == 2 ? 4 : 3) : (I == 2 ? (CAP > SHORT_CAP ? 7 : UTREE_SHORT_MIN_WAVES) : 5))
+__global__ __launch_bounds__(256, CAP > SHORT2_CAP ? (I == 2 ? 4 : 3) : (I == 2 ? UTREE_SHORT_MIN_WAVES : 5))
 void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
                       const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
                       utk_workspace ws) {
