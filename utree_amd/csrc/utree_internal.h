@@ -27,7 +27,7 @@ extern "C" {
 #define UTREE_CURSOR_BYTES (512 + 2 * UTREE_WORK_PARTS * UTREE_WORK_STRIDE * 8)   /* cursors[] + part counters (main, mid) */
 #define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds      */
 #define UTREE_SHORT2_CAP 640u                    /* ... its second size: 250-300 bp reads with the reverse strand */
-#define UTREE_MID_DEFAULT 1536u                  /* measured cross-over to classify_long_k on hit-dense reads (UTREE_MID_LIMIT overrides) */
+#define UTREE_MID_DEFAULT 2112u                  /* = UTREE_MID_CAP: since r01l the wave-per-read pass beats classify_long_k up to its capacity (2100 bp: 65 vs 46 M reads/s); UTREE_MID_LIMIT overrides */
 #define UTREE_MID_CAP 2112u                      /* ... and its mid-length instantiation; longer: classify_long */
 
 /* image flags */
