@@ -436,3 +436,22 @@ def test_byte_fuzz_vs_oracle(torch_cuda, name, with_gt, tmp_path):
         gcode, st = search_gg(db, [tree], str(fa), str(got), rc=rc, threads=2)
         assert {lib.OK: 0, lib.E_FASTA: 2, lib.E_IO: 1}[gcode] == code
         assert got.read_bytes() == want.read_bytes()
+
+
+def test_framing_fuzz_vs_oracle(torch_cuda, tmp_path):
+    """The same forty random framing files through the product's whole-file path: exit code and output equal the oracle's
+    (which equals the genuine reference's: test_oracle_golden.py::test_framing_fuzz_oracle_vs_reference)."""
+    db, tree = tree_for("toy")
+    o = orc.OracleDB.load(util.fixture_ctr("toy"))
+    for seed in range(40):
+        fa = tmp_path / "f.fa"
+        fa.write_bytes(util.framing_fuzz_case(seed))
+        for rc in (False, True):
+            want, got = tmp_path / "orc.txt", tmp_path / "gpu.txt"
+            for f in (want, got):
+                if f.exists():
+                    f.unlink()
+            code, nr, good, err = o.search_file(str(fa), str(want), threads=2, rc=rc)
+            gcode, st = search_gg(db, [tree], str(fa), str(got), rc=rc, threads=2)
+            assert {lib.OK: 0, lib.E_FASTA: 2, lib.E_IO: 1}[gcode] == code, seed
+            assert (got.read_bytes() if got.exists() else b"") == (want.read_bytes() if want.exists() else b""), seed

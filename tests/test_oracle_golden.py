@@ -255,3 +255,24 @@ def test_build_hostile_labels_oracle_vs_reference(exe, W, gg, tmp_path):
             ext = ".gg.log" if gg else ".log"
             assert open(got, "rb").read() == open(want, "rb").read()
             assert open(got + ext, "rb").read() == open(want + ext, "rb").read()
+
+
+@pytest.mark.skipif(not util.have_ref(), reason="needs oracle/_ref (the genuine reference, built from /root/reference by `make -C oracle ref`)")
+def test_framing_fuzz_oracle_vs_reference(tmp_path):
+    """Sixteen random files from the grammar of framing corner cases (util.framing_fuzz_case; 150 were run once while writing
+    this test), both strands: the oracle's exit code and output file equal the genuine reference's."""
+    import subprocess
+    o = orc.OracleDB.load(util.fixture_ctr("toy"))
+    for seed in range(16):
+        fa = tmp_path / "f.fa"
+        fa.write_bytes(util.framing_fuzz_case(seed))
+        for rc in (False, True):
+            want, got = tmp_path / "ref.txt", tmp_path / "orc.txt"
+            for f in (want, got):
+                if f.exists():
+                    f.unlink()
+            r = subprocess.run([os.path.join(util.REF_DIR, "xtree-searchGG"), util.fixture_ctr("toy"), str(fa), str(want), "1"] + (["RC"] if rc else []),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            code, nr, good, err = o.search_file(str(fa), str(got), threads=2, rc=rc)
+            assert code == r.returncode, seed
+            assert (got.read_bytes() if got.exists() else None) == (want.read_bytes() if want.exists() else None), seed
