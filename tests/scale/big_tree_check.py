@@ -5,7 +5,7 @@ This is the only way to exercise the 8-byte bin-table reader and the 64-bit offs
 (`UTREE_FORCE_OFF64` covers the kernels on small trees).  Needs ~30 GB of /dev/shm and ~150 GB of HBM.
 usage: big_tree_check.py [nodes] [reads]"""
 import hashlib, json, os, subprocess, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from utree_amd import lib, synth

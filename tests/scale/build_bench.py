@@ -3,7 +3,7 @@
 files and the two `.gg.log` files must be identical.  Synthetic references: mutated copies of a few root sequences with
 GG-style labels, so k-mers collide at every rank.  usage: build_bench.py [n_refs] [ref_len] [complevel]"""
 import json, os, subprocess, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from utree_amd import ctrfile, lib
 n_refs = int(sys.argv[1]) if len(sys.argv) > 1 else 400

@@ -5,7 +5,7 @@ References: mutated copies of a few root sequences with GG-style labels (k-mers 
 slices of the references with 1 % substitutions, some reverse-complemented.  usage: chain_check.py [n_refs] [ref_len] [complevel] [n_reads]
 VARIANT=k64|ix32 selects the reference's -D PACKSIZE=64 / -D IXTYPE=uint32_t builds."""
 import hashlib, json, os, subprocess, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from utree_amd import ctrfile, lib
 n_refs = int(sys.argv[1]) if len(sys.argv) > 1 else 300

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measure `.ubt` -> `.ctr`: our xtree-compress (GPU) vs the genuine reference's, same file, outputs compared."""
 import json, os, subprocess, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from utree_amd import ctrfile, lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000_000

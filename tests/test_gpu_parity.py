@@ -298,7 +298,7 @@ def test_64bit_offset_instantiations(torch_cuda, name, monkeypatch):
 @pytest.mark.parametrize("name,parts", [("toy", 4), ("k64", 8), ("ix32", 64), ("katq2", 2), ("vote", 16)])
 def test_image_built_in_parts(torch_cuda, name, parts, monkeypatch):
     """Trees of billions of nodes get their (hash, position, rest) order in 2..64 parts by the top hash bits so that the sort
-    buffers fit beside the image (tools/big_tree_check.py runs a 4.4 G-node tree); a hook forces that path on small ones."""
+    buffers fit beside the image (tests/scale/big_tree_check.py runs a 4.4 G-node tree); a hook forces that path on small ones."""
     monkeypatch.setenv("UTREE_BUILD_PARTS", str(parts))
     db = CtrDB.open(util.fixture_ctr(name))
     tree = DeviceTree.upload(db, 0, 3)
