@@ -246,14 +246,16 @@ constexpr int32_t RANK_PENDING = -4;                // one distinct label: resul
 // CAP = staged bases a wavefront's LDS slice holds.  CAP = SHORT_CAP walks all reads of the batch and routes the
 // longer ones to the mid / long lists; CAP = MID_CAP (LISTED) walks the mid list.  Its 37 KB of LDS per
 // workgroup allow 4 workgroups per CU, so it may use 128 VGPRs.
-template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED>
+template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED, int RCMODE = 2>   // RCMODE 0 / 1: strand handling known at compile time
 #ifndef UTREE_SHORT_MIN_WAVES
 #define UTREE_SHORT_MIN_WAVES 8
 #endif
 __global__ __launch_bounds__(256, CAP > SHORT2_CAP ? (I == 2 ? 4 : 3) : (I == 2 ? UTREE_SHORT_MIN_WAVES : 5))
 void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
-                      const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utree_result *__restrict__ out,
+                      const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc_arg, utree_result *__restrict__ out,
                       utk_workspace ws) {
+    // the 150-bp-class kernel is compiled per strand mode: the other mode's code and registers disappear
+    const int do_rc = RCMODE == 2 ? do_rc_arg : RCMODE;
     constexpr uint32_t K = 4 * W;
     constexpr int NCH = CAP / 64, NWORDS = CAP / 16 + 6;
     __shared__ uint32_t s_words[WAVES_PER_BLOCK][NWORDS];
@@ -771,8 +773,11 @@ int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64
         if (ws->short_cap == UTREE_SHORT2_CAP)
             classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT2_CAP, false>
                 <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+        else if (do_rc)
+            classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT_CAP, false, 1>
+                <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
         else
-            classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT_CAP, false>
+            classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT_CAP, false, 0>
                 <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
     });
 }
