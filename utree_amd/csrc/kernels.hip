@@ -350,7 +350,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             // the old chunk; reads with more hits than that take their space directly, so the workspace bound
             // windows * 9/8 + waves * TALLY_CHUNK (dev_image.c) always holds.
             unsigned long long base;
-            const bool direct = F >= TALLY_DIRECT;
+            const bool direct = (uint32_t)CAP >= TALLY_DIRECT && F >= TALLY_DIRECT;   // (a 320-base slice never holds that many hits)
             if (direct) {
                 unsigned long long nb = 0;
                 if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)F);
