@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UTREE_ABI_VERSION 1
+#define UTREE_ABI_VERSION 2
 
 enum {
     UTREE_OK = 0,
@@ -266,6 +266,15 @@ enum {
     UTREE_BUILD_E_NO_KMERS = 4,   /* "Error: no k-mers. Bad input/params!" (631)              -> exit 2           */
     UTREE_BUILD_E_NAME = 5        /* "Error: taxon map incomplete (line %u)" (582)            -> exit 4           */
 };
+/* which check of the map parser failed (utree_build_stats.map_error when error_kind == UTREE_BUILD_E_MAP); the command
+ * line prints the reference's text for each */
+enum {
+    UTREE_MAP_E_BLANK_NAME = 1,   /* "ERROR: map line %llu\nBlank indices are NOT ALLOWED." (itree.c:530-533)               */
+    UTREE_MAP_E_EXTRA_TAB = 2,    /* "map: extra tab, line %llu" (537)                                                      */
+    UTREE_MAP_E_NO_TAB = 3,       /* "Err tab1: %llu" (538)                                                                 */
+    UTREE_MAP_E_BLANK_LABEL = 4,  /* "\nERROR: map line %llu\nBlank labels are NOT ALLOWED." (541-544)                      */
+    UTREE_MAP_E_NO_NEWLINE = 5    /* "Err line counter: %llu" (548): the text ends inside a label                           */
+};
 typedef struct {
     uint64_t n_seqs;        /* references parsed (return value of UT_parseSampFastaExternOSFA)                    */
     uint64_t n_kmers;       /* k-mers added, repeats included                                                     */
@@ -275,6 +284,9 @@ typedef struct {
     int      error_kind;    /* UTREE_BUILD_E_* when the call returns UTREE_E_BUILD (or UTREE_E_IO for MAP_EMPTY)  */
     uint32_t W, I;
     double   seconds;
+    uint64_t n_distinct;    /* distinct k-mers, BAD ones included: "Done with sequence parse: %llu k-mers made" (626-630) */
+    uint64_t map_bytes, map_lines;   /* "Parsed map. %llu bytes, %llu lines." (510, 515)                                  */
+    int      map_error;     /* UTREE_MAP_E_* when error_kind == UTREE_BUILD_E_MAP                                         */
 } utree_build_stats;
 
 int utree_build_file(const char *fasta_path, const char *map_path, const char *ubt_path, uint32_t W, uint32_t I,

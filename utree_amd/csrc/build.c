@@ -140,23 +140,27 @@ int utree_build_file(const char *fasta_path, const char *map_path, const char *u
     size_t lines = 0;
     for (uint64_t i = 0; i < mn; ++i) lines += mp[i] == '\n';
     if (mp[mn - 1] != '\n') ++lines;
+    st.map_bytes = mn; st.map_lines = lines;                                            /* "Parsed map. %llu bytes, %llu lines." (510, 515) */
     ent = (mapent *)malloc(sizeof(mapent) * (lines ? lines : 1));
     if (!ent) { rc = UTREE_E_NOMEM; goto done; }
     {
         char *ptr = (char *)mp;
         for (size_t i = 0; i < lines; ++i) {
             st.error_line = i;
-            if (*ptr == '\n' || *ptr == '\r' || *ptr == '\t') { rc = UTREE_E_BUILD; st.error_kind = UTREE_BUILD_E_MAP; goto done; }   /* 533, 539 */
+#define MAP_FAIL(why) do { rc = UTREE_E_BUILD; st.error_kind = UTREE_BUILD_E_MAP; st.map_error = (why); goto done; } while (0)
+            if (*ptr == '\n' || *ptr == '\r') MAP_FAIL(UTREE_MAP_E_BLANK_NAME);                /* 530-533 */
+            if (*ptr == '\t') MAP_FAIL(UTREE_MAP_E_EXTRA_TAB);                                  /* 537 */
             ent[i].name = ptr;
-            while (*++ptr != '\t') if (!*ptr) { rc = UTREE_E_BUILD; st.error_kind = UTREE_BUILD_E_MAP; goto done; }                     /* 540 */
+            while (*++ptr != '\t') if (!*ptr) MAP_FAIL(UTREE_MAP_E_NO_TAB);                     /* 538 */
             *ptr++ = 0;
-            if (*ptr == '\n' || *ptr == '\r') { rc = UTREE_E_BUILD; st.error_kind = UTREE_BUILD_E_MAP; goto done; }                     /* 543 */
+            if (*ptr == '\n' || *ptr == '\r') { st.error_line = i + 1; MAP_FAIL(UTREE_MAP_E_BLANK_LABEL); }   /* 541-544 */
             ent[i].label = ptr;
-            while (*ptr != '\n') {                                                     /* 549-553: a last line without '\n' is an error */
-                if (!*ptr) { rc = UTREE_E_BUILD; st.error_kind = UTREE_BUILD_E_MAP; goto done; }
+            while (*ptr != '\n') {                                                     /* 547-551: a last line without '\n' is an error */
+                if (!*ptr) MAP_FAIL(UTREE_MAP_E_NO_NEWLINE);
                 if (*ptr == '\r' || *ptr == '\t') *ptr = 0;
                 ptr++;
             }
+#undef MAP_FAIL
             *ptr++ = 0;
         }
     }
@@ -239,7 +243,7 @@ int utree_build_file(const char *fasta_path, const char *map_path, const char *u
         rc = utk_build_phase1(&job, &res, &S);
         if (rc) goto done;
     }
-    st.n_kmers = res.n_occ; st.n_nodes = res.n_nodes;
+    st.n_kmers = res.n_occ; st.n_nodes = res.n_nodes; st.n_distinct = res.n_distinct;
     if (!res.n_occ) { rc = UTREE_E_BUILD; st.error_kind = UTREE_BUILD_E_NO_KMERS; goto done; }          /* 631: exit 2 */
     /* ---- label indices in the reference's order of creation: a reference's label when the reference is parsed (583),
      *      a cut label at the collision that first produced it (297); the clock is the position in the input ---- */

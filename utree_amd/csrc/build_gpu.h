@@ -22,6 +22,7 @@ typedef struct {
 
 typedef struct {
     uint64_t total_pos, n_occ, n_nodes;  /* positions examined, k-mers added (with repeats), nodes kept                 */
+    uint64_t n_distinct;                 /* distinct k-mers, BAD ones included: the reference's "k-mers made" (itree.c:626-630) */
     uint32_t n_passes;
     uint64_t *h_first_time;              /* [n_u] 2*position+1 of the first collision that produced the label, or ~0    */
     uint64_t *h_ref_time;                /* [n_refs] 2*(positions before reference r): when its own label is created    */

@@ -180,11 +180,17 @@ __device__ __forceinline__ uint32_t shared_semicolons(const universe &U, uint32_
 template <int W, bool GG>
 __global__ __launch_bounds__(BLOCK) void fold_k(const uint64_t *__restrict__ key_lo, const uint64_t *__restrict__ key_hi,
                                                 const uint64_t *__restrict__ val, uint64_t n, universe U,
-                                                unsigned long long *__restrict__ first_time, uint32_t *__restrict__ state_out) {
+                                                unsigned long long *__restrict__ first_time, uint32_t *__restrict__ state_out,
+                                                unsigned long long *__restrict__ n_distinct) {
     const uint64_t j = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t lo = j < n ? key_lo[j] : 0, hi = (W == 16 && j < n) ? key_hi[j] : 0;
+    const bool head = j < n && !(j && key_lo[j - 1] == lo && (W == 8 || key_hi[j - 1] == hi));
+    {   // distinct k-mers of the pass (the reference's NumsInserted, itree.c:448,466): one atomic per wavefront
+        const uint64_t hm = __ballot(head);
+        if (hm && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(hm)) atomicAdd(n_distinct, (unsigned long long)__popcll(hm));
+    }
     if (j >= n) return;
-    const uint64_t lo = key_lo[j], hi = W == 16 ? key_hi[j] : 0;
-    if (j && key_lo[j - 1] == lo && (W == 8 || key_hi[j - 1] == hi)) { state_out[j] = ST_SKIP; return; }
+    if (!head) { state_out[j] = ST_SKIP; return; }
     uint32_t st = (uint32_t)(val[j] & 0xFFFFFFu);                           // first occurrence: its reference's label
     for (uint64_t t = j + 1; t < n && key_lo[t] == lo && (W == 8 || key_hi[t] == hi); ++t) {
         const uint64_t v = val[t];
@@ -251,7 +257,8 @@ void utk_build_free(utk_build_state *s) {
 
 /* one pass: the k-mers whose bucket is in [b_lo, b_hi): emit, stable sort, replay, keep what is not BAD */
 static int build_pass(const utk_build_job *job, const dev_in &in, const universe &U, uint32_t b_lo, uint32_t b_hi, uint64_t n_expect,
-                      uint32_t *d_counts, uint64_t *d_block_off, uint64_t n_blocks, unsigned long long *d_first, build_seg *seg) {
+                      uint32_t *d_counts, uint64_t *d_block_off, uint64_t n_blocks, unsigned long long *d_first,
+                      unsigned long long *d_distinct, build_seg *seg) {
     int rc = UTREE_OK;
     const int W = (int)job->W;
     uint64_t *k_lo = nullptr, *k_hi = nullptr, *k_val = nullptr, *a_lo = nullptr, *a_val = nullptr, *idx = nullptr, *idx2 = nullptr, *g_hi = nullptr;
@@ -306,10 +313,10 @@ static int build_pass(const utk_build_job *job, const dev_in &in, const universe
         }
         // ---- replay each k-mer's occurrences ----
         if (dmalloc(&d_state, n)) { rc = UTREE_E_NOMEM; goto fail; }
-        if (W == 8 && job->gg) fold_k<8, true><<<dim3(gb), dim3(BLOCK)>>>(k_lo, k_hi, k_val, n, U, d_first, d_state);
-        else if (W == 8) fold_k<8, false><<<dim3(gb), dim3(BLOCK)>>>(k_lo, k_hi, k_val, n, U, d_first, d_state);
-        else if (job->gg) fold_k<16, true><<<dim3(gb), dim3(BLOCK)>>>(k_lo, k_hi, k_val, n, U, d_first, d_state);
-        else fold_k<16, false><<<dim3(gb), dim3(BLOCK)>>>(k_lo, k_hi, k_val, n, U, d_first, d_state);
+        if (W == 8 && job->gg) fold_k<8, true><<<dim3(gb), dim3(BLOCK)>>>(k_lo, k_hi, k_val, n, U, d_first, d_state, d_distinct);
+        else if (W == 8) fold_k<8, false><<<dim3(gb), dim3(BLOCK)>>>(k_lo, k_hi, k_val, n, U, d_first, d_state, d_distinct);
+        else if (job->gg) fold_k<16, true><<<dim3(gb), dim3(BLOCK)>>>(k_lo, k_hi, k_val, n, U, d_first, d_state, d_distinct);
+        else fold_k<16, false><<<dim3(gb), dim3(BLOCK)>>>(k_lo, k_hi, k_val, n, U, d_first, d_state, d_distinct);
         HK(hipGetLastError());
         HK(hipFree(k_val)); k_val = nullptr;
         // ---- keep what is not BAD, ascending ----
@@ -417,6 +424,7 @@ int utk_build_phase1(const utk_build_job *job, utk_build_result *res, utk_build_
         for (uint32_t b = 0; b < N_BUCKETS; ++b) n += h_hist[b];
         res->n_occ = S->n_occ = n;
         if (!n) goto done;
+        HK(hipMemset(d_hist, 0, 8));                                     /* the histogram is on the host now: word 0 counts distinct k-mers */
         // passes: contiguous bucket ranges of at most `limit` occurrences
         HK(hipMemGetInfo(&free_b, &total_b));
         uint64_t limit = (free_b > ((uint64_t)2 << 30) ? free_b - ((uint64_t)2 << 30) : 0) / (W == 16 ? 72ull : 44ull);
@@ -430,7 +438,7 @@ int utk_build_phase1(const utk_build_job *job, utk_build_result *res, utk_build_
             if (cnt > limit) { rc = n > limit && limit < (1ull << 31) - 1 ? UTREE_E_NOMEM : UTREE_E_UNSUPPORTED; goto fail; }   /* one bucket too large */
             while (e < N_BUCKETS && cnt + h_hist[e] <= limit) cnt += h_hist[e++];
             if (cnt) {
-                rc = build_pass(job, in, U, b, e, cnt, d_counts, d_block_off, n_blocks, d_first, &S->seg[S->n_seg]);
+                rc = build_pass(job, in, U, b, e, cnt, d_counts, d_block_off, n_blocks, d_first, d_hist, &S->seg[S->n_seg]);
                 if (rc) { S->n_seg++; goto fail; }
                 S->n_nodes += S->seg[S->n_seg].n;
                 S->n_seg++;
@@ -439,6 +447,7 @@ int utk_build_phase1(const utk_build_job *job, utk_build_result *res, utk_build_
         }
         res->n_nodes = S->n_nodes;
         res->n_passes = S->n_seg;
+        { unsigned long long nd = 0; HK(hipMemcpy(&nd, d_hist, 8, hipMemcpyDeviceToHost)); res->n_distinct = nd; }
         HK(hipMemcpy(res->h_first_time, d_first, 8ull * job->n_u, hipMemcpyDeviceToHost));
     }
 done:

@@ -106,6 +106,7 @@ int utree_compress_file(const char *ubt_path, const char *ctr_path, int device, 
     }
     HIPC(hipMalloc((void **)&d_first, (size_t)UTREE_NUMBINS * 8));
     HIPC(hipMemset(d_first, 0xFF, (size_t)UTREE_NUMBINS * 8));
+    HIPC(hipDeviceSynchronize());                                             /* the chunk streams are non-blocking: no implicit order with the null stream */
     {
         uint64_t done = 0, pend_first[2] = {0, 0}, pend_cnt[2] = {0, 0};
         for (int slot = 0; done < N || pend_cnt[0] || pend_cnt[1]; slot ^= 1) {

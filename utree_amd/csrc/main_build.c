@@ -10,6 +10,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "../../include/utree_amd.h"
 
 #define VER "[v2.0RF SigNature Edition]"          /* itree.c:1350 */
@@ -25,6 +28,16 @@ int main(int argc, char *argv[]) {
         exit(1);
     }
     printf("This is UTree " VER "\n");
+    {                                                                                     /* itree.c:1385-1389, 1395 */
+        int threads = atoi(argv[4]);
+#ifdef _OPENMP
+        if (!threads) threads = omp_get_max_threads();
+#else
+        if (!threads) threads = 1;
+#endif
+        printf("Using up to %d threads.\n", threads);
+        puts("Tree initialized.");
+    }
     unsigned cl = 1;                                                                      /* itree.c:1396-1398 */
     if (argc > 5) cl = (unsigned)atoi(argv[5]);
     printf("Setting compression level to %u\n", cl);
@@ -34,19 +47,29 @@ int main(int argc, char *argv[]) {
     int device = getenv("UTREE_DEVICE") ? atoi(getenv("UTREE_DEVICE")) : 0;
     utree_build_stats st;
     int rc = utree_build_file(argv[1], argv[2], argv[3], W, I, (int)cl, DO_GG, device, &st);
-    if (rc == UTREE_E_IO && st.error_kind == UTREE_BUILD_E_MAP_EMPTY) { puts("\nInput map empty."); exit(1); }   /* itree.c:512 */
+    if (rc == UTREE_E_IO && st.error_kind == UTREE_BUILD_E_MAP_EMPTY) { printf("Parsed map. 0 bytes"); puts("\nInput map empty."); exit(1); }   /* itree.c:510-511 */
     if (rc == UTREE_E_IO) { puts("Invalid input file(s)"); exit(1); }                     /* itree.c:504 */
+    if (st.map_lines) printf("Parsed map. %llu bytes, %llu lines.\n", (unsigned long long)st.map_bytes, (unsigned long long)st.map_lines);   /* 510, 515 */
     if (rc == UTREE_E_BUILD) {
+        const unsigned long long el = (unsigned long long)st.error_line;
         switch (st.error_kind) {
-            case UTREE_BUILD_E_MAP: printf("ERROR: malformatted map at line %llu\n", (unsigned long long)st.error_line); exit(2);
+            case UTREE_BUILD_E_MAP:
+                switch (st.map_error) {                                                   /* the reference's text per check */
+                    case UTREE_MAP_E_BLANK_NAME: printf("ERROR: map line %llu\nBlank indices are NOT ALLOWED.\n", el); break;       /* 531 */
+                    case UTREE_MAP_E_EXTRA_TAB: printf("map: extra tab, line %llu\n", el); break;                                  /* 537 */
+                    case UTREE_MAP_E_NO_TAB: printf("Err tab1: %llu\n", el); break;                                                /* 538 */
+                    case UTREE_MAP_E_BLANK_LABEL: printf("\nERROR: map line %llu\nBlank labels are NOT ALLOWED.\n", el); break;    /* 542 */
+                    default: printf("Err line counter: %llu\n", el); break;                                                       /* 548 */
+                }
+                exit(2);
             case UTREE_BUILD_E_FASTA: printf("Error parsing FASTA (1pass): %llu", (unsigned long long)st.error_line); exit(2);   /* 586 */
-            case UTREE_BUILD_E_NO_KMERS: puts("Error: no k-mers. Bad input/params!"); exit(2);                                    /* 631 */
+            case UTREE_BUILD_E_NO_KMERS: puts("Done with sequence parse: 0 k-mers made"); puts("Error: no k-mers. Bad input/params!"); exit(2);                                    /* 631 */
             case UTREE_BUILD_E_NAME: printf("Error: taxon map incomplete (line %u)\n", (unsigned)st.error_line); exit(4);         /* 582 */
             default: exit(2);
         }
     }
     if (rc) { fprintf(stderr, "ERROR: %s\n", utree_strerror(rc)); exit(3); }
-    printf("Done with sequence parse: %llu k-mers added\n", (unsigned long long)st.n_kmers);
+    printf("Done with sequence parse: %llu k-mers made\n", (unsigned long long)st.n_distinct);   /* itree.c:630: distinct k-mers */
     puts("File parsed.");
     printf("Total nodes in tree: %llu [%llu labels]\n", (unsigned long long)st.n_nodes, (unsigned long long)st.n_labels);   /* 1337 */
     puts("Tree written.");

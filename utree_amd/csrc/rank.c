@@ -83,9 +83,12 @@ static int state_reserve(utree_dev *d, uint64_t need, hipStream_t st) {
     void *nu = NULL;
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMalloc(&nu, cap * 4));
-    HIPCHK(hipMemset(nu, 0, cap * 4));                                  /* untouched entries read as label 0 */
+    /* stream-ordered on the caller's stream: its kernels read the array next, and a non-blocking stream has no
+     * implicit ordering with the null stream */
+    HIPCHK(hipMemsetAsync(nu, 0, cap * 4, st));                         /* untouched entries read as label 0 */
     if (d->rank_state) {
-        HIPCHK(hipMemcpy(nu, d->rank_state, d->rank_state_cap * 4, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpyAsync(nu, d->rank_state, d->rank_state_cap * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));                               /* the old array is freed next */
         HIPCHK(hipFree(d->rank_state));
     }
     d->rank_state = nu; d->rank_state_cap = cap;
@@ -99,7 +102,10 @@ int utree_rank_reset(utree_dev *d) {
     int rc = UTREE_OK;
     if (!d) return UTREE_E_ARG;
     HIPCHK(hipSetDevice(d->device));
-    if (d->rank_state) HIPCHK(hipMemset(d->rank_state, 0, d->rank_state_cap * 4));
+    if (d->rank_state) {
+        HIPCHK(hipMemset(d->rank_state, 0, d->rank_state_cap * 4));
+        HIPCHK(hipDeviceSynchronize());                                 /* the batches' streams are non-blocking: order by completion */
+    }
 fail:
     return rc;
 }

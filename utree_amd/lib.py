@@ -51,7 +51,8 @@ class CompressStats(C.Structure):
 class BuildStats(C.Structure):
     _fields_ = [("n_seqs", C.c_uint64), ("n_kmers", C.c_uint64), ("n_nodes", C.c_uint64), ("n_labels", C.c_uint64),
                 ("error_line", C.c_uint64), ("error_kind", C.c_int), ("W", C.c_uint32), ("I", C.c_uint32),
-                ("seconds", C.c_double)]
+                ("seconds", C.c_double), ("n_distinct", C.c_uint64), ("map_bytes", C.c_uint64), ("map_lines", C.c_uint64),
+                ("map_error", C.c_int)]
 
 
 class RankParams(C.Structure):
