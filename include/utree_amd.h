@@ -148,6 +148,12 @@ int utree_lookup_words(utree_dev *dev, const uint64_t *d_hi, const uint64_t *d_l
 /* Name of the dominant kernel as rocprofv3 reports it and the wall time (ms) HIP events measured around
  * its launches since the last call with reset != 0 (bench.py's roofline leg). */
 const char *utree_classify_kernel_name(const utree_dev *dev);
+/* Measurement aid for the byte model of the bucketed image (bench.py): over the reads of up to 640 staged
+ * bases, h_counts5 = { reads, valid k-mer windows, distinct 64-byte buckets per read (summed), distinct 128-byte HBM lines per
+ * read (summed), distinct buckets that carry an overflow descriptor }.  Synchronous.  Evaluated window by window with the
+ * load-time minimizer code, independently of the search kernels' sliding minimum. */
+int utree_model_counts(utree_dev *dev, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
+                       int do_rc, uint64_t *h_counts5, void *stream);
 int utree_classify_kernel_time(utree_dev *dev, int reset, double *ms_total, uint64_t *launches);
 
 /* ------------------------------------------------------------------------------------------------
@@ -191,10 +197,26 @@ typedef struct {
     uint64_t good_finds;    /* "Good finds: %llu" (1106)                                                  */
     double   seconds_total, seconds_kernels;
     utree_fasta_error fasta_error;
+    /* Where the time went.  pipeline 1 = device text pipeline (framing and formatting on the GPU; the host only moves
+     * bytes): the figures are LANE-seconds, summed over the n_lanes host threads that each carry one chunk at a time
+     * through all stages.  pipeline 0 = host framing / formatting (rank-specific search, opt-in input formats, malformed
+     * input): seconds of the four overlapped stage threads; seconds_frame = host framing, seconds_classify_format =
+     * H2D + kernels + D2H, seconds_d2h = host formatting. */
+    int      pipeline, n_lanes;
+    double   seconds_read;              /* file -> pinned memory                                                      */
+    double   seconds_frame;             /* H2D of the chunk + newline scan + framing kernels (until the host knows the read count) */
+    double   seconds_classify_format;   /* classify + vote + line lengths (until the host knows the text length)      */
+    double   seconds_order_wait;        /* waiting for the earlier chunks' text lengths (output offsets are in input order) and for the file (one writer at a time) */
+    double   seconds_d2h;               /* format kernel + D2H of the text                                            */
+    double   seconds_write;             /* pwrite                                                                     */
+    uint64_t bytes_in, bytes_out;
 } utree_search_stats;
 
 int utree_search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path,
                       const char *out_path, int do_rc, int host_threads, utree_search_stats *stats);
+/* Optional: allocate the search's pinned and device buffers now (they are kept in the device handles and reused by later
+ * searches), so that the first search does not pay for them -- "database resident" then includes them. */
+int utree_search_prepare(const utree_ctr *ctr, utree_dev **devs, int n_dev, int do_rc);
 /* Same with an opt-in input format (UTREE_INPUT_*; AUTO looks at the first byte); gzip input is read through zlib. */
 int utree_search_file_opts(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *reads_path,
                            const char *out_path, int do_rc, int host_threads, int input_format, utree_search_stats *stats);

@@ -1,0 +1,195 @@
+"""GPU tests of the whole-file search with framing and formatting on the device (csrc/search_dev.c, text_kernels.hip),
+through the C-ABI (utree_search_file): the reference's committed outputs, the oracle on seeded files, chunk boundaries
+at every position class, two device handles (the multi-GPU sharding and ordered concatenation of search_dev.c on one
+card), and the hand-over to the host framing for input the kernels do not take.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import orc
+from utree_amd import lib
+from utree_amd.search import CtrDB, DeviceTree, search_gg
+import util
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+_TREES = {}
+
+
+def tree_for(name):
+    if name not in _TREES:
+        db = CtrDB.open(util.fixture_ctr(name))
+        _TREES[name] = (db, DeviceTree.upload(db, 0))
+    return _TREES[name]
+
+
+def run(db, trees, data, tmp_path, rc=False, threads=4):
+    fa, out = tmp_path / "in.fa", tmp_path / "out.txt"
+    fa.write_bytes(data)
+    if out.exists():
+        out.unlink()
+    code, st = search_gg(db, trees, str(fa), str(out), rc=rc, threads=threads)
+    return code, st, out.read_bytes()
+
+
+@pytest.mark.parametrize("name,rc", [("toy", 0), ("toy", 1), ("k64", 1), ("ix32", 0), ("vote", 0), ("katq2", 0), ("generic", 0)])
+def test_golden_files_take_the_device_pipeline(torch_cuda, name, rc, tmp_path):
+    db, tree = tree_for(name)
+    data = util.fixture_bytes(util.READS_OF.get(name, name) + "_reads.fa.gz")
+    code, st, got = run(db, [tree], data, tmp_path, rc=bool(rc))
+    assert code == lib.OK
+    want = util.fixture_bytes("%s_out%s.txt.gz" % (name, "_rc" if rc else ""))
+    assert got == want
+    if b"\0" not in data:
+        assert st.pipeline == 1 and st.n_lanes >= 1                  # framed and formatted on the GPU, not handed to the host path
+    assert st.good_finds == want.count(b"\n") and st.n_reads == data.count(b"\n") // 2
+    assert st.bytes_out == len(want) and st.bytes_in == len(data)
+
+
+@pytest.mark.parametrize("chunk", [300, 1000, 4096, 65536 + 17])
+def test_chunk_boundaries(torch_cuda, chunk, tmp_path, monkeypatch):
+    """Small chunks put a boundary after almost every record class of the toy reads (N, lowercase, CRLF, short, no-hit);
+    chunks go to the lanes in turn and the texts are concatenated in input order."""
+    monkeypatch.setenv("UTREE_CHUNK_BYTES", str(chunk))
+    db, tree = tree_for("toy")
+    data = util.fixture_bytes("toy_reads.fa.gz")[: 400_000 if chunk < 4096 else None]
+    data = data[: data.rfind(b"\n>") + 1]
+    o = orc.OracleDB.load(util.fixture_ctr("toy"))
+    fa, want = tmp_path / "w.fa", tmp_path / "want.txt"
+    fa.write_bytes(data)
+    ocode, nr, good, err = o.search_file(str(fa), str(want), threads=4, rc=True)
+    code, st, got = run(db, [tree], data, tmp_path, rc=True)
+    assert code == lib.OK and ocode == 0
+    assert st.pipeline == 1
+    assert got == want.read_bytes()
+    assert st.n_reads == nr and st.good_finds == good
+
+
+def test_two_device_handles_share_the_chunks(torch_cuda, tmp_path, monkeypatch):
+    """n_dev = 2 on one card: the second handle adopts a byte copy of the image (what utree_dev_replicate's broadcast
+    delivers), lanes of both handles take chunks in turn, the output is the one-device output (= the reference's)."""
+    torch = torch_cuda
+    monkeypatch.setenv("UTREE_CHUNK_BYTES", "20000")
+    db, tree = tree_for("toy")
+    ptr, used = tree.image_ptr()
+
+    class _Raw:                                   # the library-owned image as a torch view (plumbing: a device-to-device copy)
+        __cuda_array_interface__ = {"shape": (used,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    src = torch.as_tensor(_Raw(), device="cuda:0")
+    copy = torch.empty(used + 4096, dtype=torch.uint8, device="cuda:0")[4096:]
+    copy.copy_(src)
+    torch.cuda.synchronize()
+    t2 = DeviceTree.attach(db, copy, 0)
+    for rc in (False, True):
+        data = util.fixture_bytes("toy_reads.fa.gz")
+        code, st, got = run(db, [tree, t2], data, tmp_path, rc=rc)
+        assert code == lib.OK and st.pipeline == 1 and st.n_lanes >= 2
+        assert got == util.fixture_bytes("toy_out%s.txt.gz" % ("_rc" if rc else ""))
+    # the host pipeline (UTREE_HOST_TEXT) shards every framed chunk over the handles instead: same file
+    monkeypatch.setenv("UTREE_HOST_TEXT", "1")
+    code, st, got = run(db, [tree, t2], util.fixture_bytes("toy_reads.fa.gz"), tmp_path, rc=True)
+    assert code == lib.OK and st.pipeline == 0
+    assert got == util.fixture_bytes("toy_out_rc.txt.gz")
+    t2.close()
+
+
+def test_last_line_without_newline_crlf_and_empty_file(torch_cuda, tmp_path):
+    db, tree = tree_for("toy")
+    o = orc.OracleDB.load(util.fixture_ctr("toy"))
+    base = util.fixture_bytes("toy_reads.fa.gz")[:30_000]
+    base = base[: base.rfind(b"\n>") + 1]
+    cases = {
+        "no_final_newline": base[:-1],
+        "crlf": base.replace(b"\n", b"\r\n"),
+        "crlf_no_final_newline": base.replace(b"\n", b"\r\n")[:-2],
+        "empty": b"",
+        "spaces_and_tabs_in_headers": base.replace(b">", b">x y\tz ", 50),
+    }
+    for nm, data in cases.items():
+        fa, want = tmp_path / "w.fa", tmp_path / "want.txt"
+        fa.write_bytes(data)
+        ocode, nr, good, err = o.search_file(str(fa), str(want), threads=2, rc=False)
+        code, st, got = run(db, [tree], data, tmp_path)
+        assert code == lib.OK and ocode == 0, nm
+        assert st.pipeline == 1, nm
+        assert got == want.read_bytes(), nm
+        assert st.n_reads == nr, nm
+
+
+def test_input_for_the_host_framing_is_handed_over(torch_cuda, tmp_path, monkeypatch):
+    """Malformed or unusual input leaves the device pipeline (stats.pipeline == 0) and gets the reference's behaviour from
+    the host framing: NUL bytes, a header without '>', a sequence line starting with '>', a trailing header, a record
+    larger than a chunk."""
+    db, tree = tree_for("toy")
+    o = orc.OracleDB.load(util.fixture_ctr("toy"))
+    base = util.fixture_bytes("toy_reads.fa.gz")[:20_000]
+    base = base[: base.rfind(b"\n>") + 1]
+    mid = base.find(b"\n>", 10_000) + 1
+    cases = {
+        "nul_in_sequence": base[:mid + 30] + b"\0" + base[mid + 31:],
+        "no_header": base[:mid] + b"r_without_gt\nACGT\n" + base[mid:],
+        "sequence_begins_gt": base[:mid] + b">a\n>b\n" + base[mid:],
+        "trailing_header": base + b">last\n",
+        "blank_line": base[:mid] + b"\n" + base[mid:],
+    }
+    for nm, data in cases.items():
+        fa, want = tmp_path / "w.fa", tmp_path / "want.txt"
+        fa.write_bytes(data)
+        ocode, nr, good, err = o.search_file(str(fa), str(want), threads=2, rc=True)
+        code, st, got = run(db, [tree], data, tmp_path, rc=True)
+        assert {lib.OK: 0, lib.E_FASTA: 2, lib.E_IO: 1}[code] == ocode, nm
+        assert st.pipeline == 0, nm
+        assert got == want.read_bytes(), nm
+    # a record that does not fit a chunk
+    monkeypatch.setenv("UTREE_CHUNK_BYTES", "200")
+    long_rec = b">long\n" + b"ACGT" * 200 + b"\n"
+    data = base[:mid] + long_rec + base[mid:]
+    fa, want = tmp_path / "w.fa", tmp_path / "want.txt"
+    fa.write_bytes(data)
+    ocode, nr, good, err = o.search_file(str(fa), str(want), threads=2, rc=False)
+    code, st, got = run(db, [tree], data, tmp_path)
+    assert code == lib.OK and st.pipeline == 0 and got == want.read_bytes()
+
+
+def test_context_is_reused_and_strand_mode_may_change(torch_cuda, tmp_path):
+    db, tree = tree_for("toy")
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    for rc in (False, True, False, True):
+        code, st, got = run(db, [tree], data, tmp_path, rc=rc)
+        assert code == lib.OK and st.pipeline == 1
+        assert got == util.fixture_bytes("toy_out%s.txt.gz" % ("_rc" if rc else ""))
+    assert lib.load().utree_search_prepare(db._h, (__import__("ctypes").c_void_p * 1)(tree._h), 1, 1) == lib.OK
+
+
+def test_seeded_multichunk_file_vs_oracle(torch_cuda, tmp_path):
+    """A 150 MB file (three 64 MiB chunks, four lanes) on a synthetic database: output equals the oracle's file."""
+    torch = torch_cuda
+    from utree_amd import synth
+    sdb = synth.make_db(torch.device("cuda:0"), n_nodes=3_000_000, seed=synth.DB_SEED, keep_raw=True)
+    n = 900_000
+    reads = synth.make_reads(sdb, n_reads=n, read_len=150, seed=5)
+    seq = reads.bases.cpu().numpy().reshape(n, 150)
+    names = np.char.add(">read_", np.arange(n).astype("U9")).astype("S")
+    data = b"".join(names[i] + b"\n" + seq[i].tobytes() + b"\n" for i in range(n))
+    assert len(data) > 2 * (64 << 20)
+    o = orc.OracleDB.from_memory(sdb.W, 2, sdb.binix.cpu().numpy().view(np.uint32).astype(np.uint64), sdb.records.cpu().numpy(), sdb.label_text)
+    fa, want = tmp_path / "w.fa", tmp_path / "want.txt"
+    fa.write_bytes(data)
+    ocode, nr, good, err = o.search_file(str(fa), str(want), threads=16, rc=False)
+    code, st, got = run(sdb.ctr, [sdb.tree], data, tmp_path, threads=8)
+    assert code == lib.OK and ocode == 0 and st.pipeline == 1
+    assert st.n_reads == n == nr and st.good_finds == good
+    assert got == want.read_bytes()

@@ -383,6 +383,7 @@ void utree_dev_free(utree_dev *d) {
     if (!d) return;
     hipSetDevice(d->device);
     for (int i = 0; i < d->n_events; ++i) hipEventDestroy(d->events[i]);
+    if (d->search_ctx) utree_search_ctx_free(d->search_ctx);
     if (d->owns && d->image) hipFree(d->image);
     if (d->rank_state) hipFree(d->rank_state);
     free(d);
@@ -474,7 +475,7 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     /* the bracket goes around the batch's dominant kernel: the long-read kernel when the batch has long reads,
      * else the mid-length pass when it has mid-length reads, else the 150-bp-class kernel */
     const int dominant = w.long_blocks ? 2 : (w.mid_reads ? 1 : 0);
-    d->last_long = dominant == 2;
+    d->last_long = dominant == 2; d->last_mid = dominant == 1; d->last_rc = do_rc; d->last_short_cap = w.short_cap;
     if (w.mid_reads) KCHK(utk_route(d_len, n_reads, do_rc, &w, st));
     if (e0 && dominant == 0) HIPCHK(hipEventRecord(e0, st));
     KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
@@ -504,9 +505,30 @@ fail:
     return rc;
 }
 
-const char *utree_classify_kernel_name(const utree_dev *d) {
-    if (!d) return "";
-    return d->last_long ? utk_classify_long_name() : utk_classify_short_name(d->hdr.W, d->hdr.I);
+const char *utree_classify_kernel_name(const utree_dev *dc) {
+    if (!dc) return "";
+    utree_dev *d = (utree_dev *)dc;                       /* the signature string lives in the handle */
+    return d->last_long ? utk_classify_long_name(&d->kimg, d->kernel_sig, sizeof d->kernel_sig)
+                        : utk_classify_short_name(&d->kimg, d->last_short_cap ? d->last_short_cap : UTREE_SHORT_CAP, d->last_mid, d->last_rc,
+                                                  d->kernel_sig, sizeof d->kernel_sig);
+}
+
+/* measurement aid (bench.py's byte model): counts[0..4] = reads looked at (up to 640 staged bases), valid windows, distinct
+ * 64-byte buckets per read summed, distinct 128-byte lines per read summed, distinct buckets with an overflow descriptor */
+int utree_model_counts(utree_dev *d, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
+                       int do_rc, uint64_t *h_counts5, void *stream) {
+    int rc = UTREE_OK;
+    unsigned long long *dc = NULL;
+    if (!d || !d_bases || !d_off || !d_len || !h_counts5) return UTREE_E_ARG;
+    HIPCHK(hipSetDevice(d->device));
+    HIPCHK(hipMalloc((void **)&dc, 64));
+    HIPCHK(hipMemsetAsync(dc, 0, 64, (hipStream_t)stream));
+    KCHK(utk_model_counts(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, dc, stream));
+    HIPCHK(hipMemcpyAsync(h_counts5, dc, 40, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+fail:
+    if (dc) hipFree(dc);
+    return rc;
 }
 
 int utree_classify_kernel_time(utree_dev *d, int reset, double *ms_total, uint64_t *launches) {

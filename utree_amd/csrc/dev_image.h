@@ -13,16 +13,21 @@ struct utree_dev {
     utk_image kimg;
     /* HIP-event timing of the dominant kernel (enabled by the first utree_classify_kernel_time call) */
     int timing_on, n_pending, n_events, last_long;   /* last_long: the last batch's dominant kernel was classify_long_k */
+    int last_mid, last_rc; uint32_t last_short_cap;  /* ... and which wave-per-read instantiation it was otherwise        */
+    char kernel_sig[160];
     void *events[2 * UTREE_MAX_PENDING];
     double ms_total;
     uint64_t launches;
     /* rank-specific search: the reference's never-cleared hit array as later reads see it (rank.c) */
     void *rank_state;
     uint64_t rank_state_cap;
+    /* whole-file search: per-lane pinned / device buffers, kept between searches (search_dev.c) */
+    void *search_ctx;
 };
 
 void utree_dev_set_hip_error(int err, const char *what);
 const char *utree_last_hip_error(void);
 int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits);
+void utree_search_ctx_free(void *ctx);
 
 #endif

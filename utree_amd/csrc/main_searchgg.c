@@ -88,6 +88,9 @@ int main(int argc, char *argv[]) {
         rc = utree_dev_replicate(ctr, devs[0], ids, n_dev, devs);
         if (rc) { fprintf(stderr, "ERROR: RCCL broadcast of the tree: %s\n", utree_strerror(rc)); exit(3); }
     }
+#ifndef UTREE_RANK_SPECIFIC
+    (void)utree_search_prepare(ctr, devs, n_dev, doRC);                                   /* the search's pinned / device buffers: part of "database resident" */
+#endif
     puts("Tree read.");                                                                   /* itree.c:826 */
     utree_dev_info di;
     utree_dev_get_info(devs[0], &di);
@@ -126,8 +129,9 @@ int main(int argc, char *argv[]) {
     if (rc) { fprintf(stderr, "ERROR: %s\n", utree_strerror(rc)); exit(3); }
     printf("Good finds: %llu\n", (unsigned long long)st.good_finds);                      /* itree.c:1106 */
     printf("Searched %llu queries\n", (unsigned long long)st.n_reads);                    /* itree.c:1375 */
-    fprintf(stderr, "[utree_amd] search %.3f s (%.0f reads/s), GPU batches %.3f s\n", st.seconds_total,
-            st.seconds_total > 0 ? (double)st.n_reads / st.seconds_total : 0.0, st.seconds_kernels);
+    fprintf(stderr, "[utree_amd] search %.3f s (%.0f reads/s), GPU batches %.3f s%s\n", st.seconds_total,
+            st.seconds_total > 0 ? (double)st.n_reads / st.seconds_total : 0.0, st.seconds_kernels,
+            st.pipeline ? " (lane-seconds; framing and formatting on the GPU)" : "");
     for (int i = n_dev - 1; i >= 0; --i) utree_dev_free(devs[i]);
     utree_ctr_close(ctr);
     exit(0);

@@ -26,6 +26,7 @@
 #endif
 #include "ctr_host.h"
 #include "dev_image.h"
+#include "search_dev.h"
 
 #define CHUNK_BYTES ((size_t)96 << 20)        /* must hold two maximal (16 MiB) lines                    */
 #define MAX_READS_PER_BATCH ((size_t)2 << 20)  /* more reads in a chunk (tiny reads) simply take another batch */
@@ -335,6 +336,14 @@ static int search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const 
                        int do_rc, const utree_rank_params *rank, int host_threads, int input_format, utree_search_stats *stats) {
     if (!ctr || !devs || n_dev < 1 || !fasta_path || !out_path || input_format < 0 || input_format > UTREE_INPUT_AUTO) return UTREE_E_ARG;
     int rc = UTREE_OK;
+    /* The GG search on the reference's input format takes the device text pipeline (search_dev.c); it hands back input it
+     * does not take -- malformed records, NUL bytes, lines fgets would split -- and the host framing below then reproduces
+     * the reference on it case by case.  UTREE_HOST_TEXT=1 forces the host pipeline (tests, A/B). */
+    if (!rank && input_format == UTREE_INPUT_REFERENCE && !getenv("UTREE_HOST_TEXT")) {
+        rc = utree_search_file_device(ctr, devs, n_dev, fasta_path, out_path, do_rc, host_threads, stats);
+        if (rc != UTREE_RETRY_HOST) return rc;
+        rc = UTREE_OK;
+    }
     double t_start = now_s();
     pipe_t *P = (pipe_t *)calloc(1, sizeof *P);
     if (!P) return UTREE_E_NOMEM;
@@ -408,6 +417,9 @@ done:
     }
     P->st.seconds_total = now_s() - t_start;
     P->st.seconds_kernels = P->t_gpu;
+    P->st.pipeline = 0; P->st.n_lanes = 1;
+    P->st.seconds_read = P->t_read; P->st.seconds_frame = P->t_frame; P->st.seconds_classify_format = P->t_gpu;
+    P->st.seconds_d2h = P->t_format; P->st.seconds_write = P->t_write;
     if (getenv("UTREE_DEBUG") || getenv("UTREE_TIMING"))
         fprintf(stderr, "[utree_amd] stages: read %.3f s, frame %.3f s | gpu %.3f s | format %.3f s, write %.3f s (overlapped)\n",
                 P->t_read, P->t_frame, P->t_gpu, P->t_format, P->t_write);

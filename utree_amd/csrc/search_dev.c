@@ -1,0 +1,419 @@
+/* search_dev.c -- whole-file search with the byte work on the GPU (the "device text pipeline"): XT_doSearch32's GG branch
+ * (itree.c:833-1108) where the host only moves bytes.
+ *
+ *   file --pread--> pinned chunk --H2D--> [newline scan, framing | classify, vote | format] --D2H--> pinned text --pwrite--> file
+ *
+ * The reference frames reads under `omp critical` (itree.c:867-874) and prints under the stdio lock (1032, 1040, 1096); the
+ * round-1 pipeline (search.c) framed and formatted with host thread teams, which on a GPU box's CPU share (16 cores per
+ * GPU) cost more than everything else together.  Here a chunk of the FASTA is cut at a record boundary ("\n>": in
+ * well-formed input only header lines begin with '>'), goes to HBM as it stands, and comes back as its output text.
+ *
+ * Chunks are independent, so they are handed out to LANES -- host threads that each take the next chunk and carry it
+ * through all stages on their own stream and buffers; several lanes per GPU overlap one chunk's file read with another's
+ * kernels and a third's write, and with more GPUs the lanes simply belong to different devices (reads shard by chunk, no
+ * exchange).  The only ordering between chunks is the output offset: chunk c is written at the sum of the text lengths of
+ * the chunks before it, published in chunk order.
+ *
+ * Input the kernels do not take (NUL bytes, lines fgets would split, malformed records, records larger than a chunk,
+ * more reads or text per chunk than the buffers hold) makes the whole search return UTREE_RETRY_HOST: search.c then runs
+ * the file through the host framing, which reproduces the reference case by case on malformed input.
+ */
+#define _FILE_OFFSET_BITS 64
+#define _GNU_SOURCE
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <fcntl.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "ctr_host.h"
+#include "dev_image.h"
+#include "search_dev.h"
+#include "text_kernels.h"
+
+#define DCHUNK_BYTES ((size_t)64 << 20)
+#define DOUT_BYTES   ((size_t)128 << 20)       /* output text a chunk may produce                                  */
+#define DMAX_READS   ((uint32_t)4 << 20)       /* reads per chunk (a chunk of shorter records takes the host path)  */
+#define LINELEN_MAX 16777216u                  /* itree.c:836                                                      */
+#define MAX_LANES 64
+
+/* bytes per chunk: DCHUNK_BYTES; UTREE_CHUNK_BYTES lowers it (tests: many chunk boundaries in a small file) */
+static size_t chunk_bytes(void) {
+    const char *e = getenv("UTREE_CHUNK_BYTES");
+    if (e && atoll(e) >= 64 && (size_t)atoll(e) < DCHUNK_BYTES) return (size_t)atoll(e);
+    return DCHUNK_BYTES;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ---- per-device buffers, kept in the utree_dev between searches (pinned memory is slow to allocate) ---- */
+typedef struct {
+    hipStream_t stream;
+    uint8_t *h_in, *h_out;                      /* pinned                                                           */
+    utk_text_meta *h_meta;                      /* pinned                                                           */
+    uint8_t *d_in, *d_out;
+    uint32_t *d_counts, *d_nl, *d_seq_len, *d_name_off, *d_name_len, *d_line_len;
+    uint64_t *d_seq_off, *d_line_off;
+    utree_result *d_res;
+    utk_text_meta *d_meta;
+    void *d_scan, *d_ws;
+    size_t scan_bytes, ws_bytes;
+    int ws_rc;                                  /* do_rc the workspace was sized for                                */
+} lane_buf;
+
+struct utree_search_ctx {
+    int device, n_lanes;
+    uint32_t n_labels;
+    uint32_t *d_ix2rank;
+    lane_buf lane[MAX_LANES];
+};
+
+static void lane_free(lane_buf *b) {
+    if (b->h_in) hipHostFree(b->h_in);
+    if (b->h_out) hipHostFree(b->h_out);
+    if (b->h_meta) hipHostFree(b->h_meta);
+    void *dp[] = {b->d_in, b->d_out, b->d_counts, b->d_nl, b->d_seq_len, b->d_name_off, b->d_name_len, b->d_line_len, b->d_seq_off,
+                  b->d_line_off, b->d_res, b->d_meta, b->d_scan, b->d_ws};
+    for (size_t i = 0; i < sizeof dp / sizeof dp[0]; ++i) if (dp[i]) hipFree(dp[i]);
+    if (b->stream) hipStreamDestroy(b->stream);
+    memset(b, 0, sizeof *b);
+}
+
+void utree_search_ctx_free(void *p) {
+    struct utree_search_ctx *c = (struct utree_search_ctx *)p;
+    if (!c) return;
+    hipSetDevice(c->device);
+    for (int i = 0; i < c->n_lanes; ++i) lane_free(&c->lane[i]);
+    if (c->d_ix2rank) hipFree(c->d_ix2rank);
+    free(c);
+}
+
+#define HA(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return UTREE_E_NOMEM; } } while (0)
+static int lane_alloc(utree_dev *dev, lane_buf *b, int do_rc) {
+    if (!b->stream) {
+        if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return UTREE_E_HIP;
+        HA(hipHostMalloc((void **)&b->h_in, DCHUNK_BYTES + 64, hipHostMallocDefault));
+        HA(hipHostMalloc((void **)&b->h_out, DOUT_BYTES, hipHostMallocDefault));
+        HA(hipHostMalloc((void **)&b->h_meta, sizeof(utk_text_meta), hipHostMallocDefault));
+        HA(hipMalloc((void **)&b->d_in, DCHUNK_BYTES + 256));
+        HA(hipMalloc((void **)&b->d_out, DOUT_BYTES));
+        HA(hipMalloc((void **)&b->d_counts, (DCHUNK_BYTES / 4096 + 2) * 4));
+        HA(hipMalloc((void **)&b->d_nl, (size_t)2 * DMAX_READS * 4));
+        HA(hipMalloc((void **)&b->d_seq_off, (size_t)DMAX_READS * 8));
+        HA(hipMalloc((void **)&b->d_seq_len, (size_t)DMAX_READS * 4));
+        HA(hipMalloc((void **)&b->d_name_off, (size_t)DMAX_READS * 4));
+        HA(hipMalloc((void **)&b->d_name_len, (size_t)DMAX_READS * 4));
+        HA(hipMalloc((void **)&b->d_line_len, (size_t)DMAX_READS * 4));
+        HA(hipMalloc((void **)&b->d_line_off, (size_t)DMAX_READS * 8));
+        HA(hipMalloc((void **)&b->d_res, (size_t)DMAX_READS * sizeof(utree_result)));
+        HA(hipMalloc((void **)&b->d_meta, sizeof(utk_text_meta)));
+        b->scan_bytes = utk_text_scan_temp_bytes(DMAX_READS);
+        if (!b->scan_bytes) return UTREE_E_HIP;
+        HA(hipMalloc(&b->d_scan, b->scan_bytes));
+        b->ws_rc = -1;
+    }
+    if (b->ws_rc < do_rc) {                    /* the both-strands workspace also serves forward-only searches */
+        if (b->d_ws) { hipFree(b->d_ws); b->d_ws = NULL; }
+        b->ws_bytes = utree_classify_workspace_bytes(dev, DMAX_READS, DCHUNK_BYTES, LINELEN_MAX, do_rc);
+        if (!b->ws_bytes) return UTREE_E_ARG;
+        HA(hipMalloc(&b->d_ws, b->ws_bytes));
+        b->ws_rc = do_rc;
+    }
+    return UTREE_OK;
+}
+
+/* the device's context; lanes get their buffers on first use (lane_alloc), or all at once through utree_search_prepare */
+static int ctx_get(const utree_ctr *ctr, utree_dev *dev, int n_lanes, struct utree_search_ctx **out) {
+    if (hipSetDevice(dev->device) != hipSuccess) return UTREE_E_HIP;
+    struct utree_search_ctx *c = (struct utree_search_ctx *)dev->search_ctx;
+    if (c && c->n_labels != ctr->info.n_labels) { utree_search_ctx_free(c); dev->search_ctx = c = NULL; }
+    if (!c) {
+        c = (struct utree_search_ctx *)calloc(1, sizeof *c);
+        if (!c) return UTREE_E_NOMEM;
+        c->device = dev->device; c->n_labels = ctr->info.n_labels;
+        dev->search_ctx = c;
+        if (hipMalloc((void **)&c->d_ix2rank, ((size_t)c->n_labels + 1) * 4) != hipSuccess) return UTREE_E_NOMEM;
+        if (hipMemcpy(c->d_ix2rank, ctr->ix2rank, (size_t)c->n_labels * 4, hipMemcpyHostToDevice) != hipSuccess) return UTREE_E_HIP;
+    }
+    if (n_lanes > MAX_LANES) n_lanes = MAX_LANES;
+    if (n_lanes > c->n_lanes) c->n_lanes = n_lanes;
+    *out = c;
+    return UTREE_OK;
+}
+
+/* ---- the search --------------------------------------------------------------------------------------------------- */
+typedef struct dpipe dpipe;
+typedef struct {
+    dpipe *P;
+    utree_dev *dev;
+    lane_buf *b;
+    int read_threads;
+    pthread_t th;
+    double t_read, t_frame, t_classify, t_d2h, t_wait, t_wlock, t_write;
+    uint64_t chunks;
+} lane_t;
+
+struct dpipe {
+    const utree_ctr *ctr;
+    int fd, fo, do_rc;
+    off_t file_size;
+    size_t chunk_bytes;
+    pthread_mutex_t mu; pthread_cond_t cv;
+    pthread_mutex_t wmu;                        /* one pwrite at a time: writers of ONE file serialise on its inode anyway, and
+                                                 * concurrent ones only fight over it (tmpfs, measured: 4 writers 3.0 GB/s, one 5.7 GB/s) */
+    off_t next_off; uint64_t n_taken;           /* chunk dispenser                                                  */
+    uint64_t published; off_t cum_out;          /* chunks whose output offset is fixed; text bytes before the next  */
+    uint64_t n_reads, good, next_progress, bytes_in;
+    int rc, stop;                               /* first error; UTREE_RETRY_HOST = input for the host path          */
+    uint8_t tail[(64 << 10) + 8];
+};
+
+static void dfail(dpipe *P, int rc) {
+    pthread_mutex_lock(&P->mu);
+    if (!P->rc) P->rc = rc;
+    P->stop = 1;
+    pthread_cond_broadcast(&P->cv);
+    pthread_mutex_unlock(&P->mu);
+}
+
+/* Next chunk [off, off+len): ends after a '\n' that a '>' follows, or at the end of the file.  Called with the lock held.
+ * Returns 0 = none left, 1 = chunk, -1 = no record boundary inside a chunk's worth of bytes. */
+static int take_chunk(dpipe *P, off_t *off, size_t *len, int *final, uint64_t *index) {
+    if (P->next_off >= P->file_size) return 0;
+    const off_t a = P->next_off;
+    const size_t cb = P->chunk_bytes;
+    size_t want = (size_t)(P->file_size - a < (off_t)cb ? P->file_size - a : (off_t)cb);
+    if (a + (off_t)want == P->file_size) { *off = a; *len = want; *final = 1; *index = P->n_taken++; P->next_off = P->file_size; return 1; }
+    /* look backwards from the end of the range for "\n>", a window at a time (one more byte: the '>' may be the byte after) */
+    size_t hi = want;                                            /* candidates: newline positions < hi (relative to a) */
+    while (hi > 0) {
+        const size_t win = hi < (64u << 10) ? hi : (64u << 10), lo = hi - win;
+        size_t got = 0;
+        while (got < win + 1) {
+            ssize_t r = pread(P->fd, P->tail + got, win + 1 - got, a + (off_t)(lo + got));
+            if (r <= 0) return -1;
+            got += (size_t)r;
+        }
+        for (size_t i = win; i-- > 0;) {
+            if (P->tail[i] == '\n' && P->tail[i + 1] == '>') {
+                *off = a; *len = lo + i + 1; *final = 0; *index = P->n_taken++;
+                P->next_off = a + (off_t)(lo + i + 1);
+                return 1;
+            }
+        }
+        hi = lo;
+    }
+    return -1;
+}
+
+#define LH(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); dfail(P, UTREE_E_HIP); return NULL; } } while (0)
+#define LK(x) do { if ((x) != 0) { dfail(P, UTREE_E_HIP); return NULL; } } while (0)
+
+static void *lane_main(void *arg) {
+    lane_t *L = (lane_t *)arg;
+    dpipe *P = L->P;
+    lane_buf *b = L->b;
+    if (hipSetDevice(L->dev->device) != hipSuccess) { dfail(P, UTREE_E_HIP); return NULL; }
+    for (;;) {
+        off_t off = 0; size_t len = 0; int final = 0; uint64_t c = 0;
+        pthread_mutex_lock(&P->mu);
+        int got = P->stop ? 0 : take_chunk(P, &off, &len, &final, &c);
+        pthread_mutex_unlock(&P->mu);
+        if (got < 0) { dfail(P, UTREE_RETRY_HOST); return NULL; }
+        if (!got) return NULL;
+        if (!b->stream || b->ws_rc < P->do_rc) {                  /* first chunk of this lane: its buffers */
+            int arc = lane_alloc(L->dev, b, P->do_rc);
+            if (arc) { dfail(P, arc); return NULL; }
+        }
+        /* ---- file -> pinned memory (the page-cache copy), a small team ---- */
+        double t0 = now_s();
+        {
+            int T = L->read_threads, bad = 0;
+            if ((size_t)T > len / ((size_t)4 << 20) + 1) T = (int)(len / ((size_t)4 << 20) + 1);
+#pragma omp parallel for num_threads(T) schedule(static, 1) reduction(| : bad)
+            for (int t = 0; t < T; ++t) {
+                size_t a = len * (size_t)t / (size_t)T, e = len * (size_t)(t + 1) / (size_t)T;
+                while (a < e) {
+                    ssize_t r = pread(P->fd, b->h_in + a, e - a, off + (off_t)a);
+                    if (r <= 0) { bad |= 1; break; }
+                    a += (size_t)r;
+                }
+            }
+            if (bad) { dfail(P, UTREE_E_IO); return NULL; }
+        }
+        size_t n = len;
+        if (final && b->h_in[n - 1] != '\n') b->h_in[n++] = '\n';      /* the last line needs no newline (fgets ends at EOF) */
+        double t1 = now_s();
+        L->t_read += t1 - t0;
+        /* ---- newlines, framing ---- */
+        LH(hipMemcpyAsync(b->d_in, b->h_in, n, hipMemcpyHostToDevice, b->stream));
+        LK(utk_text_newlines(b->d_in, n, b->d_counts, b->d_nl, 2 * DMAX_READS, b->d_meta, b->stream));
+        LK(utk_text_frame(b->d_in, b->d_nl, DMAX_READS, (uint32_t)(n / 4 + 1), b->d_seq_off, b->d_seq_len, b->d_name_off, b->d_name_len,
+                          b->d_meta, b->stream));
+        LH(hipMemcpyAsync(b->h_meta, b->d_meta, sizeof(utk_text_meta), hipMemcpyDeviceToHost, b->stream));
+        LH(hipStreamSynchronize(b->stream));
+        double t2 = now_s();
+        L->t_frame += t2 - t1;
+        const utk_text_meta m1 = *b->h_meta;
+        if (m1.flags || (m1.n_lines & 1u) || m1.n_lines > 2 * DMAX_READS) { dfail(P, UTREE_RETRY_HOST); return NULL; }
+        const uint32_t nr = m1.n_lines / 2;
+        /* ---- classify (kernels.hip), then the output text ---- */
+        if (nr) {
+            int e = utree_classify_batch(L->dev, b->d_in, b->d_seq_off, b->d_seq_len, nr, m1.total_bases, m1.max_len, P->do_rc, b->d_res,
+                                         b->d_ws, b->ws_bytes, b->stream);
+            if (e) { dfail(P, e); return NULL; }
+            LK(utk_text_format(&L->dev->kimg, ((struct utree_search_ctx *)L->dev->search_ctx)->d_ix2rank, b->d_in, b->d_res, b->d_name_off,
+                               b->d_name_len, nr, b->d_line_len, b->d_line_off, b->d_scan, b->scan_bytes, b->d_out, DOUT_BYTES, b->d_meta, 0,
+                               b->stream));
+        }
+        LH(hipMemcpyAsync(b->h_meta, b->d_meta, sizeof(utk_text_meta), hipMemcpyDeviceToHost, b->stream));
+        LH(hipStreamSynchronize(b->stream));
+        double t3 = now_s();
+        L->t_classify += t3 - t2;
+        const utk_text_meta m2 = *b->h_meta;
+        if (m2.flags || m2.out_bytes > DOUT_BYTES) { dfail(P, UTREE_RETRY_HOST); return NULL; }
+        if (nr && m2.out_bytes) {
+            LK(utk_text_format(&L->dev->kimg, ((struct utree_search_ctx *)L->dev->search_ctx)->d_ix2rank, b->d_in, b->d_res, b->d_name_off,
+                               b->d_name_len, nr, b->d_line_len, b->d_line_off, b->d_scan, b->scan_bytes, b->d_out, DOUT_BYTES, b->d_meta, 1,
+                               b->stream));
+            LH(hipMemcpyAsync(b->h_out, b->d_out, (size_t)m2.out_bytes, hipMemcpyDeviceToHost, b->stream));
+        }
+        /* ---- the chunk's place in the output: after the text of every earlier chunk (input order, like one thread) ---- */
+        off_t base;
+        pthread_mutex_lock(&P->mu);
+        while (P->published != c && !P->stop) pthread_cond_wait(&P->cv, &P->mu);
+        if (P->stop) { pthread_mutex_unlock(&P->mu); hipStreamSynchronize(b->stream); return NULL; }
+        base = P->cum_out;
+        P->cum_out += (off_t)m2.out_bytes;
+        P->n_reads += nr; P->good += nr ? m2.good_finds : 0; P->bytes_in += len;
+        while (P->n_reads >= P->next_progress) {                                   /* itree.c:878 */
+            printf("Searched %llu queries...\n", (unsigned long long)P->next_progress);
+            P->next_progress += 1048576;
+        }
+        P->published++;
+        pthread_cond_broadcast(&P->cv);
+        pthread_mutex_unlock(&P->mu);
+        double t4 = now_s();
+        L->t_wait += t4 - t3;
+        LH(hipStreamSynchronize(b->stream));
+        double t5 = now_s();
+        L->t_d2h += t5 - t4;
+        size_t done = 0;
+        pthread_mutex_lock(&P->wmu);
+        double t6 = now_s();
+        while (done < (size_t)m2.out_bytes) {
+            ssize_t w = pwrite(P->fo, b->h_out + done, (size_t)m2.out_bytes - done, base + (off_t)done);
+            if (w <= 0) { pthread_mutex_unlock(&P->wmu); dfail(P, UTREE_E_IO); return NULL; }
+            done += (size_t)w;
+        }
+        pthread_mutex_unlock(&P->wmu);
+        L->t_wlock += t6 - t5;
+        L->t_write += now_s() - t6;
+        L->chunks++;
+    }
+}
+
+static int lanes_per_device(int n_dev) {
+    const char *e = getenv("UTREE_LANES");
+    if (e && atoi(e) >= 1 && atoi(e) <= 16) return atoi(e);
+    return n_dev <= 2 ? 4 : 3;
+}
+
+int utree_search_prepare(const utree_ctr *ctr, utree_dev **devs, int n_dev, int do_rc) {
+    if (!ctr || !devs || n_dev < 1) return UTREE_E_ARG;
+    const int K = lanes_per_device(n_dev);
+    for (int g = 0; g < n_dev; ++g) {
+        struct utree_search_ctx *c = NULL;
+        int rc = ctx_get(ctr, devs[g], K, &c);
+        for (int i = 0; !rc && i < K; ++i) rc = lane_alloc(devs[g], &c->lane[i], do_rc);
+        if (rc) return rc;
+    }
+    return UTREE_OK;
+}
+
+int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
+                             int do_rc, int host_threads, utree_search_stats *stats) {
+    const double t_start = now_s();
+    dpipe *P = (dpipe *)calloc(1, sizeof *P);
+    if (!P) return UTREE_E_NOMEM;
+    P->ctr = ctr; P->do_rc = do_rc; P->next_progress = 1048576;
+    P->fd = open(fasta_path, O_RDONLY);
+    P->fo = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);                   /* fopen(outfile, "wb"), itree.c:834 */
+    struct stat sb;
+    if (P->fd < 0 || P->fo < 0 || fstat(P->fd, &sb) != 0) {                       /* itree.c:835 */
+        if (P->fd >= 0) close(P->fd);
+        if (P->fo >= 0) close(P->fo);
+        free(P);
+        return UTREE_E_IO;
+    }
+    if (!S_ISREG(sb.st_mode)) { close(P->fd); close(P->fo); free(P); return UTREE_RETRY_HOST; }   /* a pipe: no pread */
+    P->file_size = sb.st_size;
+    P->chunk_bytes = chunk_bytes();
+    const int K = lanes_per_device(n_dev), n_lanes = K * n_dev;
+    int rc = UTREE_OK;
+    for (int g = 0; g < n_dev && !rc; ++g) { struct utree_search_ctx *c = NULL; rc = ctx_get(ctr, devs[g], K, &c); }
+#ifdef _OPENMP
+    if (host_threads <= 0) host_threads = omp_get_max_threads();
+#else
+    host_threads = 1;
+#endif
+    if (host_threads > 16 * n_dev) host_threads = 16 * n_dev;                     /* a GPU's share of the host cores */
+    int per_lane = host_threads / n_lanes;
+    if (per_lane < 1) per_lane = 1;
+    if (per_lane > 8) per_lane = 8;
+    lane_t *lanes = (lane_t *)calloc((size_t)n_lanes, sizeof(lane_t));
+    if (!lanes && !rc) rc = UTREE_E_NOMEM;
+    pthread_mutex_init(&P->mu, NULL);
+    pthread_mutex_init(&P->wmu, NULL);
+    pthread_cond_init(&P->cv, NULL);
+    if (!rc) {
+        int started = 0;
+        for (int i = 0; i < n_lanes; ++i) {                                       /* lane i: device i % n_dev, so consecutive chunks go to different GPUs */
+            lanes[i].P = P; lanes[i].dev = devs[i % n_dev];
+            lanes[i].b = &((struct utree_search_ctx *)devs[i % n_dev]->search_ctx)->lane[i / n_dev];
+            lanes[i].read_threads = per_lane;
+            if (pthread_create(&lanes[i].th, NULL, lane_main, &lanes[i])) { dfail(P, UTREE_E_NOMEM); break; }
+            ++started;
+        }
+        for (int i = 0; i < started; ++i) pthread_join(lanes[i].th, NULL);
+        rc = P->rc;
+    }
+    close(P->fd);
+    close(P->fo);
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_reads = P->n_reads; stats->good_finds = P->good;
+        stats->bytes_in = P->bytes_in; stats->bytes_out = (uint64_t)P->cum_out;
+        stats->pipeline = 1; stats->n_lanes = n_lanes;
+        for (int i = 0; lanes && i < n_lanes; ++i) {
+            stats->seconds_read += lanes[i].t_read; stats->seconds_frame += lanes[i].t_frame;
+            stats->seconds_classify_format += lanes[i].t_classify; stats->seconds_d2h += lanes[i].t_d2h;
+            stats->seconds_order_wait += lanes[i].t_wait + lanes[i].t_wlock; stats->seconds_write += lanes[i].t_write;
+        }
+        stats->seconds_kernels = stats->seconds_frame + stats->seconds_classify_format;
+        stats->seconds_total = now_s() - t_start;
+    }
+    if ((getenv("UTREE_DEBUG") || getenv("UTREE_TIMING")) && lanes && rc == UTREE_OK) {
+        double r = 0, f = 0, c = 0, d = 0, w = 0, o = 0;
+        for (int i = 0; i < n_lanes; ++i) { r += lanes[i].t_read; f += lanes[i].t_frame; c += lanes[i].t_classify; d += lanes[i].t_d2h; o += lanes[i].t_wait + lanes[i].t_wlock; w += lanes[i].t_write; }
+        fprintf(stderr, "[utree_amd] device text pipeline, %d lanes x %d read threads, lane-seconds: read %.3f | H2D+frame %.3f | classify+format %.3f | "
+                        "order + write-turn wait %.3f | D2H %.3f | write %.3f; wall %.3f s\n", n_lanes, per_lane, r, f, c, o, d, w, now_s() - t_start);
+    }
+    pthread_mutex_destroy(&P->mu);
+    pthread_mutex_destroy(&P->wmu);
+    pthread_cond_destroy(&P->cv);
+    free(lanes);
+    free(P);
+    return rc;
+}

@@ -1,0 +1,13 @@
+/* search_dev.h -- the device text pipeline of the whole-file search (search_dev.c), private. */
+#ifndef UTREE_SEARCH_DEV_H
+#define UTREE_SEARCH_DEV_H
+#include "utree_internal.h"
+
+/* not an error of the ABI: the input needs the host framing (search.c runs it next) */
+#define UTREE_RETRY_HOST 1000
+
+int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
+                             int do_rc, int host_threads, utree_search_stats *stats);
+void utree_search_ctx_free(void *ctx);
+
+#endif

@@ -134,8 +134,10 @@ int utk_rank_vote(const utk_image *im, utree_result *d_out, uint32_t n_reads, co
                   void *stream);
 int utk_rank_state(uint32_t n_reads, const utk_rank_ws *ws, void *stream);
 
-const char *utk_classify_short_name(uint32_t W, uint32_t I);
-const char *utk_classify_long_name(void);
+const char *utk_classify_short_name(const utk_image *im, uint32_t short_cap, int mid, int do_rc, char *buf, size_t cap);
+const char *utk_classify_long_name(const utk_image *im, char *buf, size_t cap);
+int utk_model_counts(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
+                     int do_rc, unsigned long long *d_counts, void *stream);
 
 #ifdef __cplusplus
 }

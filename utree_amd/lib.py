@@ -40,7 +40,10 @@ class FastaError(C.Structure):
 
 class SearchStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("good_finds", C.c_uint64), ("seconds_total", C.c_double),
-                ("seconds_kernels", C.c_double), ("fasta_error", FastaError)]
+                ("seconds_kernels", C.c_double), ("fasta_error", FastaError), ("pipeline", C.c_int), ("n_lanes", C.c_int),
+                ("seconds_read", C.c_double), ("seconds_frame", C.c_double), ("seconds_classify_format", C.c_double),
+                ("seconds_order_wait", C.c_double), ("seconds_d2h", C.c_double), ("seconds_write", C.c_double),
+                ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64)]
 
 
 class CompressStats(C.Structure):
@@ -89,6 +92,7 @@ SYMBOLS = {
                                        C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "utree_lookup_words": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "utree_classify_kernel_name": (C.c_char_p, [C.c_void_p]),
+    "utree_model_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "utree_classify_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "utree_fasta_frame": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(FastaError)]),
@@ -113,6 +117,7 @@ SYMBOLS = {
                                               C.c_int, C.c_int, C.POINTER(SearchStats)]),
     "utree_build_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                    C.POINTER(BuildStats)]),
+    "utree_search_prepare": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "utree_search_file": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
                                     C.POINTER(SearchStats)]),
 }

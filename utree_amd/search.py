@@ -262,6 +262,15 @@ class DeviceTree:
     def rank_reset(self):
         _lib.check(_lib.load().utree_rank_reset(self._h), "utree_rank_reset")
 
+    def model_counts(self, bases, off, length, rc: bool = False) -> dict:
+        """Measurement aid (bench.py's byte model): windows and distinct buckets / HBM lines per read of a batch."""
+        import torch
+        out = (C.c_uint64 * 5)()
+        stream = torch.cuda.current_stream(bases.device).cuda_stream
+        _lib.check(_lib.load().utree_model_counts(self._h, bases.data_ptr(), off.data_ptr(), length.data_ptr(), off.numel(), int(rc),
+                                                  out, stream), "utree_model_counts")
+        return dict(zip(("reads", "windows", "buckets", "lines128", "overflow_buckets"), [int(x) for x in out]))
+
     def kernel_name(self) -> str:
         return _lib.load().utree_classify_kernel_name(self._h).decode()
 
