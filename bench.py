@@ -9,13 +9,19 @@ One process per GPU.  A "step" is one pass of the hot path (reverse-complement s
 node lookup, tally, vote -> one 24-byte result per read) over one batch of reads that is already resident in
 HBM; the database image is resident too.  Reads shard across ranks (each rank has its own batches: weak
 scaling, no data-path collective); the only collective is the one-off RCCL broadcast of the database image
-from rank 0 before the timed region.  Rank 0 prints ONE JSON line.
+from rank 0 before the timed region, issued from C (utree_dev_replicate_rank).  Rank 0 prints ONE JSON line.
 
-Extra objects on that line (see DESIGN.md §6):
-  roofline      dominant kernel (classify_short_k): algorithmic bytes per launch / average launch duration
-                measured with HIP events on the launch stream, against 8 TB/s HBM peak.
-  cpu_baseline  (N=1 only) the CPU oracle (OpenMP port of the reference path) timed on this box's host cores
-                on a bounded sample of the same batches, and a parity check of the GPU results on that sample.
+Extra objects on that line (DESIGN.md section 6):
+  roofline      dominant kernel (classify_short_k): bytes the kernel must move per launch by the byte model of the image AS
+                BUILT (distinct 64-byte buckets per read, counted on the device) / average launch duration measured with
+                HIP events on the launch stream, against 8 TB/s; next to it the PMC-measured HBM fraction and the VALU / SALU
+                issue fractions from the kept profile (profiles/traffic.json) -- used only when that profile was taken from
+                exactly the kernel sources this library was built from; the SURVEY section 8(d) figure (per-window binary search,
+                which this image does not do) is kept as `contract_*` for reference only.
+  cpu_baseline  (N=1 only) the genuine reference binary (and the CPU oracle port) timed on this box's host cores on a
+                bounded sample of the same batches, and a parity check of the GPU results on that sample.
+  e2e           (N=1 only) SURVEY section 8(d)'s metric as defined there: database resident -> output file closed, on a FASTA
+                file of the same 40 M reads through utree_search_file (C-ABI), with stage times and parity flags.
 """
 import argparse
 import json
@@ -28,10 +34,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: peak engine clock
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMD16
 
 
-def algorithmic_bytes_per_read(n_nodes: int, W: int, I: int, read_len: int):
-    """B_win = 8 + SZ*(ceil(log2(nbar))+1);  B_read = windows*B_win + L + 24."""
+def contract_bytes_per_read(n_nodes: int, W: int, I: int, read_len: int):
+    """B_win = 8 + SZ*(ceil(log2(nbar))+1);  B_read = windows*B_win + L + 24 -- the traffic of the
+    REFERENCE's per-window bin search (itree.c:699-707, 720-730), which the bucketed image replaces."""
     SZ = W + I - 3
     k = 4 * W
     nbar = n_nodes / float(1 << 24)
@@ -50,7 +59,8 @@ def main():
     ap.add_argument("--batch-reads", type=int, default=4_000_000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--kmer", type=int, default=32, choices=(32, 64))
-    ap.add_argument("--distinct-batches", type=int, default=3)
+    ap.add_argument("--distinct-batches", type=int, default=0,
+                    help="distinct read batches resident in HBM (0 = one per timed step: no batch is classified twice in the timed region)")
     ap.add_argument("--fine-bits", type=int, default=-1)
     ap.add_argument("--rc", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the batches alternate over (batch i+1's lookups overlap batch i's vote)")
@@ -59,8 +69,13 @@ def main():
     ap.add_argument("--no-reference-baseline", action="store_true", help="cpu_baseline from the oracle port only")
     ap.add_argument("--reference-threads", type=int, default=16, help="threads for the genuine reference (its best on a 256-core box)")
     ap.add_argument("--reference-reads", type=int, default=1_000_000)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file -> file leg")
+    ap.add_argument("--e2e-reads", type=int, default=0, help="reads of the file -> file leg (0 = steps x batch-reads, config 2: 40 M)")
+    ap.add_argument("--model-reads", type=int, default=200_000, help="reads of batch 0 the byte model's bucket counts are taken on")
+    ap.add_argument("--replicate", default="c", choices=("c", "torch"),
+                    help="N>1: image broadcast issued from C (utree_dev_replicate_rank, RCCL) or through torch.distributed.broadcast")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse on one GPU")
-    ap.add_argument("--share-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--share-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo --replicate torch)")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line: libraries that chat on fd 1 (RCCL prints a version banner there when its
@@ -73,6 +88,7 @@ def main():
     import torch
     import torch.distributed as dist
     from utree_amd import dist as udist
+    from utree_amd import lib as ulib
     from utree_amd import synth
     from utree_amd.search import CtrDB, DeviceTree
 
@@ -93,30 +109,57 @@ def main():
             dist.init_process_group(args.backend)
     W = args.kmer // 4
     want_cpu = (world == 1 and not args.no_cpu_baseline)
+    want_e2e = (world == 1 and not args.no_e2e)
 
     # ---- database: rank 0 builds the image in HBM, the others receive it by ONE broadcast (RCCL / xGMI) ----
     t0 = time.time()
     bcast_s = 0.0
+    bcast_how = ""
+    sdb = None
     if rank == 0:
-        sdb = synth.make_db(dev, args.nodes, W=W, fine_bits=args.fine_bits, keep_raw=want_cpu)
+        sdb = synth.make_db(dev, args.nodes, W=W, fine_bits=args.fine_bits, keep_raw=(want_cpu or want_e2e))
         tree, ctr = sdb.tree, sdb.ctr
     if dist_on:
+        def ctr_of_rank(m):
+            dummy_bins = np.zeros((1 << 24) + 1, dtype=np.uint64)
+            dummy_bins[-1] = m["n_nodes"]
+            return CtrDB.from_memory(m["W"], 2, m["n_nodes"], dummy_bins, None, m["label_text"])
         meta = None
         if rank == 0:
             used = tree.image_ptr()[1]                      # the built image may be smaller than its allocation
             meta = dict(label_text=sdb.label_text, image_bytes=used, W=W, n_nodes=args.nodes)
-        image, m, bcast_s = udist.broadcast_image(tree.image_tensor()[:used] if rank == 0 else None, meta, 0, dev)
+        use_c = args.replicate == "c" and args.backend == "nccl" and not args.share_gpu0
+        if use_c:
+            # the broadcast itself is issued from C (ncclCommInitRank + one ncclBroadcast); torch.distributed only carries
+            # the unique id and the metadata.  If any rank reports an error, every rank falls back to torch's broadcast.
+            ok = 1
+            try:
+                t_c, c2, m, bcast_s = udist.replicate_image_c(tree if rank == 0 else None, ctr_of_rank, meta, 0, local)
+            except Exception as ex:
+                print("[bench] utree_dev_replicate_rank failed on rank %d: %r" % (rank, ex), file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use_c = bool(flag.item())
+            if use_c:
+                tree = t_c
+                if rank != 0:
+                    ctr = c2
+                bcast_how = "one ncclBroadcast issued from C (utree_dev_replicate_rank)"
+        if not use_c:
+            image, m, bcast_s = udist.broadcast_image(tree.image_tensor()[:used] if rank == 0 else None, meta, 0, dev)
+            if rank != 0:
+                ctr = ctr_of_rank(m)
+                tree = DeviceTree.attach(ctr, image, local)
+            bcast_how = "torch.distributed.broadcast"
         if rank != 0:
-            dummy_bins = np.zeros((1 << 24) + 1, dtype=np.uint64)
-            dummy_bins[-1] = m["n_nodes"]
-            ctr = CtrDB.from_memory(m["W"], 2, m["n_nodes"], dummy_bins, None, m["label_text"])
-            tree = DeviceTree.attach(ctr, image, local)
             sdb = synth.SynthDB(ctr=ctr, tree=tree, n_nodes=m["n_nodes"], W=m["W"], block=max(1, m["n_nodes"] // synth.N_LABELS),
                                 seed=synth.DB_SEED, tree2file=torch.zeros(1, device=dev), label_text=m["label_text"])
     db_s = time.time() - t0
 
     # ---- reads: each rank's own batches, resident in HBM before the timed region ----
-    nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
+    nb = args.distinct_batches if args.distinct_batches > 0 else args.steps
+    nb = max(1, min(nb, args.steps + args.warmup))
     batches = [synth.make_reads(sdb, args.batch_reads, args.read_len, seed=synth.READ_SEED + 1000 * rank + b, device=dev)
                for b in range(nb)]
     total_bases = args.batch_reads * args.read_len
@@ -128,14 +171,15 @@ def main():
 
     def step(i):
         # consecutive batches alternate over the streams (each with its own workspace and result buffer), the way a
-        # double-buffered host pipeline submits them; every step is still one complete pass of the hot path
+        # double-buffered host pipeline submits them; every step is still one complete pass of the hot path.
+        # The timed steps take batches 0 .. steps-1: with the default (one distinct batch per step) none is classified twice.
         b = batches[i % nb]
         with torch.cuda.stream(streams[i % ns]):
             tree.classify(b.bases, b.off, b.length, rc=bool(args.rc), total_bases=total_bases, max_len=args.read_len,
                           out=outs[i % nb], workspace=wss[i % ns])
 
     for i in range(args.warmup):
-        step(i)
+        step(nb - 1 - (i % nb))
     torch.cuda.synchronize()
     tree.kernel_time(reset=True)                 # switches the HIP-event bracket of the dominant kernel on
     if dist_on:
@@ -143,7 +187,7 @@ def main():
     torch.cuda.synchronize()
     t1 = time.time()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(i)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -156,40 +200,37 @@ def main():
     if rank == 0:
         reads_total = world * args.batch_reads * args.steps
         value = reads_total / elapsed
-        b_read, b_win, windows = algorithmic_bytes_per_read(args.nodes, W, 2, args.read_len)
-        if args.rc:
-            b_read = 2 * windows * b_win + args.read_len + 24
         avg_launch_s = (k_ms / 1e3) / max(1, k_launches)
-        achieved = b_read * args.batch_reads / avg_launch_s / 1e9 if k_launches else None
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                key = "nodes=%d,reads=%d,len=%d" % (args.nodes, args.batch_reads, args.read_len)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        nfound = int((outs[(args.warmup + args.steps - 1) % nb][:, 2] > 0).sum().item())
+        kernel_sig = tree.kernel_name()
+        roof = roofline(args, tree, batches[0], outs[0], W, avg_launch_s, k_launches, kernel_sig, ulib)
+        nfound = int((outs[(args.steps - 1) % nb][:, 2] > 0).sum().item())
         line = {
             "metric": "reads classified/sec, 8 GB L2 CTR, 150 bp reads",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64" if W == 8 else "u128", "data": "synthetic",
             "config": {"workload": "configs[1]: %.3g-node synthetic L2 CTR (k=%d, %d labels, image %.1f GiB, fine_bits=%d), "
-                                   "%d x %d bp reads per GPU (%d steps x %d-read batches), RC=%d"
+                                   "%d x %d bp reads per GPU (%d steps x %d-read batches, %d distinct batches resident in HBM), RC=%d"
                                    % (args.nodes, args.kmer, synth.N_LABELS, tree.info.image_bytes / 2**30, tree.info.fine_bits,
-                                      args.batch_reads * args.steps, args.read_len, args.steps, args.batch_reads, args.rc),
+                                      args.batch_reads * args.steps, args.read_len, args.steps, args.batch_reads, nb, args.rc),
                        "parallelism": "reads sharded over %d GPU(s), CTR image replicated%s; batches alternate over %d HIP stream(s) per GPU" %
-                                      (world, " by one RCCL broadcast (%.2f s)" % bcast_s if dist_on else "", ns)},
-            "roofline": {"bound": "hbm", "kernel": tree.kernel_name(), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes_per_read": b_read, "reads_per_launch": args.batch_reads,
-                         "avg_launch_ms": 1e3 * avg_launch_s, "launches": int(k_launches)},
+                                      (world, " by %s (%.2f s)" % (bcast_how, bcast_s) if dist_on else "", ns)},
+            "roofline": roof,
             "db_build_seconds": db_s, "classified_fraction_last_batch": nfound / args.batch_reads,
         }
-        if want_cpu:
-            line["cpu_baseline"] = cpu_baseline(args, sdb, batches[0], outs, tree, total_bases)
+        files = None
+        try:
+            if want_cpu or want_e2e:
+                files = BenchFiles(args, sdb)
+            if want_cpu:
+                line["cpu_baseline"] = cpu_baseline(args, sdb, batches[0], tree, total_bases, files)
+            if want_e2e:
+                del batches[1:], outs[1:], wss[:]
+                torch.cuda.empty_cache()
+                line["e2e"] = e2e_leg(args, sdb, tree, files, line.get("cpu_baseline"))
+        finally:
+            if files:
+                files.cleanup()
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
@@ -199,7 +240,113 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, sdb, batch, outs, tree, total_bases):
+def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, ulib):
+    """The roofline object: a byte model derived from the image as built, the measured fractions from the kept profile
+    (only when it matches this library), and the SURVEY 8(d) contract figure as a labelled legacy number."""
+    import torch
+    L = args.read_len
+    nm = max(1, min(args.model_reads, batch.n))
+    # distinct 64-byte buckets / 128-byte lines per read, counted on the device with the load-time minimizer code
+    mc = tree.model_counts(batch.bases, batch.off[:nm], batch.length[:nm], rc=bool(args.rc))
+    reads = max(1, mc["reads"])
+    buckets = mc["buckets"] / reads
+    lines128 = mc["lines128"] / reads
+    over = mc["overflow_buckets"] / reads
+    # tally entries written for vote_k (reads with more than one distinct label), from the results of batch 0
+    multi = out0[:, 3] > 1
+    tally_entries = float(out0[multi, 3].sum().item()) / batch.n
+    # bytes a read must move: its bases, each distinct bucket once (+ one more 64-byte fetch where the bucket overflows into
+    # the sorted records), its 24-byte result and its (rank, count) list
+    model = L + 64.0 * (buckets + over) + 24.0 + 8.0 * tally_entries
+    achieved = model * args.batch_reads / avg_launch_s / 1e9 if k_launches else None
+    contract, b_win, windows = contract_bytes_per_read(args.nodes, W, 2, L)
+    if args.rc:
+        contract = 2 * windows * b_win + L + 24
+    roof = {"bound": "hbm", "kernel": kernel_sig, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+            "algorithmic_bytes_per_read": model,
+            "model": {"what": "bases + 64 B x distinct buckets (+64 B per overflowing bucket) + 24 B result + 8 B x tally entries",
+                      "sample_reads": mc["reads"], "windows_per_read": mc["windows"] / reads, "distinct_buckets_per_read": buckets,
+                      "distinct_128B_lines_per_read": lines128, "overflow_buckets_per_read": over, "tally_entries_per_read": tally_entries,
+                      "bytes_if_hbm_delivers_128B_lines": L + 128.0 * lines128 + 24.0 + 8.0 * tally_entries},
+            "reads_per_launch": args.batch_reads, "avg_launch_ms": 1e3 * avg_launch_s, "launches": int(k_launches),
+            "contract_bytes_per_read": contract,
+            "contract_frac_legacy": (contract * args.batch_reads / avg_launch_s / 1e9 / HBM_PEAK_GBS) if k_launches else None,
+            "contract_note": "SURVEY 8(d): traffic of the reference's per-window bin search (itree.c:699-707), which this image replaces by "
+                             "shared bucket lines; not a roofline fraction of this kernel (can exceed 1)"}
+    # measured fractions: only from a profile of exactly this kernel
+    prof = {"source": "profiles/traffic.json", "used": False}
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tp))
+        key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (args.nodes, args.batch_reads, L, args.kmer, args.rc)
+        e = tj.get(key)
+        src_hash = ulib.kernel_source_sha256()
+        if e is None:
+            prof["why_not"] = "no entry for %s" % key
+        elif e.get("kernel_source_sha256") != src_hash:
+            prof["why_not"] = "stale: profiled kernel sources %s..., this library %s..." % (str(e.get("kernel_source_sha256"))[:12], src_hash[:12])
+        elif kernel_sig not in e.get("kernel", ""):
+            prof["why_not"] = "kernel differs: profile has %s" % e.get("kernel")
+        else:
+            prof.update(used=True, kernel=e["kernel"], kernel_source_sha256=src_hash, profile_avg_launch_ms=e.get("avg_launch_ms"),
+                        summary=e.get("source"))
+            roof["traffic"] = e["hbm_bytes_per_launch"]
+            t_prof = e.get("avg_launch_ms", 1e3 * avg_launch_s) / 1e3       # counters and duration from the same (profiled) runs
+            roof["hbm_frac_measured"] = e["hbm_bytes_per_launch"] / t_prof / 1e9 / HBM_PEAK_GBS
+            if e.get("SQ_INSTS_VALU_per_launch"):
+                cyc = t_prof * PEAK_CLOCK_HZ
+                valu = e["SQ_INSTS_VALU_per_launch"] * 4.0 / (N_SIMD * cyc)       # a wave64 VALU instruction occupies its SIMD16 for 4 cycles
+                salu = e.get("SQ_INSTS_SALU_per_launch", 0.0) / (N_SIMD / 4 * cyc) # one scalar unit per CU
+                roof.update(valu_issue_frac=valu, salu_issue_frac=salu, issue_frac=max(valu, salu),
+                            issue_note="wave instructions x cycles each / (SIMDs x launch duration x %.1f GHz peak clock); "
+                                       "per read: %.0f VALU, %.0f SALU" % (PEAK_CLOCK_HZ / 1e9, e["SQ_INSTS_VALU_per_launch"] / args.batch_reads,
+                                                                         e.get("SQ_INSTS_SALU_per_launch", 0.0) / args.batch_reads))
+                fr = {"hbm (measured traffic)": roof["hbm_frac_measured"], "hbm (byte model)": roof["frac"] or 0.0,
+                      "valu issue": valu, "salu issue": salu}
+                roof["binding"] = max(fr, key=fr.get)
+    except Exception as ex:                                   # a broken profile file must not take the line down
+        prof["why_not"] = repr(ex)
+    roof["profile"] = prof
+    return roof
+
+
+class BenchFiles:
+    """The database as a real `.ctr` file and FASTA files in /dev/shm, shared by the cpu_baseline and e2e legs."""
+
+    def __init__(self, args, sdb):
+        import shutil
+        import tempfile
+        need = 12 * 2**30 + 200 * (args.e2e_reads or args.steps * args.batch_reads)
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * need else None
+        self.dir = tempfile.mkdtemp(prefix="utree_bench_", dir=base)
+        self.ctr_path = None
+        self.sdb = sdb
+
+    def path(self, name):
+        return os.path.join(self.dir, name)
+
+    def ctr(self):
+        import numpy as np
+        if self.ctr_path is None:
+            sdb = self.sdb
+            p = self.path("db.ctr")
+            records = sdb.records.cpu().numpy()
+            with open(p, "wb") as f:
+                f.write(np.array([sdb.W, 0, 2, sdb.n_nodes], dtype="<u8").tobytes())
+                f.write(sdb.binix.cpu().numpy().view(np.uint32).tobytes())
+                for lo in range(0, records.size, 1 << 30):
+                    f.write(records[lo:lo + (1 << 30)].tobytes())
+                f.write(sdb.label_text)
+            self.ctr_path = p
+        return self.ctr_path
+
+    def cleanup(self):
+        import shutil
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+
+def cpu_baseline(args, sdb, batch, tree, total_bases, files):
     """CPU baselines on this box's host cores, rank 0, N=1 only, on a bounded sample of batch 0:
 
     kind "reference": the GENUINE reference binary (oracle/_ref/xtree-searchGG, compiled from /root/reference by
@@ -209,13 +356,11 @@ def cpu_baseline(args, sdb, batch, outs, tree, total_bases):
         threads: profiles/r01/reference_thread_sweep.txt); database load time taken out with an empty-FASTA run.
     kind "port": the CPU oracle (oracle/, OpenMP parallel-for over reads, no input critical section) on all cores.
     Both also serve as parity checks of the GPU results on the sample."""
-    import hashlib
-    import shutil
     import subprocess
-    import tempfile
     import numpy as np
     import torch
     from oracle import orc
+    from utree_amd import synth
     cores = os.cpu_count() or 1
     L = batch.read_len
     cap = min(batch.n, 2_000_000)
@@ -239,6 +384,7 @@ def cpu_baseline(args, sdb, batch, outs, tree, total_bases):
     t0 = time.time()
     want = o.classify_batch(host, off[:n], ln[:n], rc=bool(args.rc), threads=cores)
     dt = time.time() - t0
+    del o, records
     got = res[:n].view(np.uint32)
     hit = want["found"] > 0
     multi = hit & (want["uix"] > 1)
@@ -252,25 +398,13 @@ def cpu_baseline(args, sdb, batch, outs, tree, total_bases):
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "xtree-searchGG" + ("-k64" if sdb.W == 16 else ""))
     if not os.path.exists(ref_bin) or args.no_reference_baseline:
         return out
-    tmp = None
     try:
-        base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 3 * records.nbytes else None
-        tmp = tempfile.mkdtemp(prefix="utree_bench_", dir=base)
-        ctr_path, fa, empty = os.path.join(tmp, "db.ctr"), os.path.join(tmp, "sample.fa"), os.path.join(tmp, "empty.fa")
-        with open(ctr_path, "wb") as f:
-            f.write(np.array([sdb.W, 0, 2, sdb.n_nodes], dtype="<u8").tobytes())
-            f.write(binix_u32.tobytes())
-            for lo in range(0, records.size, 1 << 30):
-                f.write(records[lo:lo + (1 << 30)].tobytes())
-            f.write(sdb.label_text)
+        ctr_path = files.ctr()
+        fa, empty = files.path("sample.fa"), files.path("empty.fa")
         T = args.reference_threads
-        nref = int(min(cap, max(50_000, args.reference_reads)))
-        seq = host[: nref * L].reshape(nref, L)
-        with open(fa, "wb") as f:
-            for i in range(nref):
-                f.write(b">r%d\n" % i)
-                f.write(seq[i].tobytes())
-                f.write(b"\n")
+        nref = int(min(cap, batch.n, max(50_000, args.reference_reads)))
+        sample = synth.SynthReads(bases=batch.bases[: nref * L], off=batch.off[:nref], length=batch.length[:nref], n=nref, read_len=L)
+        synth.fasta_tensor(sample, 0).cpu().numpy().tofile(fa)
         open(empty, "wb").close()
         rcarg = ["RC"] if args.rc else []
 
@@ -279,8 +413,8 @@ def cpu_baseline(args, sdb, batch, outs, tree, total_bases):
             subprocess.run([ref_bin, ctr_path, fasta, outp, str(T)] + rcarg, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            check=True, timeout=900)
             return time.time() - t
-        t_load = run(empty, os.path.join(tmp, "e.txt"))
-        t_all = run(fa, os.path.join(tmp, "ref.txt"))
+        t_load = run(empty, files.path("e.txt"))
+        t_all = run(fa, files.path("ref.txt"))
         search = max(1e-6, t_all - t_load)
         # parity: GPU results formatted by the product's formatter == the reference's lines (as a multiset:
         # the reference writes in thread-completion order)
@@ -289,8 +423,9 @@ def cpu_baseline(args, sdb, batch, outs, tree, total_bases):
         lens = np.array([len(b"r%d" % i) for i in range(nref)], dtype=np.uint32)
         names_off[1:] = np.cumsum(lens[:-1])
         ours = sdb.ctr.format(np.frombuffer(names, dtype=np.uint8), names_off, lens, res[:nref])
-        ref_lines = sorted(open(os.path.join(tmp, "ref.txt"), "rb").read().split(b"\n"))
+        ref_lines = sorted(open(files.path("ref.txt"), "rb").read().split(b"\n"))
         same = sorted(ours.split(b"\n")) == ref_lines
+        files.sample_reads = nref
         out = {"value": nref / search, "unit": "reads/s", "cores": T, "kind": "reference", "parity_ok": bool(same and ok),
                "sample": "genuine reference binary (itree.c -D SEARCH_GG), %d threads, first %d reads of batch 0 on the same "
                          "database written as a .ctr file: %.1f s total - %.1f s load-only run = %.2f s search; its output "
@@ -298,10 +433,88 @@ def cpu_baseline(args, sdb, batch, outs, tree, total_bases):
                "port": port}
     except Exception as e:  # the baseline must never take the benchmark line down
         out["reference_error"] = repr(e)
-    finally:
-        if tmp:
-            shutil.rmtree(tmp, ignore_errors=True)
     return out
+
+
+def e2e_leg(args, sdb, tree, files, cpu):
+    """SURVEY 8(d)'s metric as it defines it: reads in the FASTA / wall time from "database resident" to "output file closed"
+    (file read, H2D, framing, kernels, formatting, D2H, write), through utree_search_file on the resident image.  The FASTA holds
+    the bench's own read batches (seeds READ_SEED + b), so its first reads are the cpu_baseline sample: the head of the output
+    must equal the reference's lines for that sample.  Files live in /dev/shm (the reference baseline's do too)."""
+    import ctypes as C
+    import hashlib
+    import numpy as np
+    import torch
+    from utree_amd import lib as ulib
+    from utree_amd import synth
+    from utree_amd.search import search_gg
+    out = {"metric": "reads/s, FASTA file in -> classifications file closed, database image resident", "unit": "reads/s"}
+    try:
+        n_total = args.e2e_reads or args.steps * args.batch_reads
+        fa = files.path("reads.fa")
+        t0 = time.time()
+        with open(fa, "wb") as f:
+            done, b = 0, 0
+            while done < n_total:
+                n = min(args.batch_reads, n_total - done)
+                r = synth.make_reads(sdb, args.batch_reads, args.read_len, seed=synth.READ_SEED + b, device=tree_device(tree))
+                if n < args.batch_reads:
+                    r = synth.SynthReads(bases=r.bases[: n * args.read_len], off=r.off[:n], length=r.length[:n], n=n, read_len=args.read_len)
+                synth.fasta_tensor(r, done).cpu().numpy().tofile(f)
+                done += n
+                b += 1
+                del r
+        out["fasta_bytes"] = os.path.getsize(fa)
+        out["fasta_write_seconds"] = time.time() - t0
+        torch.cuda.empty_cache()
+        L = ulib.load()
+        arr = (C.c_void_p * 1)(tree._h)
+        ulib.check(L.utree_search_prepare(sdb.ctr._h, arr, 1, int(bool(args.rc))), "utree_search_prepare")   # buffers: part of "resident"
+        runs = []
+        for rep, target in enumerate(("out.txt", "out2.txt", "/dev/null")):
+            outp = target if target.startswith("/dev/") else files.path(target)
+            t0 = time.time()
+            code, st = search_gg(sdb.ctr, [tree], fa, outp, rc=bool(args.rc), threads=16)
+            wall = time.time() - t0
+            ulib.check(code, "utree_search_file")
+            runs.append({"output": "discarded (/dev/null)" if target == "/dev/null" else "file in /dev/shm", "wall_seconds": wall,
+                         "reads_per_second": st.n_reads / wall, "reads": int(st.n_reads), "lines": int(st.good_finds), "bytes_in": int(st.bytes_in),
+                         "bytes_out": int(st.bytes_out), "pipeline": "device text" if st.pipeline else "host text", "lanes": int(st.n_lanes),
+                         "lane_seconds": {"read": st.seconds_read, "h2d_frame": st.seconds_frame, "classify_format": st.seconds_classify_format,
+                                          "order_and_write_turn_wait": st.seconds_order_wait, "d2h": st.seconds_d2h, "write": st.seconds_write}})
+        best = max(runs[:2], key=lambda r: r["reads_per_second"])
+        out["value"] = best["reads_per_second"]
+        out["runs"] = runs
+        out["value_output_discarded"] = runs[2]["reads_per_second"]
+        out["write_GBps"] = best["bytes_out"] / max(1e-9, best["lane_seconds"]["write"]) / 1e9
+        out["bound"] = ("output file: %.2f GB of text into fresh page-cache pages of ONE file at %.1f GB/s (one writer; the kernel allocates "
+                        "tmpfs pages at ~5-6 GB/s whatever the thread count: tools/hostio_probe*.c, profiles/r02/hostio_*.txt); with the output "
+                        "discarded the same pipeline runs at %.0f M reads/s" % (best["bytes_out"] / 1e9, out["write_GBps"], runs[2]["reads_per_second"] / 1e6))
+        # parity: (1) both runs wrote the same bytes; (2) the head of the file == the reference's lines for the cpu_baseline sample
+        h1 = hashlib.sha256(open(files.path("out.txt"), "rb").read()).hexdigest()
+        h2 = hashlib.sha256(open(files.path("out2.txt"), "rb").read()).hexdigest()
+        out["output_sha256"] = h1
+        out["runs_identical"] = (h1 == h2)
+        nref = getattr(files, "sample_reads", 0)
+        if nref and os.path.exists(files.path("ref.txt")):
+            ref_lines = sorted(open(files.path("ref.txt"), "rb").read().split(b"\n"))
+            head = []
+            with open(files.path("out.txt"), "rb") as f:
+                for ln in f:
+                    if int(ln[1:ln.index(b"\t")]) >= nref:
+                        break
+                    head.append(ln.rstrip(b"\n"))
+            head.append(b"")
+            out["parity_head_vs_reference"] = (sorted(head) == ref_lines)
+            out["parity_sample"] = "lines of the first %d reads (input order) == the genuine reference's output on those reads (sorted)" % nref
+        out["parity_ok"] = bool(out["runs_identical"] and out.get("parity_head_vs_reference", True))
+    except Exception as e:
+        out["error"] = repr(e)
+    return out
+
+
+def tree_device(tree):
+    return "cuda:%d" % tree.info.device
 
 
 if __name__ == "__main__":

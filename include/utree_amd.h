@@ -116,6 +116,14 @@ int utree_dev_get_info(const utree_dev *dev, utree_dev_info *info);
 /* Replicate dev[0]'s image to the other devices with one ncclBroadcast (RCCL over xGMI) and attach it
  * there.  devices[0] must be dev0's device.  out[0] = dev0. */
 int utree_dev_replicate(const utree_ctr *ctr, utree_dev *dev0, const int *devices, int n_devices, utree_dev **out);
+/* The same broadcast with one PROCESS per GPU: the root makes an id (utree_rccl_unique_id, UTREE_RCCL_ID_BYTES bytes) and hands
+ * it to the other ranks over the launcher's control channel; every rank then calls utree_dev_replicate_rank with its own
+ * device.  Root: dev0 = its image, *out = dev0.  Others: dev0 = NULL, `ctr` may describe the database (checked against the
+ * image header) or be NULL; *out = a handle that owns the received copy. */
+#define UTREE_RCCL_ID_BYTES 128
+int utree_rccl_unique_id(void *id_out, size_t cap);
+int utree_dev_replicate_rank(const utree_ctr *ctr, utree_dev *dev0, int device, int rank, int world, int root, const void *id_bytes,
+                             size_t id_len, utree_dev **out);
 
 /* ------------------------------------------------------------------------------------------------
  * The hot path.  Replaces, for a batch of reads, the body of XT_doSearch32's GG branch:

@@ -356,10 +356,16 @@ def test_more_long_reads_than_resident_workgroups(torch_cuda, rc, tmp_path):
     assert got == out.read_bytes()
 
 
-def test_overflowing_buckets(torch_cuda, tmp_path):
+@pytest.mark.parametrize("run_max", [0, 20])
+def test_overflowing_buckets(torch_cuda, tmp_path, run_max, monkeypatch):
     """Hundreds of k-mers that share ONE minimizer land in one 64-byte bucket: 7 stay inline, the rest are reached through the
     bucket's overflow descriptor (binary search in the sorted records).  Such buckets are ~1 % at the design load and never
-    occur in the small fixtures, so this database is made of them (k = 32 and k = 64)."""
+    occur in the small fixtures, so this database is made of them (k = 32 and k = 64).
+    run_max = 20: the same database with the descriptor's range cut to 20 records (UTREE_BUCKET_RUN_MAX; the real limit is
+    2^22, e.g. millions of k-mers containing A^16, whose hash is 0) -- the runs then saturate, the bins of their nodes are
+    flagged and searched with the reference's probe sequence, and the database still loads and answers like the oracle."""
+    if run_max:
+        monkeypatch.setenv("UTREE_BUCKET_RUN_MAX", str(run_max))
     def mix32(x):
         x = np.uint32(x)
         with np.errstate(over="ignore"):
@@ -389,6 +395,7 @@ def test_overflowing_buckets(torch_cuda, tmp_path):
         ctrfile.write_ctr(ctr, W, 2, hi[order], lo[order], ix[order], labels)
         db = CtrDB.open(ctr)
         tree = DeviceTree.upload(db, 0)
+        assert (tree.info.irregular_bins > 0) == bool(run_max)
         o = orc.OracleDB.load(ctr)
         reads = [("h%d" % i, s) for i, s in enumerate(kmers)]
         reads += [("m%d" % i, s[:-1] + "ACGT"[("ACGT".index(s[-1]) + 1) & 3]) for i, s in enumerate(kmers[::3])]   # near misses

@@ -249,11 +249,19 @@ static int build_finish(builder *b, const void *d_binix_raw) {
         HIPCHK(hipMemsetAsync(b->d_counters, 0, 16, st));
         HIPCHK(hipMemcpyAsync(img, &d->hdr, sizeof d->hdr, hipMemcpyHostToDevice, st));   /* the kernels read the region table there */
         KCHK(utk_build_min(d->hdr.W, d->hdr.I, off64, coarse, recs, c0, d->hdr.n_min, (const uint64_t *)(img + offsetof(utree_image_header, regions)),
-                           d->hdr.n_slots, (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs), b->d_counters, st));
+                           d->hdr.n_slots, (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs),
+                           (uint32_t *)(img + d->hdr.off_irreg), b->d_counters, st));
         KCHK(utk_fill_recs_pad((uint64_t *)(img + d->hdr.off_mrecs) + d->hdr.n_min * d->hdr.rec_words, 8 * d->hdr.rec_words, st));
         HIPCHK(hipMemcpyAsync(counters, b->d_counters, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (counters[0]) { rc = UTREE_E_UNSUPPORTED; goto fail; }       /* >= 2^22 nodes share one table slot */
+        if (counters[0]) {
+            /* buckets with more nodes than an overflow descriptor can count (a minimizer shared by millions of k-mers, e.g.
+             * A^16, whose hash is 0): the bins of their nodes were flagged irregular, so their words take the reference's own
+             * probe sequence over the FILE records.  Any `.ctr` the reference loads is searched. */
+            d->hdr.flags |= UTREE_F_IRREGULAR;
+            d->hdr.n_irregular += counters[1];
+            if (timing_on()) fprintf(stderr, "[utree_amd] image: %llu bucket(s) beyond the overflow descriptor's range: %llu bins take the exact-probe path\n", counters[0], counters[1]);
+        }
         /* nothing reads the FILE records when every bin is ascending: leave them out of the image */
         if (!(d->hdr.flags & UTREE_F_IRREGULAR)) d->hdr.total_bytes = d->hdr.off_recs;
     }

@@ -152,7 +152,7 @@ __global__ void emit_k(const uint64_t *__restrict__ recs, uint64_t c0, const IDX
 // rest of the bucket stays flagged empty); a longer run leaves CAP-1 records inline and an overflow descriptor last.
 template <int W, int I>
 __global__ void bucket_k(const uint32_t *__restrict__ Hs, const uint64_t *__restrict__ mrecs, uint64_t base, uint64_t m,
-                         const uint64_t *__restrict__ regions, uint64_t *__restrict__ table, unsigned long long *overflow) {
+                         const uint64_t *__restrict__ regions, uint64_t *__restrict__ table, uint64_t run_max, unsigned long long *overflow) {
     // Hs / mrecs: this part's sorted hashes and records (a part = a range of whole buckets); base = MIN records in earlier parts
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = 8 / EW;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
@@ -173,11 +173,33 @@ __global__ void bucket_k(const uint32_t *__restrict__ Hs, const uint64_t *__rest
             for (int x = 0; x < EW; ++x) o[q * EW + x] = mrecs[(j + q) * EW + x];     // flag bits of a record are 0
         if (n > (uint64_t)CAP) {
             uint64_t rest = n - inl;
-            if (rest >= (1ull << 22)) { atomicAdd(overflow, 1ull); rest = (1ull << 22) - 1; }
+            // a run the 22-bit count cannot describe: the descriptor saturates (never followed: flag_saturated_k sends the words
+            // of these nodes' bins down the exact-probe path instead) and the bucket is counted
+            if (rest > run_max) { atomicAdd(overflow, 1ull); rest = (1ull << 22) - 1; }
 #pragma unroll
             for (int x = 0; x < EW; ++x) o[inl * EW + x] = 0;
             o[inl * EW + KW] = MFLAG_RUN | (rest << 40) | ((base + j + inl) & M40);
         }
+    }
+}
+
+// Nodes of a bucket whose run saturated its descriptor: their 24-bit bins are flagged irregular, so that every word of those
+// bins takes the reference's own probe sequence over the FILE records (exact_probe) and never reads the saturated descriptor's
+// count.  Only launched for a part in which bucket_k counted such a bucket (e.g. millions of k-mers that contain A^16, whose
+// hash is 0: all of them share the first bucket).
+template <int W, int I, typename OFF, typename IDX>
+__global__ void flag_saturated_k(const uint32_t *__restrict__ Hs, const IDX *__restrict__ idx, uint64_t m, uint64_t c0,
+                                 const OFF *__restrict__ coarse, const uint64_t *__restrict__ regions, const uint64_t *__restrict__ table,
+                                 uint32_t *irreg, unsigned long long *counters) {
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = 8 / EW;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t b; uint32_t hl;
+        bucket_of(regions, Hs[j], b, hl);
+        const uint64_t d = table[b * 8 + (uint64_t)(CAP - 1) * EW + KW];
+        if ((d >> 62) != 2 || ((d >> 40) & 0x3FFFFFull) != 0x3FFFFFull) continue;
+        const uint32_t p = bin_of<OFF>(coarse, c0 + (uint64_t)idx[j]);
+        const uint32_t bit = 1u << (p & 31);
+        if (!(__atomic_load_n(&irreg[p >> 5], __ATOMIC_RELAXED) & bit) && !(atomicOr(&irreg[p >> 5], bit) & bit)) atomicAdd(&counters[1], 1ull);
     }
 }
 
@@ -256,7 +278,7 @@ struct in_part {
 // nodes are handled in 2^pb parts by the top bits of the hash -- parts are contiguous in the final order.
 template <int W, int I, typename OFF, typename IDX>
 int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, const uint64_t *regions, uint64_t n_buckets,
-              uint64_t *table, uint64_t *mrecs, unsigned long long *d_overflow, hipStream_t st) {
+              uint64_t *table, uint64_t *mrecs, uint32_t *irreg, unsigned long long *d_overflow, hipStream_t st) {
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
     const uint64_t nslots = n_buckets * (8 / EW);                                      // entries, all flagged empty to begin with
     for (int x = 0; x < EW; ++x) fill_u64_k<<<grid_for(nslots), 256, 0, st>>>(table, nslots, x == KW ? MFLAG_EMPTY : 0ull, EW, x);
@@ -271,7 +293,10 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
     uint32_t nparts = 1;
     part_bounds pbnd;
     uint64_t cap = m, base = 0;
-    unsigned long long h_counts[65] = {0};
+    unsigned long long h_counts[65] = {0}, sat_seen = 0;
+    // longest run an overflow descriptor may describe (22-bit count, all ones = saturated); UTREE_BUCKET_RUN_MAX lowers it (tests)
+    uint64_t run_max = (1ull << 22) - 2;
+    { const char *e = getenv("UTREE_BUCKET_RUN_MAX"); if (e && atoll(e) > 0 && (uint64_t)atoll(e) < run_max) run_max = (uint64_t)atoll(e); }
     const bool chat = getenv("UTREE_TIMING") != nullptr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto done; } } while (0)
     CK(hipMalloc((void **)&H, m * 4)); CK(hipMalloc((void **)&K1, m * 8));
@@ -369,8 +394,18 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
         if ((rc = sort_pass32<IDX>(H, idx, idx2, Hg, Hg2, mq, tmp, t64, st))) goto done;             // minimizer hash
         // Hg2 now holds the sorted hashes but emit_k recomputes them from H[idx]: reuse Hg as the sorted-hash array
         emit_k<W, I, IDX><<<grid_for(mq), 256, 0, st>>>(recs, c0, idx, H, K1, K2, regions, mq, mrecs + base * EW, Hg);
-        bucket_k<W, I><<<grid_for(mq), 256, 0, st>>>(Hg, mrecs + base * EW, base, mq, regions, table, d_overflow);
+        bucket_k<W, I><<<grid_for(mq), 256, 0, st>>>(Hg, mrecs + base * EW, base, mq, regions, table, run_max, d_overflow);
         CK(hipGetLastError());
+        {
+            unsigned long long sat = 0;
+            CK(hipMemcpyAsync(&sat, d_overflow, 8, hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st));
+            if (sat != sat_seen) {                  // this part has saturated buckets: their nodes' bins take the exact-probe path
+                flag_saturated_k<W, I, OFF, IDX><<<grid_for(mq), 256, 0, st>>>(Hg, idx, mq, c0, coarse, regions, table, irreg, d_overflow);
+                CK(hipGetLastError());
+                sat_seen = sat;
+            }
+        }
         if (chat) { CK(hipStreamSynchronize(st)); fprintf(stderr, "[utree_amd] image: part %u sorted and emitted\n", q + 1); }
         base += mq;
     }
@@ -429,18 +464,19 @@ int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream) {
     return (int)hipGetLastError();
 }
 
-/* nodes [c0, c0+m) = what the (monotone) bin table reaches.  d_overflow[0] += slots with >= 2^22 nodes. */
+/* nodes [c0, c0+m) = what the (monotone) bin table reaches.  d_overflow[0] += buckets whose run saturates the descriptor,
+ * d_overflow[1] += bins newly flagged in d_irreg because of them. */
 int utk_build_min(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
-                  const uint64_t *d_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, unsigned long long *d_overflow,
-                  void *stream) {
+                  const uint64_t *d_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
+                  unsigned long long *d_overflow, void *stream) {
     int rc = 0;
     int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
         constexpr int W = decltype(w)::value, I = decltype(i)::value;
         hipStream_t st = (hipStream_t)stream;
         const bool idx64 = m >= 0xFFFFFFFFull;
-        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_overflow, st);
-        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_overflow, st);
-        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_overflow, st);
+        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
+        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
+        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
     });
     return rc ? rc : drc;
 }

@@ -52,3 +52,53 @@ done:
     free(comms); free(streams); free(images);
     return rc;
 }
+
+/* ---- one process per GPU (bench.py under torchrun, or any launcher that gives every rank one device) --------------------
+ * The same single broadcast, with a communicator built from a unique id the root hands to the other ranks over the
+ * launcher's own control channel (bench.py: torch.distributed's store).  Root: dev0 = its image.  Others: dev0 = NULL; the
+ * image size arrives first (an 8-byte broadcast), then the image, which is attached and owned by the returned handle. */
+int utree_rccl_unique_id(void *id_out, size_t cap) {
+    ncclUniqueId id;
+    if (!id_out || cap < sizeof id) return UTREE_E_ARG;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return UTREE_E_RCCL;
+    memcpy(id_out, &id, sizeof id);
+    return UTREE_OK;
+}
+
+int utree_dev_replicate_rank(const utree_ctr *ctr, utree_dev *dev0, int device, int rank, int world, int root, const void *id_bytes,
+                             size_t id_len, utree_dev **out) {
+    ncclUniqueId id;
+    if (!out || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || !id_bytes || id_len < sizeof id) return UTREE_E_ARG;
+    if ((rank == root) != (dev0 != NULL)) return UTREE_E_ARG;
+    if (dev0 && dev0->device != device) return UTREE_E_ARG;
+    *out = NULL;
+    if (world == 1) { *out = dev0; return UTREE_OK; }
+    memcpy(&id, id_bytes, sizeof id);
+    int rc = UTREE_OK;
+    ncclComm_t comm = NULL;
+    hipStream_t st = NULL;
+    unsigned long long *d_size = NULL, h_size = dev0 ? (unsigned long long)dev0->image_bytes : 0ull;
+    void *image = dev0 ? dev0->image : NULL;
+    if (hipSetDevice(device) != hipSuccess) return UTREE_E_HIP;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rc = UTREE_E_HIP; goto done; }
+    if (ncclCommInitRank(&comm, world, id, rank) != ncclSuccess) { rc = UTREE_E_RCCL; goto done; }
+    if (hipMalloc((void **)&d_size, 8) != hipSuccess) { rc = UTREE_E_NOMEM; goto done; }
+    if (hipMemcpyAsync(d_size, &h_size, 8, hipMemcpyHostToDevice, st) != hipSuccess) { rc = UTREE_E_HIP; goto done; }
+    if (ncclBroadcast(d_size, d_size, 8, ncclUint8, root, comm, st) != ncclSuccess) { rc = UTREE_E_RCCL; goto done; }
+    if (hipMemcpyAsync(&h_size, d_size, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = UTREE_E_HIP; goto done; }
+    if (h_size < UTREE_IMG_HEADER_BYTES) { rc = UTREE_E_FORMAT; goto done; }
+    if (!dev0 && hipMalloc(&image, (size_t)h_size) != hipSuccess) { image = NULL; rc = UTREE_E_NOMEM; goto done; }
+    if (ncclBroadcast(image, image, (size_t)h_size, ncclUint8, root, comm, st) != ncclSuccess) { rc = UTREE_E_RCCL; goto done; }
+    if (hipStreamSynchronize(st) != hipSuccess) { rc = UTREE_E_HIP; goto done; }
+    if (dev0) *out = dev0;
+    else {
+        rc = utree_dev_attach(ctr, device, image, (size_t)h_size, out);
+        if (!rc) { (*out)->owns = 1; image = NULL; }
+    }
+done:
+    if (comm) ncclCommDestroy(comm);
+    if (d_size) hipFree(d_size);
+    if (st) hipStreamDestroy(st);
+    if (!dev0 && image) hipFree(image);
+    return rc;
+}

@@ -78,7 +78,7 @@ int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_
 int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
                  uint32_t *d_irreg, unsigned long long *d_counters, void *stream);
 int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
-                  const uint64_t *d_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs,
+                  const uint64_t *d_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
                   unsigned long long *d_overflow, void *stream);
 int utk_compress_chunk(uint32_t W, uint32_t I, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
                        void *d_out, void *stream);

@@ -44,6 +44,25 @@ def broadcast_image(image, meta: Optional[dict], src: int, device):
     return image, meta, time.time() - t0
 
 
+def replicate_image_c(tree, ctr_of_rank, meta: Optional[dict], src: int, device_index: int):
+    """The same replication through the C-ABI (utree_dev_replicate_rank: ncclCommInitRank + ONE ncclBroadcast issued from C,
+    as north_star asks of the host orchestration).  torch.distributed only carries the control plane: the RCCL unique id and the
+    small metadata dict.  `ctr_of_rank(meta)` builds the non-source ranks' host-side database object from the metadata.
+    Returns (tree, ctr, meta, seconds)."""
+    import time
+    import torch.distributed as dist
+    from .search import DeviceTree
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [(meta, DeviceTree.rccl_unique_id()) if rank == src else None]
+    dist.broadcast_object_list(box, src=src)
+    meta, uid = box[0]
+    ctr = None if rank == src else ctr_of_rank(meta)
+    dist.barrier()
+    t0 = time.time()
+    tree = DeviceTree.replicate_rank(ctr, tree if rank == src else None, device_index, rank, world, src, uid)
+    return tree, ctr, meta, time.time() - t0
+
+
 def max_over_ranks(value: float, device) -> float:
     import torch
     import torch.distributed as dist

@@ -87,6 +87,9 @@ SYMBOLS = {
     "utree_dev_free": (None, [C.c_void_p]),
     "utree_dev_get_info": (C.c_int, [C.c_void_p, C.POINTER(DevInfo)]),
     "utree_dev_replicate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "utree_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "utree_dev_replicate_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                           C.POINTER(C.c_void_p)]),
     "utree_classify_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int]),
     "utree_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                        C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -121,6 +124,17 @@ SYMBOLS = {
     "utree_search_file": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
                                     C.POINTER(SearchStats)]),
 }
+
+
+def kernel_source_sha256() -> str:
+    """Content hash of the sources the search kernels are compiled from: a kept profile (profiles/traffic.json) is only valid
+    for the library built from exactly these files (bench.py checks it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "wave_common.hpp", "device_common.hpp", "utree_internal.h", "Makefile"):
+        with open(os.path.join(_HERE, "csrc", f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+    return h.hexdigest()
 
 
 class UtreeError(RuntimeError):

@@ -185,6 +185,24 @@ class DeviceTree:
                    "utree_dev_attach")
         return cls(h.value, db, keepalive=image)
 
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        """Root side of the one-process-per-GPU replication: the id every rank's communicator is built from."""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().utree_rccl_unique_id(buf, 128), "utree_rccl_unique_id")
+        return buf.raw
+
+    @classmethod
+    def replicate_rank(cls, db: Optional[CtrDB], tree: Optional["DeviceTree"], device: int, rank: int, world: int, root: int,
+                       uid: bytes) -> "DeviceTree":
+        """utree_dev_replicate_rank: ONE ncclBroadcast (RCCL over xGMI) of the root's flat image issued from C; the root
+        passes its tree and gets it back, the others pass tree=None and get a handle that owns the received copy."""
+        h = C.c_void_p()
+        _lib.check(_lib.load().utree_dev_replicate_rank(db._h if db is not None else None, tree._h if tree is not None else None,
+                                                        device, rank, world, root, uid, len(uid), C.byref(h)),
+                   "utree_dev_replicate_rank")
+        return tree if tree is not None else cls(h.value, db)
+
     def image_tensor(self):
         """The flat image as a torch uint8 tensor view (for broadcast); only when torch owns the memory."""
         return self._keep

@@ -205,6 +205,34 @@ def make_reads(db: SynthDB, n_reads: int, read_len: int = 150, seed: int = READ_
     return SynthReads(bases=seq.contiguous().view(-1), off=off, length=length, n=n_reads, read_len=read_len)
 
 
+def fasta_tensor(reads: SynthReads, first_index: int = 0):
+    """The same FASTA text as reads_to_fasta, assembled on the device (uint8 tensor): reads whose index has the same number of
+    digits have records of one size, so each such group is one 2-D byte tensor."""
+    import torch
+    dev = reads.bases.device
+    L = reads.read_len
+    seq = reads.bases.view(reads.n, L)
+    parts = []
+    lo = first_index
+    end = first_index + reads.n
+    while lo < end:
+        nd = len(str(lo))
+        hi = min(end, 10 ** nd)
+        cnt = hi - lo
+        rec = torch.empty((cnt, 2 + nd + 1 + L + 1), dtype=torch.uint8, device=dev)
+        rec[:, 0] = ord(">")
+        rec[:, 1] = ord("r")
+        idx = torch.arange(lo, hi, dtype=torch.int64, device=dev)
+        for d in range(nd):
+            rec[:, 2 + nd - 1 - d] = ((idx // (10 ** d)) % 10 + ord("0")).to(torch.uint8)
+        rec[:, 2 + nd] = ord("\n")
+        rec[:, 3 + nd: 3 + nd + L] = seq[lo - first_index: hi - first_index]
+        rec[:, 3 + nd + L] = ord("\n")
+        parts.append(rec.view(-1))
+        lo = hi
+    return torch.cat(parts) if len(parts) != 1 else parts[0]
+
+
 def reads_to_fasta(reads: SynthReads, first_index: int = 0) -> bytes:
     """FASTA text (headers `>r<index>`) of a SynthReads batch, for the CLI / CPU baselines."""
     seq = reads.bases.view(reads.n, reads.read_len).cpu().numpy()
