@@ -295,13 +295,23 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
             t_prof = e.get("avg_launch_ms", 1e3 * avg_launch_s) / 1e3       # counters and duration from the same (profiled) runs
             roof["hbm_frac_measured"] = e["hbm_bytes_per_launch"] / t_prof / 1e9 / HBM_PEAK_GBS
             if e.get("SQ_INSTS_VALU_per_launch"):
-                cyc = t_prof * PEAK_CLOCK_HZ
+                # cycles the launch had: GRBM_GUI_ACTIVE counts every XCD's active cycles (8 XCDs) at the clock the chip really
+                # ran at; without it, the launch duration at the peak clock
+                if e.get("GRBM_GUI_ACTIVE_per_launch"):
+                    cyc = e["GRBM_GUI_ACTIVE_per_launch"] / 8.0
+                    clock = "measured cycles (GRBM_GUI_ACTIVE / 8 XCDs = %.2f GHz over the launch)" % (cyc / t_prof / 1e9)
+                else:
+                    cyc = t_prof * PEAK_CLOCK_HZ
+                    clock = "launch duration x %.1f GHz peak clock" % (PEAK_CLOCK_HZ / 1e9)
                 valu = e["SQ_INSTS_VALU_per_launch"] * 4.0 / (N_SIMD * cyc)       # a wave64 VALU instruction occupies its SIMD16 for 4 cycles
                 salu = e.get("SQ_INSTS_SALU_per_launch", 0.0) / (N_SIMD / 4 * cyc) # one scalar unit per CU
                 roof.update(valu_issue_frac=valu, salu_issue_frac=salu, issue_frac=max(valu, salu),
-                            issue_note="wave instructions x cycles each / (SIMDs x launch duration x %.1f GHz peak clock); "
-                                       "per read: %.0f VALU, %.0f SALU" % (PEAK_CLOCK_HZ / 1e9, e["SQ_INSTS_VALU_per_launch"] / args.batch_reads,
-                                                                         e.get("SQ_INSTS_SALU_per_launch", 0.0) / args.batch_reads))
+                            valu_issue_frac_at_peak_clock=e["SQ_INSTS_VALU_per_launch"] * 4.0 / (N_SIMD * t_prof * PEAK_CLOCK_HZ),
+                            issue_note="wave instructions x cycles each (VALU 4 on a SIMD16, SALU 1 on the CU's scalar unit) / (units x %s); "
+                                       "per read: %.0f VALU, %.0f SALU, %.0f LDS, %.1f VMEM" %
+                                       (clock, e["SQ_INSTS_VALU_per_launch"] / args.batch_reads, e.get("SQ_INSTS_SALU_per_launch", 0.0) / args.batch_reads,
+                                        e.get("SQ_INSTS_LDS_per_launch", 0.0) / args.batch_reads,
+                                        (e.get("SQ_INSTS_VMEM_RD_per_launch", 0.0) + e.get("SQ_INSTS_VMEM_WR_per_launch", 0.0)) / args.batch_reads))
                 fr = {"hbm (measured traffic)": roof["hbm_frac_measured"], "hbm (byte model)": roof["frac"] or 0.0,
                       "valu issue": valu, "salu issue": salu}
                 roof["binding"] = max(fr, key=fr.get)

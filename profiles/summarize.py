@@ -33,7 +33,7 @@ for tag in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcc"):
     for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"]
         if "classify" in k or "vote_k" in k:
-            k = k.split("(")[0].replace("void (anonymous namespace)::", "").strip()
+            k = k.replace("void ", "", 1).replace("(anonymous namespace)::", "").split("(")[0].strip()
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[(k, r["Counter_Name"])] += 1
     for k, v in agg.items():
