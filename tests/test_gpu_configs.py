@@ -1,0 +1,104 @@
+"""BASELINE.json's configurations at FULL database size, through the C-ABI on the MI355X, against the CPU oracle on a sample
+and through size-independent properties (the fixtures in tests/golden pin the same code at toy size):
+
+  configs[1]  8 GB L2 CTR (1 217 000 000 32-mer nodes), 150 bp reads
+  configs[4]  PACKSIZE=64 build (568 000 000 64-mer nodes, the wide-key lookup path), 150 bp reads
+  configs[2]  500 MB L4 CTR (72 000 000 nodes), long reads (1-100 kb, mean ~10 kb), RC on: the mid-length pass and classify_long_k
+
+Databases and reads are seeded synthetic (utree_amd.synth); the oracle gets the same on-disk pieces (bin
+table + packed records + labels).  Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import orc
+from utree_amd import synth
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def oracle_of(sdb):
+    return orc.OracleDB.from_memory(sdb.W, 2, sdb.binix.cpu().numpy().view(np.uint32).astype(np.uint64), sdb.records.cpu().numpy(),
+                                    sdb.label_text)
+
+
+def assert_records_equal(got, want, n):
+    """got: int32 [n, 6] from the GPU; want: the oracle's record arrays."""
+    g = got[:n].view(np.uint32)
+    assert np.array_equal(g[:, 2], want["found"])
+    hit = want["found"] > 0
+    multi = hit & (want["uix"] > 1)
+    assert np.array_equal(g[hit, 3], want["uix"][hit])
+    assert np.array_equal(g[hit, 0], want["label"][hit])
+    assert np.array_equal(got[:n][hit, 1], want["cut"][hit])
+    assert np.array_equal(g[multi, 4], want["sl"][multi]) and np.array_equal(g[multi, 5], want["ol"][multi])
+    return int(hit.sum()), int(multi.sum())
+
+
+@pytest.mark.parametrize("W,nodes", [(8, 1_217_000_000), (16, 568_000_000)], ids=["config2_k32_1217M_nodes", "config5_k64_568M_nodes"])
+def test_150bp_reads_on_the_full_size_database(torch_cuda, W, nodes):
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    sdb = synth.make_db(dev, nodes, W=W, keep_raw=True)
+    n = 240_000
+    reads = synth.make_reads(sdb, n, 150, seed=synth.READ_SEED + 77)
+    for rc in (False, True):
+        got = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
+        again = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
+        assert torch.equal(got, again)                                                  # idempotent
+        if rc:
+            # strand symmetry: with RC on, the reverse complement of every read classifies identically
+            comp = torch.full((256,), ord("N"), dtype=torch.uint8, device=dev)
+            for a, b in zip(b"ACGTacgt", b"TGCAtgca"):
+                comp[a] = b
+            rcseq = comp[reads.bases.view(n, 150).long()].flip(1).contiguous().view(-1)
+            other = sdb.tree.classify(rcseq, reads.off, reads.length, rc=True)
+            assert torch.equal(got, other)
+        if not rc:
+            o = oracle_of(sdb)
+            host = reads.bases.cpu().numpy()
+            want = o.classify_batch(host, np.arange(n, dtype=np.uint64) * 150, np.full(n, 150, dtype=np.uint32), rc=False, threads=16)
+            hits, multi = assert_records_equal(got.cpu().numpy(), want, n)
+            assert hits > 0.9 * n and multi > 0.3 * n                                   # the sample exercises the vote
+            del o
+    perm = torch.randperm(n, device=dev)
+    shuffled = sdb.tree.classify(reads.bases, reads.off[perm], reads.length[perm], rc=False)
+    assert torch.equal(sdb.tree.classify(reads.bases, reads.off, reads.length, rc=False)[perm], shuffled)   # reads are independent
+    sdb.tree.close()
+
+
+def test_long_reads_with_both_strands_on_the_l4_size_database(torch_cuda):
+    """configs[2]: 72 M nodes; reads of 1 kb ... 100 kb (hit-dense: a planted k-mer every 32 bases), RC on."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    sdb = synth.make_db(dev, 72_000_000, W=8, keep_raw=True)
+    classes = [(1_000, 24_000), (2_000, 12_000), (3_000, 8_000), (10_000, 12_000), (30_000, 3_000), (100_000, 400)]   # (length, reads): ~25 kb... mean 5 kb
+    bases, offs, lens = [], [], []
+    at = 0
+    for i, (L, cnt) in enumerate(classes):
+        r = synth.make_reads(sdb, cnt, L, seed=synth.READ_SEED + 500 + i)
+        bases.append(r.bases)
+        offs.append(r.off + at)
+        lens.append(r.length)
+        at += cnt * L
+    bases, off, ln = torch.cat(bases), torch.cat(offs), torch.cat(lens)
+    n = off.numel()
+    perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(3))      # lengths interleaved, as a file would have them
+    off, ln = off[perm].contiguous(), ln[perm].contiguous()
+    got = sdb.tree.classify(bases, off, ln, rc=True)
+    assert "classify_long_k" in sdb.tree.kernel_name()
+    again = sdb.tree.classify(bases, off, ln, rc=True)
+    assert torch.equal(got, again)
+    o = oracle_of(sdb)
+    want = o.classify_batch(bases.cpu().numpy(), off.cpu().numpy().astype(np.uint64), ln.cpu().numpy().astype(np.uint32), rc=True, threads=16)
+    hits, multi = assert_records_equal(got.cpu().numpy(), want, n)
+    assert hits > 0.9 * n and multi > 0.5 * n
+    assert int(want["found"].max()) > 5000                                              # thousands of hits per read: the long tally paths
+    sdb.tree.close()
