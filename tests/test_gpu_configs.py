@@ -100,5 +100,5 @@ def test_long_reads_with_both_strands_on_the_l4_size_database(torch_cuda):
     want = o.classify_batch(bases.cpu().numpy(), off.cpu().numpy().astype(np.uint64), ln.cpu().numpy().astype(np.uint32), rc=True, threads=16)
     hits, multi = assert_records_equal(got.cpu().numpy(), want, n)
     assert hits > 0.9 * n and multi > 0.5 * n
-    assert int(want["found"].max()) > 5000                                              # thousands of hits per read: the long tally paths
+    assert int(want["found"].max()) > 3000                                              # thousands of hits per read: the long tally paths
     sdb.tree.close()

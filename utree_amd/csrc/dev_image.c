@@ -77,7 +77,7 @@ int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
 
 static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     memset(h, 0, sizeof *h);
-    h->magic = UTREE_IMG_MAGIC; h->version = 5;   /* 5: minimizers ordered by hash >> 9 */
+    h->magic = UTREE_IMG_MAGIC; h->version = 6;   /* 6: k = 32 / u16-label records keep the rest in their low word (scan_bucket82) */
     h->W = ctr->info.W; h->I = ctr->info.I; h->k = ctr->info.k;
     h->fine_bits = F; h->rec_words = utree_rec_words(h->W, h->I);
     h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
@@ -375,7 +375,7 @@ int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t byt
     if (!d) return UTREE_E_NOMEM;
     d->device = device; d->n_cu = n_cu; d->image = d_image; d->owns = 0;
     HIPCHK(hipMemcpy(&d->hdr, d_image, sizeof d->hdr, hipMemcpyDeviceToHost));
-    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 5 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
+    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 6 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
     if (ctr && (ctr->info.W != d->hdr.W || ctr->info.I != d->hdr.I || ctr->info.n_nodes != d->hdr.n_nodes ||
                 ctr->info.n_labels != d->hdr.n_labels)) { rc = UTREE_E_ARG; goto fail; }
     d->image_bytes = d->hdr.total_bytes;
@@ -499,6 +499,9 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
         if (e0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
     }
     KCHK(utk_vote(&d->kimg, d_out, &w, n_reads, st));
+#ifdef UTREE_PHASE_TIMERS
+    { extern void utk_phase_dump(void); static int calls; if (++calls == 12) utk_phase_dump(); }
+#endif
 fail:
     return rc;
 }

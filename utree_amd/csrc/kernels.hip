@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include "device_common.hpp"
 #include "wave_common.hpp"
 
@@ -21,13 +22,48 @@ using namespace utk;
 
 namespace {
 
+// Phase timers (measurement builds only, -DUTREE_PHASE_TIMERS): per-wave cycle counts between TICK()s, summed over all waves
+// into g_phase[] and printed by utk_phase_dump().  s_memtime is itself a scalar memory read (it waits for the wave's LDS
+// traffic), so the figures show where a wave's time goes, not exact costs.
+#ifdef UTREE_PHASE_TIMERS
+__device__ unsigned long long g_phase[16];
+struct PhaseT { unsigned long long t, acc[12]; };
+#define PH_DECL PhaseT ph_; ph_.t = __builtin_readcyclecounter(); for (int q_ = 0; q_ < 12; ++q_) ph_.acc[q_] = 0;
+#define TICKP(ph, i) do { const unsigned long long n_ = __builtin_readcyclecounter(); (ph).acc[i] += n_ - (ph).t; (ph).t = n_; } while (0)
+#define TICK(i) TICKP(ph_, i)
+#define PH_ARG , PhaseT &ph_
+#define PH_PASS , ph_
+#define PH_WAITVM asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define PH_DECL
+#define TICK(i)
+#define PH_ARG
+#define PH_PASS
+#define PH_WAITVM
+#endif
+
 
 constexpr uint32_t KEY_TILE = 128;                    // windows per sliding-minimizer tile (256 where the LDS budget allows)
 
-// 32 bits (16 bases) of the packed stream starting at base j
-__device__ __forceinline__ uint32_t mmer_at(const uint32_t *sw, uint32_t j) {
-    const uint32_t w = j >> 4, sh = 32u - ((j & 15u) << 1);
-    return (uint32_t)((((uint64_t)sw[w] << 32) | sw[w + 1]) >> sh);
+// Every 16-mer or window word a lane extracts from the packed 2-bit stream starts at a base index congruent to its lane id
+// mod 64 (tiles and rounds start at multiples of 64 bases), so the two words it straddles sit at a fixed per-lane offset from
+// a wave-uniform word index and its shift never changes: one v_alignbit_b32 per 32 bits, no per-use address arithmetic.
+//   lane & 15 = r != 0: bits = ({sw[q], sw[q+1]} >> (32 - 2r)) low 32     r == 0: bits = sw[q] = ({sw[q-1], sw[q]} >> 0) low 32
+// (sw[-1] must be readable: the callers' arrays carry a pad word in front).
+struct LaneBits {
+    const uint32_t *swl;      // sw + (lane >> 4) - (r == 0)
+    uint32_t sh;              // (32 - 2r) & 31
+};
+__device__ __forceinline__ LaneBits lane_bits(const uint32_t *sw, uint32_t lane) {
+    LaneBits b;
+    const uint32_t r = lane & 15u;
+    b.swl = sw + (lane >> 4) - (r == 0 ? 1u : 0u);
+    b.sh = (32u - 2u * r) & 31u;
+    return b;
+}
+// 16 bases (32 bits) starting at base 16 * word + lane of the stream `s` points into (s = lb.swl + a uniform word index)
+__device__ __forceinline__ uint32_t mmer_l(const uint32_t *s, uint32_t word, uint32_t sh) {
+    return __builtin_amdgcn_alignbit(s[word], s[word + 1], sh);
 }
 
 // Sliding minimizers for a tile of windows, shared by the lanes of one wave (each 16-mer is hashed ONCE instead of
@@ -35,87 +71,182 @@ __device__ __forceinline__ uint32_t mmer_at(const uint32_t *sw, uint32_t j) {
 // without its MIN_LOW_BITS low bits, leftmost on ties -- which makes a 32-bit key { hash bits | position in the tile }
 // enough, and the sliding minimum one v_min_u32 per step.  After the call, for the window that starts at tile position t:
 //     p = min(Kk[t], Kk[t + NEXT]) & MIN_POS_MASK  =  tile position of its minimizer,  Hh[p] = that 16-mer's full hash,
-// the same (h, pos) minimizer<W>() computes from the word.  Kk and Hh need (nch + 1) * 64 entries.
+// the same (h, pos) minimizer<W>() computes from the word.  Kk and Hh need (NCH + 1) * 64 entries.
 // In place: step s replaces K[t] by min(K[t], K[t+s]); chunks ascend, so chunk c still sees chunk c+1's old values.
+// Straight-line per chunk count NCH (the dispatcher below picks it): all LDS offsets are immediates off the per-lane
+// pointers Kl = Kk + lane, Hl = Hh + lane.  Positions past the read's last full 16-mer hash stale bytes; no valid window
+// looks at them (a window's 16-mers lie inside the read).
 constexpr uint32_t MIN_POS_MASK = (1u << MIN_LOW_BITS) - 1u;       // a tile has < 2^MIN_LOW_BITS positions
 template <int W> struct MinWin { static constexpr uint32_t NEXT = (W == 16) ? 17u : 1u; };   // [t,t+16)+[t+1,t+17) / [t,t+32)+[t+17,t+49)
-template <int W>
-__device__ __forceinline__ void build_minkeys(const uint32_t *sw, uint32_t *Kk, uint32_t *Hh, uint32_t pos0, uint32_t npos,
-                                              uint32_t pos_cap, uint32_t lane) {
-    const uint32_t nch = (npos + 63) >> 6;
-    for (uint32_t c = 0; c < nch; ++c) {
-        const uint32_t t = c * 64 + lane, j = pos0 + t;
-        uint32_t key = ~0u, h = 0;
-        if (j < pos_cap) { h = mix32(mmer_at(sw, j)); key = (h & ~MIN_POS_MASK) | t; }
-        Kk[t] = key; Hh[t] = h;
-    }
-    Kk[nch * 64 + lane] = ~0u;
-    wave_lds_fence();
+template <int W, uint32_t NCH>
+__device__ __forceinline__ void build_minkeys_n(const uint32_t *s, uint32_t sh, uint32_t *Kl, uint32_t *Hl, uint32_t lane) {
+    uint32_t x[NCH];
 #pragma unroll
-    for (uint32_t s = 1; s <= ((W == 16) ? 16u : 8u); s <<= 1) {
-        for (uint32_t c = 0; c < nch; ++c) {
-            const uint32_t t = c * 64 + lane;
-            const uint32_t a = Kk[t], b = Kk[t + s];
-            wave_lds_fence();
-            Kk[t] = b < a ? b : a;
-            wave_lds_fence();
-        }
+    for (uint32_t c = 0; c < NCH; ++c) x[c] = mmer_l(s, 4 * c, sh);          // all chunks' words are requested before the first is hashed
+    // (the lane id through an opaque move: otherwise the compiler keeps lane | 64, lane | 128, ... in registers of their own for
+    // the whole kernel, and the 64 registers that 8 waves per SIMD allow are all taken)
+    uint32_t lo = lane;
+    asm volatile("" : "+v"(lo));
+#pragma unroll
+    for (uint32_t c = 0; c < NCH; ++c) {
+        const uint32_t h = mix32(x[c]);
+        Kl[c * 64] = ((h & ~MIN_POS_MASK) | lo) + c * 64;
+        Hl[c * 64] = h;
+    }
+    Kl[NCH * 64] = ~0u;
+    wave_lds_fence();
+    // every step reads ALL chunks before it writes any (one LDS round trip per step, not one per chunk and step)
+#pragma unroll
+    for (uint32_t st = 1; st <= ((W == 16) ? 16u : 8u); st <<= 1) {
+        uint32_t a[NCH], b[NCH];
+#pragma unroll
+        for (uint32_t c = 0; c < NCH; ++c) { a[c] = Kl[c * 64]; b[c] = Kl[c * 64 + st]; }
+        wave_lds_fence();
+#pragma unroll
+        for (uint32_t c = 0; c < NCH; ++c) Kl[c * 64] = b[c] < a[c] ? b[c] : a[c];
+        wave_lds_fence();
     }
 }
+template <int W, uint32_t TILE>
+__device__ __forceinline__ void build_minkeys(const uint32_t *s, uint32_t sh, uint32_t *Kl, uint32_t *Hl, uint32_t npos, uint32_t lane) {
+    constexpr uint32_t MAXCH = (TILE + 4 * W - 16 + 63) / 64;
+    static_assert(MAXCH <= 5, "tile too large");
+    const uint32_t nch = (npos + 63) >> 6;                 // wave-uniform
+    if (nch <= 1) build_minkeys_n<W, 1>(s, sh, Kl, Hl, lane);
+    else if (nch == 2) build_minkeys_n<W, 2>(s, sh, Kl, Hl, lane);
+    else if (nch == 3 || MAXCH == 3) build_minkeys_n<W, 3>(s, sh, Kl, Hl, lane);
+    else if (nch == 4) build_minkeys_n<W, MAXCH >= 4 ? 4 : 3>(s, sh, Kl, Hl, lane);
+    else build_minkeys_n<W, MAXCH >= 5 ? 5 : 3>(s, sh, Kl, Hl, lane);
+}
 
-// One wave looks up the windows [w0, w0+n) of a staged buffer (sw = packed bases, sbad = bad-base bit words, both
-// indexed from the buffer's first base) and hands every lane's result to on_rank(rank) -- called by all lanes,
-// INVALID for lanes without a hit -- once per 64 windows.  One bucket (64 bytes) is in flight per lane: its records
-// arrive in one round trip, and two buckets in flight would not fit the registers.  `regions` = the image's region
-// table, copied to LDS by the caller.
-template <int W, int I, bool EXC, typename OFF, uint32_t TILE = KEY_TILE, typename HitFn>
-__device__ __forceinline__ void wave_scan_windows(const utk_image &im, const uint32_t *sw, const uint64_t *sbad, uint64_t *Kk,
-                                                  uint32_t w0, uint32_t n, uint32_t pos_cap, const uint64_t *regions, uint32_t lane,
-                                                  HitFn &&on_rank) {
+// The block's copy of the image's region table in the form the window loop wants it (stage_regions):
+//   s_raddr[r] = address of bucket (base_r - ((r << 24) >> s_r)): with it, bucket address = s_raddr[r] + ((h >> s_r) << 6)
+//   s_rshift[r] = s_r
+struct RegionLds { const uint64_t *addr; const uint8_t *shift; };
+
+// One wave looks up the windows [w0, w0+n) of a staged buffer (lb / sw = packed bases, sbad = bad-base bit words, both
+// indexed from the buffer's first base; w0 a multiple of 64) and hands every lane's result to on_rank(rank) -- called by all
+// lanes, INVALID for lanes without a hit -- once per 64 windows.  One bucket (64 bytes) is in flight per lane: its records
+// arrive in one round trip, and two buckets in flight would not fit the registers.  CHECKBAD = false: the caller knows the
+// windows hold no bad base (most reads), and the per-window test disappears.
+template <int W, int I, bool EXC, typename OFF, uint32_t TILE, bool CHECKBAD, bool PAIRS, typename HitFn>
+__device__ __forceinline__ void wave_scan_windows(const utk_image &im, const LaneBits &lb, const uint64_t *sbad, uint64_t *Kk,
+                                                  uint32_t w0, uint32_t n, const RegionLds &rg, uint32_t lane, HitFn &&on_rank PH_ARG) {
     constexpr uint32_t K = 4 * W;
     static_assert(TILE + 64 <= (1u << MIN_LOW_BITS), "tile positions must fit the key's position field");
-    uint32_t *Kp = (uint32_t *)Kk, *Hh = Kp + (TILE + 128);              // the wave's 8 * (TILE + 128) bytes: keys, then hashes
+    uint32_t *Kp = (uint32_t *)Kk;                                          // the wave's 8 * (TILE + 128) bytes: keys, then hashes
+    uint32_t *Kl = Kp + lane, *Hl = Kp + (TILE + 128) + lane;
+    const uint32_t *Hh = Kp + (TILE + 128);
+    const uint32_t nlane = 0u - lane;
     for (uint32_t wb = 0; wb < n; wb += TILE) {
         const uint32_t tn = n - wb < TILE ? n - wb : TILE;
-        build_minkeys<W>(sw, Kp, Hh, w0 + wb, tn + K - 16, pos_cap, lane);  // 16-mers of windows w0+wb .. w0+wb+tn-1
+        const uint32_t *st = lb.swl + ((w0 + wb) >> 4);                      // the tile's first word, per lane
+        build_minkeys<W, TILE>(st, lb.sh, Kl, Hl, tn + K - 16, lane);       // 16-mers of windows w0+wb .. w0+wb+tn-1
+        TICK(2);
 #if defined(UTREE_ABLATE) && UTREE_ABLATE == 2
         continue;
 #endif
-        for (uint32_t it = 0; it * 64 < tn; ++it) {
-            const uint32_t tw = it * 64 + lane, i = w0 + wb + tw;            // window index in the tile / in the buffer
-            bool ok = false;
-            if (tw < tn) {
-                const uint32_t ch = i >> 6, bit = i & 63u;
+        // A round = 64 windows, lane l taking window it*64 + l of the tile.  locate(): the bucket (and the key bits that go with
+        // it) of the lane's window in round `it`; resolve(): the rank its bucket holds for the window.
+        auto locate = [&](uint32_t it, uint64_t &baddr, uint32_t &tag) {
+            const uint32_t *Kr = Kl + it * 64;
+            const uint32_t ka = Kr[0], kb = Kr[MinWin<W>::NEXT];
+            const uint32_t p = (kb < ka ? kb : ka) & MIN_POS_MASK;
+            const uint32_t h = Hh[p];
+            const uint32_t pos = p + nlane - it * 64;                       // minimizer position inside the window
+            const uint32_t sft = rg.shift[h >> 24];
+#ifdef UTREE_ABLATE_L2
+            baddr = (uint64_t)(uintptr_t)im.table + ((uint64_t)((h >> sft) & 0x3FFFu) << 6);   // timing experiment: every bucket inside 1 MB (L2 hits), answers wrong
+#else
+            baddr = rg.addr[h >> 24] + ((uint64_t)(h >> sft) << 6);
+#endif
+            tag = ((h & ((1u << sft) - 1u)) << 6) | pos;                    // hash bits the bucket does not imply | position (< 64)
+        };
+        auto resolve = [&](uint32_t it, const Bucket<W, I> &bk, uint32_t tag) -> uint32_t {
+            const uint32_t *sr = st + it * 4;
+            const uint32_t pos = tag & 63u, hlow = tag >> 6;
+            if constexpr (W == 8) {
+                const uint32_t x0 = mmer_l(sr, 0, lb.sh), x1 = mmer_l(sr, 1, lb.sh);
+                const uint32_t M = (uint32_t)(0xFFFFFFFFull >> (2 * pos));           // ones over the bases after the minimizer
+                const uint32_t rest = x0 ^ ((x0 ^ x1) & M);                          // bit-select: x1 where M, x0 elsewhere
+                return resolve_bucket8<I, EXC, OFF>(im, bk, hlow, pos, rest, x0, x1);
+            } else {
+                const uint32_t x0 = mmer_l(sr, 0, lb.sh), x1 = mmer_l(sr, 1, lb.sh), x2 = mmer_l(sr, 2, lb.sh), x3 = mmer_l(sr, 3, lb.sh);
+                const uint64_t wh = ((uint64_t)x0 << 32) | x1, wl = ((uint64_t)x2 << 32) | x3;
+                uint32_t rh; uint64_t rl;
+                min_rest<W>(wh, wl, pos, rh, rl);
+                MinKey<W> mk;
+                mk.lo = rl; mk.hi = ((uint64_t)hlow << 38) | ((uint64_t)pos << 32) | rh;
+                return resolve_bucket<W, I, EXC, OFF>(im, bk, mk, wh, wl);
+            }
+        };
+        auto window_ok = [&](uint32_t it, uint32_t left) -> bool {
+            bool ok = lane < left;
+            if constexpr (CHECKBAD) {
+                const uint32_t ch = (w0 + wb + it * 64) >> 6;               // the round's first base is 64-aligned: bit = lane
                 const uint64_t b0 = sbad[ch], b1 = sbad[ch + 1];
-                const uint64_t x = (b0 >> bit) | (bit ? (b1 << (64 - bit)) : 0ull);      // bad flags of bases i..i+63
-                ok = (K == 64) ? (x == 0) : ((uint32_t)x == 0);
+                const uint64_t x = (b0 >> lane) | (lane ? (b1 << (64u - lane)) : 0ull);   // bad flags of bases i..i+63
+                ok = ok && ((K == 64) ? (x == 0) : ((uint32_t)x == 0));
             }
-            uint32_t rank = INVALID;
-            if (ok) {
-                uint64_t wh, wl, bucket; MinKey<W> mk;
-                window_word<W>(sw, i, wh, wl);
-                const uint32_t ka = Kp[tw], kb = Kp[tw + MinWin<W>::NEXT];
-                const uint32_t p = (kb < ka ? kb : ka) & MIN_POS_MASK;
-                min_finish<W>(wh, wl, Hh[p], p - tw, regions, bucket, mk);
-                const Bucket<W, I> bk = load_bucket<W, I>(im.table, bucket);
-                rank = resolve_bucket<W, I, EXC, OFF>(im, bk, mk, wh, wl);
+            return ok;
+        };
+        // PAIRS: two rounds' buckets are requested together -- one memory wait per 128 windows instead of two -- at the price of
+        // 16 more registers (7 instead of 8 waves per SIMD).  Otherwise one bucket is in flight per lane.
+        constexpr uint32_t STEP = PAIRS ? 2 : 1;
+        for (uint32_t it = 0; it * 64 < tn; it += STEP) {
+            const uint32_t left0 = tn - it * 64, left1 = left0 > 64 ? left0 - 64 : 0;
+            const bool ok0 = window_ok(it, left0);
+            uint64_t a0 = 0; uint32_t t0 = 0;
+            Bucket<W, I> bk0;
+            if (ok0) { locate(it, a0, t0); bk0 = load_bucket_at<W, I>(a0); }
+            TICK(3);
+            if constexpr (PAIRS) {
+                const bool ok1 = left1 && window_ok(it + 1, left1);
+                uint64_t a1 = 0; uint32_t t1 = 0;
+                Bucket<W, I> bk1;
+                if (ok1) { locate(it + 1, a1, t1); bk1 = load_bucket_at<W, I>(a1); }
+                PH_WAITVM;
+                TICK(4);
+                uint32_t rank0 = INVALID, rank1 = INVALID;
+                if (ok0) rank0 = resolve(it, bk0, t0);
+                if (ok1) rank1 = resolve(it + 1, bk1, t1);
+                TICK(5);
+                on_rank(rank0);                                              // itree.c:929-931
+                if (left1) on_rank(rank1);
+                TICK(6);
+            } else {
+                PH_WAITVM;
+                TICK(4);
+                uint32_t rank0 = INVALID;
+                if (ok0) rank0 = resolve(it, bk0, t0);
+                TICK(5);
+                on_rank(rank0);                                              // itree.c:929-931
+                TICK(6);
             }
-            on_rank(rank);                                                   // itree.c:929-931
         }
         wave_lds_fence();
     }
 }
 
-// the image's 2 KB region table -> LDS (all threads of the workgroup; followed by a barrier)
-__device__ __forceinline__ void stage_regions(const utk_image &im, uint64_t *s_regions) {
-    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) s_regions[x] = im.regions[x];
+// the image's region table -> LDS in the window loop's form (all threads of the workgroup; followed by a barrier)
+__device__ __forceinline__ void stage_regions(const utk_image &im, uint64_t *s_raddr, uint8_t *s_rshift) {
+    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) {
+        const uint64_t e = im.regions[x];
+        const uint32_t sft = (uint32_t)e & 0xFFu;
+        s_raddr[x] = (uint64_t)(uintptr_t)im.table + (((e >> 8) - (((uint64_t)x << 24) >> sft)) << 6);
+        s_rshift[x] = (uint8_t)sft;
+    }
     __syncthreads();
 }
 
 __device__ __forceinline__ void store_result(utree_result *out, uint32_t label, int32_t cut, uint32_t found,
                                              uint32_t uix, uint32_t sl, uint32_t ol) {
     uint32_t *o = (uint32_t *)out;
-    o[0] = label; o[1] = (uint32_t)cut; o[2] = found; o[3] = uix; o[4] = sl; o[5] = ol;
+    // the six words are materialised here: hoisted out of the read loop as constant vectors they cost six registers per call
+    // site for the whole kernel (and went to scratch at 64 registers)
+    uint32_t v0 = label, v1 = (uint32_t)cut, v2 = found, v3 = uix, v4 = sl, v5 = ol;
+    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5));
+    o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4; o[5] = v5;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -185,11 +316,13 @@ __device__ __forceinline__ void fetch_raw(const uint8_t *__restrict__ bases, uin
     }
 }
 
+// Returns whether any staged base (index < total) is bad -- wave-uniform; when none is, the window loop skips its per-window test.
 template <int CAP>
-__device__ __forceinline__ void stage_read(const uint32_t *raw, uint32_t mf, uint32_t L, uint32_t total, int do_rc,
+__device__ __forceinline__ bool stage_read(const uint32_t *raw, uint32_t mf, uint32_t L, uint32_t total, int do_rc,
                                            uint8_t *sb, uint8_t *sbadb, uint32_t lane) {
     constexpr uint32_t DW = RawBuf<CAP>::DW;
     const uint32_t ngroups = (total + 3u) >> 2;
+    bool any = false;
     const uint32_t mr = (mf + 2u * L + 1u) & 3u;                       // reverse: misalignment of a group's lowest source byte (2L - 3 - 4g)
     for (uint32_t g0 = 0; g0 < ngroups; g0 += 64) {
         const uint32_t g = g0 + lane;
@@ -212,6 +345,7 @@ __device__ __forceinline__ void stage_read(const uint32_t *raw, uint32_t mf, uin
         const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, g2);            // 0 1 2 3 -> A C T G
         const uint32_t z = (word & 0xDFDFDFDFu) ^ letter;                              // non-zero byte = bad base
         const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+        any = any || (nz & low_bytes(total > 4u * g ? total - 4u * g : 0u)) != 0u;     // bytes past the read's end do not count
         const uint32_t nib = (nz * 0x00204081u) >> 28;                                 // bits 7,15,23,31 -> 0..3
         const uint32_t nib_next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nib, 0x101, 0xF, 0xF, true);   // row_shl:1 = lane + 1
         uint32_t code = g2 ^ ((g2 >> 1) & 0x01010101u);
@@ -222,6 +356,7 @@ __device__ __forceinline__ void stage_read(const uint32_t *raw, uint32_t mf, uin
             if (!(lane & 1u)) sbadb[g >> 1] = (uint8_t)(nib | (nib_next << 4));
         }
     }
+    return __ballot(any) != 0ull;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -259,24 +394,34 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     const int do_rc = RCMODE == 2 ? do_rc_arg : RCMODE;
     constexpr uint32_t K = 4 * W;
     constexpr int NCH = CAP / 64, NWORDS = CAP / 16 + 6;
-    __shared__ uint32_t s_words[WAVES_PER_BLOCK][NWORDS];
+    __shared__ uint32_t s_words[WAVES_PER_BLOCK][NWORDS + 2];          // two pad words in front: lane_bits() may look one word back
     __shared__ uint64_t s_bad[WAVES_PER_BLOCK][NCH + 2];
     using HIT = typename std::conditional<I == 2, uint16_t, uint32_t>::type;     // ranks of u16-label databases fit 16 bits
     __shared__ HIT s_hits[WAVES_PER_BLOCK][CAP];
     // a 150 bp read with its reverse strand (270 windows) is two tiles of 256 instead of three of 128
     constexpr uint32_t TILE = CAP <= SHORT_CAP ? 256u : KEY_TILE;
+    // two rounds' buckets in flight at once (one memory wait per 128 windows): 16 more registers, 7 waves per SIMD -- measured
+    // 5 % slower than one bucket at 8 waves (same-box, round 2); -DUTREE_PAIRS builds it for comparison
+#ifdef UTREE_PAIRS
+    constexpr bool PAIRS = CAP <= SHORT2_CAP && I == 2;
+#else
+    constexpr bool PAIRS = false;
+#endif
     __shared__ uint64_t s_keys[WAVES_PER_BLOCK][TILE + 128];
-    __shared__ uint64_t s_regions[256];
+    __shared__ uint64_t s_raddr[256];
+    __shared__ uint8_t s_rshift[256];
     // the mid-length pass has no room for a raw buffer of its own and less to gain: its raw bytes pass through the hit
     // list's space (consumed by stage_read before the first hit is written) and are not requested ahead
     constexpr bool PREFETCH = CAP <= SHORT2_CAP;
     static_assert(PREFETCH || sizeof(HIT) * CAP >= 4 * (RawBuf<CAP>::DW + 4), "raw bytes must fit the hit list");
     __shared__ uint32_t s_raw[PREFETCH ? WAVES_PER_BLOCK : 1][PREFETCH ? RawBuf<CAP>::DW + 4 : 1];
-    stage_regions(im, s_regions);
+    stage_regions(im, s_raddr, s_rshift);
+    const RegionLds rg = {s_raddr, s_rshift};
     const uint32_t lane = lane_id();
     const uint32_t wv = uni32(threadIdx.x >> 6);
     uint32_t *raw = PREFETCH ? s_raw[wv] : (uint32_t *)s_hits[wv];
-    uint32_t *sw = s_words[wv];
+    uint32_t *sw = s_words[wv] + 2;
+    const LaneBits lb = lane_bits(sw, lane);
     uint8_t *sb = (uint8_t *)sw;
     uint64_t *sbad = s_bad[wv];
     HIT *hits = s_hits[wv];
@@ -299,13 +444,14 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     // wait -- in particular without waiting for the previous read's stores to be acknowledged.  The pipeline restarts at
     // every grab.
     auto stageable = [&](uint32_t len_) { const uint64_t t = do_rc ? 2 * (uint64_t)len_ + 1 : len_; return t <= (uint64_t)CAP && t >= K; };
-    auto stage = [&](uint64_t o_, uint32_t L_) {           // raw bytes -> 2-bit codes packed big-endian in LDS, bad-base bits
+    auto stage = [&](uint64_t o_, uint32_t L_) -> bool {   // raw bytes -> 2-bit codes packed big-endian in LDS, bad-base bits; any bad base?
         const uint32_t total_ = do_rc ? 2 * L_ + 1 : L_;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_fence();
-        stage_read<CAP>(raw, (uint32_t)(uintptr_t)(bases + o_) & 3u, L_, total_, do_rc, sb, (uint8_t *)sbad, lane);
+        const bool any_ = stage_read<CAP>(raw, (uint32_t)(uintptr_t)(bases + o_) & 3u, L_, total_, do_rc, sb, (uint8_t *)sbad, lane);
         if (lane == 0) sbad[(total_ + 63) >> 6] = ~0ull;
         wave_lds_fence();
+        return any_;
     };
     // ---- tally (itree.c:1028-1040) of a read with F hits in hits[]: unique labels with counts, ascending rank = strcmp order ----
     auto finish = [&](uint32_t r, uint32_t F) {
@@ -385,9 +531,23 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             if (lane == 0) store_result(&out[r], 0, CUT_PENDING, F, uix, (uint32_t)base, (uint32_t)(base >> 32));
     };
     uint32_t item = 0, item_end = 0;
+    PH_DECL
     bool ahead = false;                                    // the current read's parameters are known and, if stageable, it is staged
+    bool bad_cur = true, bad_next = true;                  // a staged read holds a bad base (the strands' separator counts)
     uint32_t r = 0, L = 0;
     uint64_t o = 0;
+    // the grab's read parameters: lane i holds read (grab start + i)'s index, length and offset -- one round trip per grab
+    // instead of one per read (each of those stalled the wave: a load's result needs every earlier store acknowledged too)
+    uint32_t grab0 = 0, g_r = 0, g_len = 0;
+    uint64_t g_off = 0;
+    auto params = [&](uint32_t it_, uint32_t &r_, uint32_t &L_, uint64_t &o_) {
+        const int k_ = (int)(it_ - grab0);
+        r_ = LISTED ? (uint32_t)__builtin_amdgcn_readlane((int)g_r, k_) : it_;
+        L_ = (uint32_t)__builtin_amdgcn_readlane((int)g_len, k_);
+        o_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(g_off >> 32), k_) << 32) |
+             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)g_off, k_);
+    };
+    static_assert(WORK_GRAB <= 64, "a grab's parameters live in the lanes of one register");
     for (;;) {
         if (item == item_end) {
             // next grab: from this wave's current part; a part that is used up (a plain load tells, no atomic) is left for good
@@ -411,11 +571,16 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             }
             if (!got) break;
             ahead = false;
+            grab0 = item;
+            if (item + lane < item_end) {
+                g_r = LISTED ? ws.mid_list[item + lane] : item + lane;
+                g_len = len[g_r]; g_off = off[g_r];
+            }
+            TICK(0);
         }
         if (!ahead) {
-            r = LISTED ? uni32(ws.mid_list[item]) : item;
-            L = uni32(len[r]); o = uni64(off[r]);
-            if (stageable(L)) { fetch_raw<CAP>(bases, o, L, raw, lane); stage(o, L); }
+            params(item, r, L, o);
+            if (stageable(L)) { fetch_raw<CAP>(bases, o, L, raw, lane); bad_cur = stage(o, L); }
         }
         ++item;
         ahead = PREFETCH && item < item_end;
@@ -423,11 +588,11 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         uint64_t o_next = 0;
         bool stage_next = false;
         if (ahead) {
-            r_next = LISTED ? uni32(ws.mid_list[item]) : item;
-            L_next = uni32(len[r_next]); o_next = uni64(off[r_next]);
+            params(item, r_next, L_next, o_next);
             stage_next = stageable(L_next);
             if (stage_next) fetch_raw<CAP>(bases, o_next, L_next, raw, lane);     // the raw buffer is free: this read is staged
         }
+        TICK(1);
         const uint64_t total64 = do_rc ? 2 * (uint64_t)L + 1 : L;
         // total64 > CAP: route_k listed it for the mid-length pass or classify_long_k, nothing to do here
         if (total64 <= (uint64_t)CAP) {
@@ -436,24 +601,35 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 #if !(defined(UTREE_ABLATE) && UTREE_ABLATE == 1)            /* ablation builds (profiles/run_pmc_variants.sh): 1 = staging only, */
             if (total >= K) {                                      /* 2 = + sliding minimizers, 3 = + window lookups, no tally        */
                 // ---- windows: lane l takes windows l, l+64, ... (itree.c:906-933) ----
-                wave_scan_windows<W, I, EXC, OFF, TILE>(im, sw, sbad, Kk, 0u, total - K + 1, (uint32_t)CAP, s_regions, lane, [&](uint32_t rank) {
+                auto on_rank = [&](uint32_t rank) {
                     const bool hit = rank != INVALID;
                     const uint64_t hm = __ballot(hit);
                     if (hit) hits[F + lanes_below(hm)] = (HIT)rank;
                     F += (uint32_t)__popcll(hm);
-                });
+                };
+                // a read without any bad base (most) takes the loop without the per-window test; with both strands staged the
+                // separator is one, so that instantiation only has the tested loop
+                if constexpr (RCMODE == 1) wave_scan_windows<W, I, EXC, OFF, TILE, true, PAIRS>(im, lb, sbad, Kk, 0u, total - K + 1, rg, lane, on_rank PH_PASS);
+                else if (!bad_cur) wave_scan_windows<W, I, EXC, OFF, TILE, false, PAIRS>(im, lb, sbad, Kk, 0u, total - K + 1, rg, lane, on_rank PH_PASS);
+                else wave_scan_windows<W, I, EXC, OFF, TILE, true, PAIRS>(im, lb, sbad, Kk, 0u, total - K + 1, rg, lane, on_rank PH_PASS);
                 wave_lds_fence();
             }
 #endif
-            if (stage_next) stage(o_next, L_next);          // sw / sbad now belong to the next read; hits[] to this one
+            TICK(9);
+            if (stage_next) bad_next = stage(o_next, L_next);   // sw / sbad now belong to the next read; hits[] to this one
+            TICK(7);
 #if defined(UTREE_ABLATE)
             if (lane == 0) store_result(&out[r], sw[0] + hits[0], -2, F, 0, 0, 0);
 #else
             finish(r, F);                                  // F == 0 (no window: no hit, no output line) included
 #endif
-        } else if (stage_next) stage(o_next, L_next);
-        r = r_next; L = L_next; o = o_next;
+            TICK(8);
+        } else if (stage_next) bad_next = stage(o_next, L_next);
+        r = r_next; L = L_next; o = o_next; bad_cur = bad_next;
     }
+#ifdef UTREE_PHASE_TIMERS
+    if (lane == 0) { for (int q = 0; q < 12; ++q) atomicAdd(&g_phase[q], ph_.acc[q]); atomicAdd(&g_phase[12], 1ull); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -475,22 +651,26 @@ __global__ __launch_bounds__(LONG_THREADS, EXC ? 5 : 8) void classify_long_k(utk
                                                                 utree_result *__restrict__ out, utk_workspace ws) {
     constexpr uint32_t K = 4 * W;
     constexpr uint32_t STAGE = LONG_TILE + 64;          // bases staged per tile (tile + K-1, rounded up)
-    __shared__ uint32_t s_words[STAGE / 16 + 8];
+    __shared__ uint32_t s_words_pad[STAGE / 16 + 8 + 2];  // two pad words in front: lane_bits() may look one word back
     __shared__ uint64_t s_bad[STAGE / 64 + 2];
     __shared__ uint32_t s_scan[LONG_THREADS / 64 + 1];
     __shared__ uint32_t s_touch[LONG_LDS_BITWORDS];
     __shared__ uint64_t s_keys[LONG_THREADS / 64][KEY_TILE + 128];
     __shared__ unsigned long long s_base;
-    __shared__ uint64_t s_regions[256];
+    __shared__ uint64_t s_raddr[256];
+    __shared__ uint8_t s_rshift[256];
     __shared__ uint32_t s_work, s_single;               // the read this workgroup took; the label of a one-label read
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = uni32(tid >> 6);
+    uint32_t *s_words = s_words_pad + 2;
     uint8_t *sb = (uint8_t *)s_words;
+    const LaneBits lb = lane_bits(s_words, lane);
     const uint32_t nl = im.n_labels, nbw = (nl + 31) >> 5;
     uint32_t *hist = ws.hist + (size_t)blockIdx.x * nl;                       // all zero between reads
     uint32_t *touch = nbw <= LONG_LDS_BITWORDS ? s_touch : ws.touch + (size_t)blockIdx.x * nbw;   // all zero between reads
     const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
     if (nbw <= LONG_LDS_BITWORDS) for (uint32_t x = tid; x < nbw; x += LONG_THREADS) s_touch[x] = 0;
-    stage_regions(im, s_regions);
+    stage_regions(im, s_raddr, s_rshift);
+    const RegionLds rg = {s_raddr, s_rshift};
 
     for (;;) {
         // long reads differ in length by orders of magnitude: hand them out one at a time
@@ -541,7 +721,8 @@ __global__ __launch_bounds__(LONG_THREADS, EXC ? 5 : 8) void classify_long_k(utk
             constexpr uint32_t PER_WAVE = LONG_TILE / (LONG_THREADS / 64);
             const uint32_t a = wv * PER_WAVE < tile_n ? wv * PER_WAVE : tile_n;
             const uint32_t b = a + PER_WAVE < tile_n ? a + PER_WAVE : tile_n;
-            wave_scan_windows<W, I, EXC, OFF>(im, s_words, s_bad, s_keys[wv], a, b - a, STAGE, s_regions, lane, [&](uint32_t rank) {
+            PH_DECL
+            wave_scan_windows<W, I, EXC, OFF, KEY_TILE, true, false>(im, lb, s_bad, s_keys[wv], a, b - a, rg, lane, [&](uint32_t rank) {
                 // one atomic per DISTINCT label of the 64 windows, not per hit: a read's hits mostly share a few labels,
                 // and 64 atomics on one address serialise in L2
                 const bool hit = rank != INVALID;
@@ -557,7 +738,7 @@ __global__ __launch_bounds__(LONG_THREADS, EXC ? 5 : 8) void classify_long_k(utk
                     }
                     left &= ~m;
                 }
-            });
+            } PH_PASS);
             __syncthreads();
         }
         // F = total hits
@@ -891,6 +1072,21 @@ int utk_lookup(const utk_image *im, const uint64_t *d_hi, const uint64_t *d_lo, 
             <<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_hi, d_lo, n, d_ix);
     });
 }
+
+#ifdef UTREE_PHASE_TIMERS
+void utk_phase_dump(void) {
+    unsigned long long h[16];
+    static const char *nm[12] = {"grab", "next read's len/off + fetch issue", "minimizers", "round: address (LDS chain) + load issue", "round: wait for the bucket",
+                                 "round: scan", "round: hit compaction", "stage next read (waits for its bytes)", "tally + result", "after windows", "", ""};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof h) != hipSuccess) return;
+    unsigned long long tot = 0;
+    for (int q = 0; q < 12; ++q) tot += h[q];
+    fprintf(stderr, "[phase timers] %llu waves, %.3g cycles per wave\n", h[12], h[12] ? (double)tot / h[12] : 0.0);
+    for (int q = 0; q < 10; ++q) fprintf(stderr, "  %-45s %5.1f %%\n", nm[q], tot ? 100.0 * h[q] / tot : 0.0);
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h, sizeof h);
+}
+#endif
 
 int utk_model_counts(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                      int do_rc, unsigned long long *d_counts, void *stream) {

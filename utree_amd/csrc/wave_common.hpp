@@ -41,6 +41,43 @@ template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket(cons
     return b;
 }
 
+// the bucket at a byte address computed from the LDS region table: the address space is stated (global), or the loads would be
+// flat ones
+template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket_at(uint64_t addr) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) u64x2 *gptr;
+    const gptr p = (gptr)addr;
+    Bucket<W, I> b;
+    constexpr int EW = RecTraits<W, I>::EW, CAP = 8 / EW;
+    u64x2 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = __builtin_nontemporal_load(p + q);
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+#pragma unroll
+        for (int x = 0; x < EW; ++x) { const int w = i * EW + x; b.e[i].w[x] = (w & 1) ? v[w >> 1].y : v[w >> 1].x; }
+    return b;
+}
+
+// The 8 entries of a k = 32 / u16-label bucket against (tag = hash bits the bucket does not imply << 5 | minimizer position, rest):
+// an entry's low word is its rest, its high word {flag2 | 0 | tag13 | rank16}.  One compare and one select per entry pick the
+// high word of the entry whose rest matches; the tag (and with it the flag: 0 = a record) is checked once.  Two entries with
+// the same rest and different tags are possible (the same 16 outer bases around a minimizer at two positions): then, and when
+// an empty entry or the overflow descriptor happens to carry the rest's bit pattern, every entry is looked at in full.
+__device__ __forceinline__ uint32_t scan_bucket82(const Bucket<8, 2> &b, uint32_t tag, uint32_t rest) {
+    uint32_t sel = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sel = (uint32_t)b.e[i].w[0] == rest ? (uint32_t)(b.e[i].w[0] >> 32) : sel;
+    uint32_t rank = INVALID;
+    if ((sel >> 16) == tag) rank = sel & 0xFFFFu;
+    else if (sel != 0xFFFFFFFFu) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if ((uint32_t)b.e[i].w[0] == rest && (uint32_t)(b.e[i].w[0] >> 48) == tag) rank = (uint32_t)(b.e[i].w[0] >> 32) & 0xFFFFu;
+    }
+    return rank == 0xFFFFu ? INVALID : rank;
+}
+
 // Second half of a lookup, given the bucket of the word's minimizer.  Words whose 24-bit bin is not strictly ascending
 // (COMPRESS' first-bin quirk) or any word of a non-monotone table take the reference's own probe sequence over the FILE
 // records instead: only that reproduces its answers there.
@@ -57,26 +94,49 @@ __device__ __forceinline__ uint32_t resolve_bucket(const utk_image &im, const Bu
         }
     }
     constexpr int CAP = BucketOf<W, I>::CAP;
-    // straight-line scan.  An entry is the record of `mk` exactly when its key word without the 16 label bits equals
-    // {flag 0 | mk} (an empty entry or the overflow descriptor has a non-zero flag, so neither can): one AND and one
-    // 64-bit compare per entry; the label bits of the matching entry are picked up raw and decoded once at the end.
-    constexpr int KW = RecTraits<W, I>::KW;
-    const uint64_t want = (W == 16 ? mk.hi : mk.lo) << 16;
-    uint32_t raw = INVALID;
+    uint32_t rank;
+    if constexpr (W == 8 && I == 2) rank = scan_bucket82(b, (uint32_t)(mk.lo >> 32), (uint32_t)mk.lo);
+    else {
+        // straight-line scan.  An entry is the record of `mk` exactly when its key word without the 16 label bits equals
+        // {flag 0 | mk} (an empty entry or the overflow descriptor has a non-zero flag, so neither can): one AND and one
+        // 64-bit compare per entry; the label bits of the matching entry are picked up raw and decoded once at the end.
+        constexpr int KW = RecTraits<W, I>::KW;
+        const uint64_t want = (W == 16 ? mk.hi : mk.lo) << 16;
+        uint32_t raw = INVALID;
 #pragma unroll
-    for (int i = 0; i < CAP; ++i) {
-        bool hit = (b.e[i].w[KW] & ~0xFFFFull) == want;
-        if constexpr (W == 16) hit = hit && b.e[i].w[0] == mk.lo;
-        raw = hit ? (uint32_t)b.e[i].w[I == 4 ? KW + 1 : KW] : raw;
+        for (int i = 0; i < CAP; ++i) {
+            bool hit = (b.e[i].w[KW] & ~0xFFFFull) == want;
+            if constexpr (W == 16) hit = hit && b.e[i].w[0] == mk.lo;
+            raw = hit ? (uint32_t)b.e[i].w[I == 4 ? KW + 1 : KW] : raw;
+        }
+        rank = raw;
+        if constexpr (I == 2) { rank = raw & 0xFFFFu; rank = rank == 0xFFFFu ? INVALID : rank; }
     }
-    uint32_t rank = raw;
-    if constexpr (I == 2) { rank = raw & 0xFFFFu; rank = rank == 0xFFFFu ? INVALID : rank; }
     if (mrec_flag<W, I>(b.e[CAP - 1]) == 2 && rank == INVALID) {                          // the rest of the bucket's nodes
         const uint64_t d = b.e[CAP - 1].w[RecTraits<W, I>::KW];
         const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull;
         rank = min_find<W, I>(im.mrecs, start, start + n, mk);
     }
     return rank;
+}
+
+// The same for k = 32 from the window loop's pieces (no 64-bit key is assembled on the common path).
+template <int I, bool EXC, typename OFF>
+__device__ __forceinline__ uint32_t resolve_bucket8(const utk_image &im, const Bucket<8, I> &b, uint32_t hlow, uint32_t pos, uint32_t rest,
+                                                    uint32_t x0, uint32_t x1) {
+    if constexpr (I == 2 && !EXC) {
+        uint32_t rank = scan_bucket82(b, (hlow << 5) | pos, rest);
+        if (mrec_flag<8, 2>(b.e[7]) == 2 && rank == INVALID) {                              // the rest of the bucket's nodes
+            const uint64_t d = b.e[7].w[0];
+            const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull;
+            MinKey<8> mk; mk.hi = 0; mk.lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
+            rank = min_find<8, 2>(im.mrecs, start, start + n, mk);
+        }
+        return rank;
+    } else {
+        MinKey<8> mk; mk.hi = 0; mk.lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
+        return resolve_bucket<8, I, EXC, OFF>(im, b, mk, 0ull, ((uint64_t)x0 << 32) | x1);
+    }
 }
 
 template <int W, int I, bool EXC, typename OFF>
