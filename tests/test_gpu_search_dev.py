@@ -193,3 +193,39 @@ def test_seeded_multichunk_file_vs_oracle(torch_cuda, tmp_path):
     assert code == lib.OK and ocode == 0 and st.pipeline == 1
     assert st.n_reads == n == nr and st.good_finds == good
     assert got == want.read_bytes()
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: utree_dev_replicate issues one ncclBroadcast over all visible devices")
+def test_replicate_rccl_over_all_visible_devices(torch_cuda, tmp_path):
+    """The C host path of the multi-GPU search (north_star: host orchestration in C): utree_dev_replicate (ncclCommInitAll + one
+    ncclBroadcast of the flat image, csrc/rccl_replicate.c), then utree_search_file over all the handles -- lanes of every device
+    take chunks in turn, the output is the reference's -- and each replica classifies a batch exactly like the original."""
+    import ctypes as C
+    torch = torch_cuda
+    n = torch.cuda.device_count()
+    db = CtrDB.open(util.fixture_ctr("toy"))
+    t0 = DeviceTree.upload(db, 0)
+    devs = (C.c_int * n)(*range(n))
+    out = (C.c_void_p * n)()
+    assert lib.load().utree_dev_replicate(db._h, t0._h, devs, n, out) == lib.OK
+    trees = [t0] + [DeviceTree(out[i], db) for i in range(1, n)]
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    for rc in (False, True):
+        code, st, got = run(db, trees, data, tmp_path, rc=rc, threads=8)
+        assert code == lib.OK and st.pipeline == 1 and st.n_lanes >= n
+        assert got == util.fixture_bytes("toy_out%s.txt.gz" % ("_rc" if rc else ""))
+    from utree_amd.search import frame_fasta
+    fr = frame_fasta(data)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    want = None
+    for g, t in enumerate(trees):
+        dev = "cuda:%d" % g
+        res = t.classify(torch.from_numpy(buf.copy()).to(dev), torch.from_numpy(fr["seq_off"].astype(np.int64)).to(dev),
+                         torch.from_numpy(fr["seq_len"].astype(np.int32)).to(dev), rc=True).cpu()
+        want = res if want is None else want
+        assert torch.equal(res, want), "replica on device %d differs" % g

@@ -255,3 +255,42 @@ def test_fastq_and_multiline_fasta_frame_like_two_line_fasta():
     assert frame_reads(b"ACGT\nACGT\n", lib.INPUT_FASTQ)["error_code"] == 2
     assert frame_reads(b"@r\nACGT\nACGT\nIIII\n", lib.INPUT_FASTQ)["error_code"] == 3
     assert frame_reads(b"@r\nACGT\n", lib.INPUT_FASTQ)["error_code"] in (1, 3)
+
+
+def test_fasta_tensor_equals_the_python_loop():
+    """synth.fasta_tensor (the bench's FASTA writer, torch ops) == synth.reads_to_fasta, across a change of the index's digit count."""
+    import torch
+    from utree_amd import synth
+    g = torch.Generator().manual_seed(3)
+    L, n = 37, 250
+    bases = torch.tensor(list(b"ACGTN"), dtype=torch.uint8)[torch.randint(0, 5, (n * L,), generator=g)]
+    r = synth.SynthReads(bases=bases, off=None, length=None, n=n, read_len=L)
+    for first in (0, 95, 999_900):
+        assert bytes(synth.fasta_tensor(r, first).numpy().tobytes()) == synth.reads_to_fasta(r, first)
+
+
+def test_kernel_source_hash_follows_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py uses a kept profile only for the library built from exactly the profiled kernel sources: the hash must change with them."""
+    import shutil
+    from utree_amd import lib as ulib
+    a = ulib.kernel_source_sha256()
+    assert a == ulib.kernel_source_sha256() and len(a) == 64
+    fake = tmp_path / "pkg"
+    shutil.copytree(os.path.join(os.path.dirname(ulib.__file__), "csrc"), fake / "csrc", ignore=shutil.ignore_patterns("*.o"))
+    monkeypatch.setattr(ulib, "_HERE", str(fake))
+    assert ulib.kernel_source_sha256() == a
+    with open(fake / "csrc" / "kernels.hip", "a") as f:
+        f.write("// touched\n")
+    assert ulib.kernel_source_sha256() != a
+
+
+def test_profile_entries_name_their_kernel_and_sources():
+    """profiles/traffic.json (what bench.py reads roofline.traffic from): every entry carries the kernel signature, the hash of
+    the kernel sources it was profiled from and the counters the fractions are computed from."""
+    import json
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert tj
+    for key, e in tj.items():
+        assert key.startswith("nodes=") and ",k=" in key and ",rc=" in key
+        assert "classify_" in e["kernel"] and len(e["kernel_source_sha256"]) == 64
+        assert e["hbm_bytes_per_launch"] > 0 and e["avg_launch_ms"] > 0 and e["SQ_INSTS_VALU_per_launch"] > 0

@@ -942,8 +942,8 @@ __global__ void lookup_k(utk_image im, const uint64_t *__restrict__ hi, const ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// model_k: measurement aid for bench.py's byte model (not on the search path).  One wavefront per read of up to
-// MODEL_CAP staged bases; per read it counts the valid windows, the DISTINCT 64-byte buckets they address (what the
+// model_k: measurement aid for bench.py's byte model (not on the search path).  One wavefront per read (longer reads in pieces
+// of MODEL_CAP windows); per read it counts the valid windows, the DISTINCT 64-byte buckets they address (what the
 // classify kernels must fetch at least once per read), the distinct 128-byte HBM lines those buckets lie in, and the
 // distinct buckets that end in an overflow descriptor.  Windows and buckets are evaluated the slow, direct way
 // (minimizer<W>() per window) -- deliberately independent of the sliding-minimum code of the search kernels.
@@ -961,37 +961,42 @@ __global__ __launch_bounds__(256) void model_k(utk_image im, const uint8_t *__re
         const uint32_t L = len[r];
         const uint64_t o = off[r];
         const uint64_t total = do_rc ? 2ull * L + 1 : L;
-        if (total > MODEL_CAP || total < K) { if (total < K) ++c_reads; continue; }
         ++c_reads;
-        const uint32_t nwin = (uint32_t)total - K + 1;
-        for (uint32_t i = lane; i < nwin; i += 64) {
-            uint64_t khi = 0, klo = 0;
-            bool ok = true;
-            for (uint32_t j = i; j < i + K; ++j) {
-                uint32_t code = 0; bool bad = true;
-                if (j < L) base_code(bases[o + j], code, bad);
-                else if (j > L) { base_code(bases[o + (2 * L - j)], code, bad); code ^= 3u; }
-                ok = ok && !bad;
-                khi = (khi << 2) | (klo >> 62); klo = (klo << 2) | code;
+        if (total < K) continue;
+        const uint64_t nwin_all = total - K + 1;
+        // longer reads in pieces of MODEL_CAP windows: buckets are counted as distinct within a piece (a bucket that two pieces
+        // share counts twice: at most one per piece, < 1 %)
+        for (uint64_t w0 = 0; w0 < nwin_all; w0 += MODEL_CAP) {
+            const uint32_t nwin = (uint32_t)(nwin_all - w0 < MODEL_CAP ? nwin_all - w0 : MODEL_CAP);
+            for (uint32_t i = lane; i < nwin; i += 64) {
+                uint64_t khi = 0, klo = 0;
+                bool ok = true;
+                for (uint64_t j = w0 + i; j < w0 + i + K; ++j) {
+                    uint32_t code = 0; bool bad = true;
+                    if (j < L) base_code(bases[o + j], code, bad);
+                    else if (j > L) { base_code(bases[o + (2ull * L - j)], code, bad); code ^= 3u; }
+                    ok = ok && !bad;
+                    khi = (khi << 2) | (klo >> 62); klo = (klo << 2) | code;
+                }
+                uint64_t bucket = ~0ull;
+                if (ok) { MinKey<W> mk; min_split<W>(W == 16 ? khi : 0ull, klo, im.regions, bucket, mk); }
+                s_b[wv][i] = bucket;
             }
-            uint64_t bucket = ~0ull;
-            if (ok) { MinKey<W> mk; min_split<W>(W == 16 ? khi : 0ull, klo, im.regions, bucket, mk); }
-            s_b[wv][i] = bucket;
-        }
-        wave_lds_fence();
-        for (uint32_t i = lane; i < nwin; i += 64) {
-            const uint64_t b = s_b[wv][i];
-            if (b == ~0ull) continue;
-            ++c_win;
-            bool first_b = true, first_l = true;
-            for (uint32_t j = 0; j < i; ++j) { const uint64_t x = s_b[wv][j]; first_b = first_b && x != b; first_l = first_l && (x == ~0ull || (x >> 1) != (b >> 1)); }
-            c_buck += first_b; c_line += first_l;
-            if (first_b) {
-                const Bucket<W, I> bk = load_bucket<W, I>(im.table, b);
-                c_over += mrec_flag<W, I>(bk.e[BucketOf<W, I>::CAP - 1]) == 2;
+            wave_lds_fence();
+            for (uint32_t i = lane; i < nwin; i += 64) {
+                const uint64_t b = s_b[wv][i];
+                if (b == ~0ull) continue;
+                ++c_win;
+                bool first_b = true, first_l = true;
+                for (uint32_t j = 0; j < i; ++j) { const uint64_t x = s_b[wv][j]; first_b = first_b && x != b; first_l = first_l && (x == ~0ull || (x >> 1) != (b >> 1)); }
+                c_buck += first_b; c_line += first_l;
+                if (first_b) {
+                    const Bucket<W, I> bk = load_bucket<W, I>(im.table, b);
+                    c_over += mrec_flag<W, I>(bk.e[BucketOf<W, I>::CAP - 1]) == 2;
+                }
             }
+            wave_lds_fence();
         }
-        wave_lds_fence();
     }
     // lane 0 alone counted the reads; the other figures are summed over the lanes
     unsigned long long v[4] = {c_win, c_buck, c_line, c_over};
