@@ -77,7 +77,7 @@ int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
 
 static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     memset(h, 0, sizeof *h);
-    h->magic = UTREE_IMG_MAGIC; h->version = 6;   /* 6: k = 32 / u16-label records keep the rest in their low word (scan_bucket82) */
+    h->magic = UTREE_IMG_MAGIC; h->version = 7;   /* 6: k = 32 / u16-label records keep the rest in their low word (scan_bucket82); 7: the MIN area keeps the overflow runs only */
     h->W = ctr->info.W; h->I = ctr->info.I; h->k = ctr->info.k;
     h->fine_bits = F; h->rec_words = utree_rec_words(h->W, h->I);
     h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
@@ -136,6 +136,17 @@ static int device_ok(int device, int *n_cu) {
 }
 
 /* ---- build ---------------------------------------------------------------------------------- */
+/* bytes [src, src+size) of the image -> [dst, dst+size), dst < src, on one stream (pieces no longer than the shift never overlap) */
+static int move_down(char *img, uint64_t dst, uint64_t src, uint64_t size, hipStream_t st) {
+    if (dst == src || !size) return 0;
+    const uint64_t step = src - dst;
+    for (uint64_t done = 0; done < size; done += step) {
+        const uint64_t n = size - done < step ? size - done : step;
+        if (hipMemcpyAsync(img + dst + done, img + src + done, n, hipMemcpyDeviceToDevice, st) != hipSuccess) return 1;
+    }
+    return 0;
+}
+
 typedef struct {
     utree_dev *d;
     const utree_ctr *ctr;
@@ -262,13 +273,49 @@ static int build_finish(builder *b, const void *d_binix_raw) {
             d->hdr.n_irregular += counters[1];
             if (timing_on()) fprintf(stderr, "[utree_amd] image: %llu bucket(s) beyond the overflow descriptor's range: %llu bins take the exact-probe path\n", counters[0], counters[1]);
         }
-        /* nothing reads the FILE records when every bin is ascending: leave them out of the image */
-        if (!(d->hdr.flags & UTREE_F_IRREGULAR)) d->hdr.total_bytes = d->hdr.off_recs;
+        /* Of the sorted MIN array only the buckets' overflow runs are read again: pack them and let everything behind them move
+         * down (the array of ALL nodes was a third of the image).  The FILE records go last and stay only when some bin needs
+         * the exact-probe path. */
+        {
+            uint64_t kept = 0;
+            const utree_image_header o = d->hdr;
+            KCHK(utk_compact_overflow(o.W, o.I, (uint64_t *)(img + o.off_table), o.n_slots, (uint64_t *)(img + o.off_mrecs), &kept, st));
+            KCHK(utk_fill_recs_pad((uint64_t *)(img + o.off_mrecs) + kept * o.rec_words, 8 * o.rec_words, st));
+            utree_image_header *h = &d->hdr;
+            const uint64_t coarse_b = (uint64_t)UTREE_NUMBINS * ((o.flags & UTREE_F_OFF64) ? 8 : 4), irreg_b = (1u << 24) / 8;
+            const uint64_t loff_b = ((uint64_t)o.n_labels + 1) * 4, blob_b = o.label_blob_bytes + 64, r2i_b = (uint64_t)o.n_labels * 4;
+            const uint64_t recs_b = (o.n_nodes + 8) * o.rec_words * 8;
+            uint64_t off = align_up(o.off_mrecs + (kept + 8) * o.rec_words * 8, 4096);
+            h->n_min = kept;
+            h->off_coarse = off; off = align_up(off + coarse_b, 256);
+            h->off_irreg = off; off = align_up(off + irreg_b, 256);
+            h->off_label_off = off; off = align_up(off + loff_b, 256);
+            h->off_label_blob = off; off = align_up(off + blob_b, 256);
+            h->off_rank2ix = off; off = align_up(off + r2i_b, 4096);
+            h->off_recs = off;
+            if (h->flags & UTREE_F_IRREGULAR) off = align_up(off + recs_b, 4096);
+            h->total_bytes = off;
+            if (move_down(img, h->off_coarse, o.off_coarse, coarse_b, st) || move_down(img, h->off_irreg, o.off_irreg, irreg_b, st) ||
+                move_down(img, h->off_label_off, o.off_label_off, loff_b, st) || move_down(img, h->off_label_blob, o.off_label_blob, blob_b, st) ||
+                move_down(img, h->off_rank2ix, o.off_rank2ix, r2i_b, st) ||
+                ((h->flags & UTREE_F_IRREGULAR) && move_down(img, h->off_recs, o.off_recs, recs_b, st))) { rc = UTREE_E_HIP; goto fail; }
+            HIPCHK(hipStreamSynchronize(st));
+            if (timing_on()) fprintf(stderr, "[utree_amd] image: %llu of %llu nodes in overflow runs; packed image %.2f GiB (built in %.2f GiB)\n",
+                                     (unsigned long long)kept, (unsigned long long)o.n_nodes, (double)h->total_bytes / 1073741824.0, (double)full_bytes / 1073741824.0);
+        }
     }
-    (void)full_bytes;
     d->image_bytes = d->hdr.total_bytes;
     HIPCHK(hipMemcpyAsync(img, &d->hdr, sizeof d->hdr, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
+    /* an image this handle allocated itself is moved into an allocation of its final size: the build area goes back to the device */
+    if (d->owns && d->hdr.total_bytes + ((uint64_t)256 << 20) < full_bytes && !getenv("UTREE_KEEP_BUILD_AREA")) {
+        void *small = NULL;
+        if (hipMalloc(&small, d->hdr.total_bytes) == hipSuccess) {
+            hipError_t e1 = hipMemcpyAsync(small, d->image, d->hdr.total_bytes, hipMemcpyDeviceToDevice, st), e2 = hipStreamSynchronize(st);
+            if (e1 == hipSuccess && e2 == hipSuccess) { hipFree(d->image); d->image = small; }
+            else { hipFree(small); (void)hipGetLastError(); }
+        } else (void)hipGetLastError();
+    }
     bind_image(d);
 fail:
     if (b->d_counters) hipFree(b->d_counters);
@@ -375,7 +422,7 @@ int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t byt
     if (!d) return UTREE_E_NOMEM;
     d->device = device; d->n_cu = n_cu; d->image = d_image; d->owns = 0;
     HIPCHK(hipMemcpy(&d->hdr, d_image, sizeof d->hdr, hipMemcpyDeviceToHost));
-    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 6 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
+    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 7 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
     if (ctr && (ctr->info.W != d->hdr.W || ctr->info.I != d->hdr.I || ctr->info.n_nodes != d->hdr.n_nodes ||
                 ctr->info.n_labels != d->hdr.n_labels)) { rc = UTREE_E_ARG; goto fail; }
     d->image_bytes = d->hdr.total_bytes;

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include "device_common.hpp"
@@ -200,6 +201,37 @@ __global__ void flag_saturated_k(const uint32_t *__restrict__ Hs, const IDX *__r
         const uint32_t p = bin_of<OFF>(coarse, c0 + (uint64_t)idx[j]);
         const uint32_t bit = 1u << (p & 31);
         if (!(__atomic_load_n(&irreg[p >> 5], __ATOMIC_RELAXED) & bit) && !(atomicOr(&irreg[p >> 5], bit) & bit)) atomicAdd(&counters[1], 1ull);
+    }
+}
+
+// After the table is built only the overflow runs of the MIN array are ever read again (records that sit inline in a bucket
+// are found there).  ovf_count_k / ovf_move_k keep those runs alone, packed in bucket order, and point the descriptors at
+// their new places: the sorted array of ALL nodes (8-32 bytes per node) leaves the image.
+template <int W, int I>
+__global__ void ovf_count_k(const uint64_t *__restrict__ table, uint64_t n_buckets, uint32_t *__restrict__ cnt) {
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = 8 / EW;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t d = table[b * 8 + (uint64_t)(CAP - 1) * EW + KW];
+        uint32_t c = (d >> 62) == 2 ? (uint32_t)((d >> 40) & 0x3FFFFFull) : 0u;
+        if (c == 0x3FFFFFu) c = 0;           // a saturated run is never followed (its nodes' bins take the exact-probe path): nothing to keep
+        cnt[b] = c;
+    }
+}
+template <int W, int I>
+__global__ void ovf_move_k(uint64_t *__restrict__ table, uint64_t n_buckets, const uint32_t *__restrict__ cnt,
+                           const uint64_t *__restrict__ prefix, const uint64_t *__restrict__ mrecs, uint64_t *__restrict__ packed) {
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = 8 / EW;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = cnt[b];
+        uint64_t *dp = table + b * 8 + (uint64_t)(CAP - 1) * EW + KW;
+        if (!c) {
+            // a saturated descriptor becomes an empty run: a word that is no node finds nothing there (words of nodes never come here)
+            if ((*dp >> 62) == 2) *dp = MFLAG_RUN;
+            continue;
+        }
+        const uint64_t d = *dp, src = d & M40, dst = prefix[b];
+        for (uint64_t q = 0; q < (uint64_t)c * EW; ++q) packed[dst * EW + q] = mrecs[src * EW + q];
+        *dp = (d & ~M40) | (dst & M40);
     }
 }
 
@@ -462,6 +494,53 @@ int utk_compress_chunk(uint32_t W_, uint32_t I_, const void *d_in, uint64_t firs
 int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream) {
     fill_pad_k<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(d_recs_end, words);
     return (int)hipGetLastError();
+}
+
+struct widen32 { __device__ uint64_t operator()(uint32_t v) const { return v; } };
+/* Pack the overflow runs to the front of d_mrecs (bucket order) and repoint the buckets' descriptors; *n_kept = records kept. */
+int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n_buckets, uint64_t *d_mrecs, uint64_t *n_kept, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *cnt = nullptr;
+    uint64_t *prefix = nullptr, *packed = nullptr;
+    void *tmp = nullptr;
+    size_t tb = 0;
+    int rc = 0;
+    const uint32_t EW = utree_rec_words(W_, I_);
+    *n_kept = 0;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto done; } } while (0)
+    CK(hipMalloc((void **)&cnt, (n_buckets + 1) * 4));
+    CK(hipMalloc((void **)&prefix, (n_buckets + 1) * 8));
+    CK(hipMemsetAsync(cnt + n_buckets, 0, 4, st));
+    {
+        int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
+            ovf_count_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(n_buckets) > 65536 ? 65536 : grid_for(n_buckets)), dim3(256), 0, st>>>(d_table, n_buckets, cnt);
+        });
+        if (drc) { rc = drc; goto done; }
+    }
+    {
+        auto in = rocprim::make_transform_iterator((const uint32_t *)cnt, widen32());
+        CK(rocprim::exclusive_scan(nullptr, tb, in, prefix, (uint64_t)0, (size_t)n_buckets + 1, rocprim::plus<uint64_t>(), st));
+        CK(hipMalloc(&tmp, tb ? tb : 8));
+        CK(rocprim::exclusive_scan(tmp, tb, in, prefix, (uint64_t)0, (size_t)n_buckets + 1, rocprim::plus<uint64_t>(), st));
+        unsigned long long total = 0;
+        CK(hipMemcpyAsync(&total, prefix + n_buckets, 8, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        *n_kept = total;
+        if (total) {
+            CK(hipMalloc((void **)&packed, (size_t)total * EW * 8));
+            int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
+                ovf_move_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(n_buckets) > 65536 ? 65536 : grid_for(n_buckets)), dim3(256), 0, st>>>(
+                    d_table, n_buckets, cnt, prefix, d_mrecs, packed);
+            });
+            if (drc) { rc = drc; goto done; }
+            CK(hipMemcpyAsync(d_mrecs, packed, (size_t)total * EW * 8, hipMemcpyDeviceToDevice, st));
+        }
+        CK(hipStreamSynchronize(st));
+    }
+done:
+#undef CK
+    (void)hipFree(cnt); (void)hipFree(prefix); (void)hipFree(packed); (void)hipFree(tmp);
+    return rc;
 }
 
 /* nodes [c0, c0+m) = what the (monotone) bin table reaches.  d_overflow[0] += buckets whose run saturates the descriptor,

@@ -80,6 +80,7 @@ int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const 
 int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
                   const uint64_t *d_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
                   unsigned long long *d_overflow, void *stream);
+int utk_compact_overflow(uint32_t W, uint32_t I, uint64_t *d_table, uint64_t n_buckets, uint64_t *d_mrecs, uint64_t *n_kept, void *stream);
 int utk_compress_chunk(uint32_t W, uint32_t I, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
                        void *d_out, void *stream);
 int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream);
