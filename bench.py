@@ -314,7 +314,11 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
                                         (e.get("SQ_INSTS_VMEM_RD_per_launch", 0.0) + e.get("SQ_INSTS_VMEM_WR_per_launch", 0.0)) / args.batch_reads))
                 fr = {"hbm (measured traffic)": roof["hbm_frac_measured"], "hbm (byte model)": roof["frac"] or 0.0,
                       "valu issue": valu, "salu issue": salu}
-                roof["binding"] = max(fr, key=fr.get)
+                roof["highest_fraction"] = max(fr, key=fr.get)
+                if e.get("SQ_WAVE_CYCLES_per_launch") and e.get("SQ_WAIT_INST_ANY_per_launch"):
+                    roof["wave_cycles_waiting_for_issue"] = e["SQ_WAIT_INST_ANY_per_launch"] / e["SQ_WAVE_CYCLES_per_launch"]
+                roof["limiter_note"] = ("no unit is saturated: the kernel is bound by each wavefront's chain of dependent steps (LDS round trips, two bucket "
+                                        "fetches, the tally) at the hardware's limit of 8 wavefronts per SIMD -- DESIGN.md section 5 has the experiments")
     except Exception as ex:                                   # a broken profile file must not take the line down
         prof["why_not"] = repr(ex)
     roof["profile"] = prof
