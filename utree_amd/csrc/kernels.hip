@@ -386,6 +386,8 @@ template <int W, int I, bool EXC, typename OFF, int CAP, bool LISTED, int RCMODE
 #ifndef UTREE_SHORT_MIN_WAVES
 #define UTREE_SHORT_MIN_WAVES 8
 #endif
+// (80 scalar registers at 8 waves per SIMD: the surplus sits in the lanes of a vector register, one v_readlane per use; lifting the
+// cap with amdgpu_waves_per_eu(1, 8) removes those and costs the eighth wave -- measured 9 % slower)
 __global__ __launch_bounds__(256, CAP > SHORT2_CAP ? (I == 2 ? 4 : 3) : (I == 2 ? UTREE_SHORT_MIN_WAVES : 5))
 void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
                       const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc_arg, utree_result *__restrict__ out,

@@ -41,8 +41,11 @@ template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket(cons
     return b;
 }
 
-// the bucket at a byte address computed from the LDS region table: the address space is stated (global), or the loads would be
-// flat ones
+// The bucket at a byte address computed from the LDS region table: the address space is stated (global), or the loads would be
+// flat ones.  Default cache policy on purpose: the four 16-byte loads of a lane -- and those of the ~9 lanes whose windows share
+// the bucket -- then merge in the L1's miss queue into one request to the L2; with the non-temporal policy (which serves single
+// 8-byte random reads best, load_slot) every one of the four instructions went to the L2 on its own (TCC_HIT 3x TCC_MISS) and the
+// kernel was 12 % slower (same-box, round 2).
 template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket_at(uint64_t addr) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef const __attribute__((address_space(1))) u64x2 *gptr;
@@ -51,7 +54,7 @@ template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket_at(u
     constexpr int EW = RecTraits<W, I>::EW, CAP = 8 / EW;
     u64x2 v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = __builtin_nontemporal_load(p + q);
+    for (int q = 0; q < 4; ++q) v[q] = p[q];
 #pragma unroll
     for (int i = 0; i < CAP; ++i)
 #pragma unroll
