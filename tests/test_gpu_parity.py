@@ -462,3 +462,43 @@ def test_framing_fuzz_vs_oracle(torch_cuda, tmp_path):
             gcode, st = search_gg(db, [tree], str(fa), str(got), rc=rc, threads=2)
             assert {lib.OK: 0, lib.E_FASTA: 2, lib.E_IO: 1}[gcode] == code, seed
             assert (got.read_bytes() if got.exists() else b"") == (want.read_bytes() if want.exists() else b""), seed
+
+
+def test_tally_workspace_under_label_diversity_and_mixed_lengths(torch_cuda):
+    """The (rank, count) lists of a batch come out of one cursor shared by the 150-bp-class pass and the mid-length pass; the
+    workspace bound (dev_image.c::carve) has to hold when nearly every window hits a different label and both passes run: reads of
+    150 and 400 bp whose planted k-mers come from random labels, many reads, against the oracle."""
+    torch = torch_cuda
+    from utree_amd import synth
+    dev = torch.device("cuda:0")
+    sdb = synth.make_db(dev, 40_000_000, keep_raw=True)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    parts, offs, lens, at = [], [], [], 0
+    for L, n in ((150, 300_000), (400, 120_000)):
+        slots = L // 32
+        node = torch.randint(0, sdb.n_nodes, (n, slots), generator=g, device=dev)                  # a random node = a random label per k-mer
+        hi = synth.mix64(node ^ synth._s64(sdb.seed))
+        shifts = torch.arange(62, -2, -2, device=dev, dtype=torch.int64)
+        codes = (hi.unsqueeze(-1) >> shifts) & 3
+        acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+        seq = acgt[torch.randint(0, 4, (n, L), generator=g, device=dev)]
+        seq[:, : slots * 32] = acgt[codes].view(n, slots * 32)
+        parts.append(seq.contiguous().view(-1))
+        offs.append(torch.arange(n, dtype=torch.int64, device=dev) * L + at)
+        lens.append(torch.full((n,), L, dtype=torch.int32, device=dev))
+        at += n * L
+    bases, off, ln = torch.cat(parts), torch.cat(offs), torch.cat(lens)
+    perm = torch.randperm(off.numel(), device=dev, generator=g)
+    off, ln = off[perm].contiguous(), ln[perm].contiguous()
+    got = sdb.tree.classify(bases, off, ln, rc=True).cpu().numpy()
+    o = orc.OracleDB.from_memory(sdb.W, 2, sdb.binix.cpu().numpy().view(np.uint32).astype(np.uint64), sdb.records.cpu().numpy(), sdb.label_text)
+    want = o.classify_batch(bases.cpu().numpy(), off.cpu().numpy().astype(np.uint64), ln.cpu().numpy().astype(np.uint32), rc=True, threads=16)
+    g32 = got.view(np.uint32)
+    assert np.array_equal(g32[:, 2], want["found"]) and np.array_equal(g32[:, 3], want["uix"])
+    hit = want["found"] > 0
+    assert np.array_equal(g32[hit, 0], want["label"][hit]) and np.array_equal(got[hit, 1], want["cut"][hit])
+    multi = want["uix"] > 1
+    assert np.array_equal(g32[multi, 4], want["sl"][multi]) and np.array_equal(g32[multi, 5], want["ol"][multi])
+    assert float(want["uix"].mean()) > 3.5                                                     # nearly every hit a label of its own
+    sdb.tree.close()

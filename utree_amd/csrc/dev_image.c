@@ -474,8 +474,14 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
     uint64_t off = 0;
     char *b = (char *)ws;
     w->cursors = (unsigned long long *)(b + off); off = align_up(off + UTREE_CURSOR_BYTES, 256);
-    /* every wave wastes < one read's windows per chunk refill and may leave one chunk part-used */
-    w->tally_cap = ((do_rc ? 2 : 1) * total_bases + (uint64_t)n_reads) * 9 / 8 + (uint64_t)d->n_cu * 32 * UTREE_TALLY_CHUNK + 4096;
+    /* (rank, count) lists: a read needs at most one entry per window.  Waves sub-allocate from UTREE_TALLY_CHUNK-entry chunks: a
+     * refill abandons fewer than UTREE_TALLY_CHUNK / 16 entries of the old chunk (longer lists reserve exactly their length), i.e.
+     * less than 1/15 of what it used, and every wave may leave ONE chunk part-used -- the resident waves of the 150-bp-class pass
+     * (8 per SIMD: 32 per CU) and, in a batch that has mid-length reads, those of the mid pass (5 workgroups of 4 per CU) on top:
+     * both passes draw from the same cursor.  The kernels do not check the cursor; this bound is what makes that safe. */
+    const uint64_t max_total_ = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
+    const uint64_t waves_per_cu = 32 + (max_total_ > UTREE_SHORT_CAP ? 20 : 0);
+    w->tally_cap = ((do_rc ? 2 : 1) * total_bases + (uint64_t)n_reads) * 9 / 8 + (uint64_t)d->n_cu * waves_per_cu * UTREE_TALLY_CHUNK + 4096;
     w->tally = (uint64_t *)(b + off); off = align_up(off + w->tally_cap * 8, 256);
     w->long_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
     w->mid_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
