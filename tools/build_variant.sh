@@ -1,11 +1,12 @@
 #!/bin/bash
-# tools/build_variant.sh <name> [-DFLAG ...] : utree_amd/libexp_<name>.so = the library with kernels.hip (and dev_image.c) compiled
+# tools/build_variant.sh <name> [-DFLAG ...] : utree_amd/libexp_<name>.so = the library with kernels.hip, lanes_kernel.hip and dev_image.c compiled
 # with extra flags (same-box A/B of kernel variants: UTREE_AMD_SO selects the library for bench.py)
 set -e
 N=$1; shift
 cd /root/repo/utree_amd/csrc
 /opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-parameter -Wno-unused-function -mllvm -amdgpu-load-store-vectorizer=0 "$@" -c kernels.hip -o /tmp/kernels_$N.o
+/opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-parameter -Wno-unused-function "$@" -c lanes_kernel.hip -o /tmp/lanes_kernel_$N.o
 gcc -std=gnu11 -O2 -g -fPIC -fopenmp -I/opt/rocm/include "$@" -c dev_image.c -o /tmp/dev_image_$N.o
 OBJS=$(echo rank_kernels.o text_kernels.o build_gpu.o image_build.o ctr_host.o fasta.o search.o search_dev.o rccl_replicate.o compress.o rank.o build.o)
-gcc -shared -fopenmp -o ../libexp_$N.so /tmp/kernels_$N.o /tmp/dev_image_$N.o $OBJS -L/opt/rocm/lib -lamdhip64 -lrccl -lstdc++ -lz -lm -lpthread -Wl,-rpath,/opt/rocm/lib
+gcc -shared -fopenmp -o ../libexp_$N.so /tmp/kernels_$N.o /tmp/lanes_kernel_$N.o /tmp/dev_image_$N.o $OBJS -L/opt/rocm/lib -lamdhip64 -lrccl -lstdc++ -lz -lm -lpthread -Wl,-rpath,/opt/rocm/lib
 echo built libexp_$N.so

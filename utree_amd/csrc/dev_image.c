@@ -469,6 +469,13 @@ static uint32_t mid_limit(void) {
     return v;
 }
 
+/* UTREE_LANES=0 keeps every batch on the wave-per-read kernels (comparison runs) */
+static int lanes_enabled(void) {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("UTREE_LANES"); v = !(e && e[0] == '0'); }
+    return v;
+}
+
 static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc,
                   utk_workspace *w, size_t *bytes) {
     uint64_t off = 0;
@@ -480,7 +487,8 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
      * (8 per SIMD: 32 per CU) and, in a batch that has mid-length reads, those of the mid pass (5 workgroups of 4 per CU) on top:
      * both passes draw from the same cursor.  The kernels do not check the cursor; this bound is what makes that safe. */
     const uint64_t max_total_ = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
-    const uint64_t waves_per_cu = 32 + (max_total_ > UTREE_SHORT_CAP ? 20 : 0);
+    /* (a batch of the lane-per-read pass runs fewer waves of its own, but leaves reads to the mid pass's kernel: both terms) */
+    const uint64_t waves_per_cu = 32 + (max_total_ > UTREE_SHORT_CAP || max_total_ <= UTREE_LANES_CAP ? 20 : 0);
     w->tally_cap = ((do_rc ? 2 : 1) * total_bases + (uint64_t)n_reads) * 9 / 8 + (uint64_t)d->n_cu * waves_per_cu * UTREE_TALLY_CHUNK + 4096;
     w->tally = (uint64_t *)(b + off); off = align_up(off + w->tally_cap * 8, 256);
     w->long_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
@@ -539,7 +547,14 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     d->last_long = dominant == 2; d->last_mid = dominant == 1; d->last_rc = do_rc; d->last_short_cap = w.short_cap;
     if (w.mid_reads) KCHK(utk_route(d_len, n_reads, do_rc, &w, st));
     if (e0 && dominant == 0) HIPCHK(hipEventRecord(e0, st));
-    KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
+    const int lanes = lanes_enabled() && !w.mid_reads && utk_lanes_ok(&d->kimg, max_len, do_rc);
+    d->last_lanes = lanes;
+    if (lanes) {
+        /* one lane per read; the reads it leaves (bad bases, overflowing buckets, many hits) are listed for the wave-per-read kernel */
+        KCHK(utk_classify_lanes(&d->kimg, d_bases, d_off, d_len, n_reads, d_out, &w, d->n_cu, st));
+        KCHK(utk_classify_mid(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
+    } else
+        KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
     if (e0 && dominant == 0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
     if (w.mid_reads) {
         if (e0 && dominant == 1) HIPCHK(hipEventRecord(e0, st));
@@ -552,6 +567,9 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
         if (e0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
     }
     KCHK(utk_vote(&d->kimg, d_out, &w, n_reads, st));
+#ifdef UTREE_LANES_TIMERS
+    { extern void utk_lanes_phase_dump(void); static int lcalls; if (++lcalls == 6) utk_lanes_phase_dump(); }
+#endif
 #ifdef UTREE_PHASE_TIMERS
     { extern void utk_phase_dump(void); static int calls; if (++calls == 12) utk_phase_dump(); }
 #endif
@@ -572,6 +590,7 @@ fail:
 const char *utree_classify_kernel_name(const utree_dev *dc) {
     if (!dc) return "";
     utree_dev *d = (utree_dev *)dc;                       /* the signature string lives in the handle */
+    if (d->last_lanes && !d->last_long && !d->last_mid) return "classify_lanes_k";
     return d->last_long ? utk_classify_long_name(&d->kimg, d->kernel_sig, sizeof d->kernel_sig)
                         : utk_classify_short_name(&d->kimg, d->last_short_cap ? d->last_short_cap : UTREE_SHORT_CAP, d->last_mid, d->last_rc,
                                                   d->kernel_sig, sizeof d->kernel_sig);

@@ -1,0 +1,467 @@
+// lanes_kernel.hip -- classify_lanes_k: the 150-bp-class pass of the SEARCH_GG path with ONE LANE PER READ (gfx950 / wave64).
+//
+// classify_short_k (kernels.hip) gives a read to a wavefront: every step of the read's chain -- bytes, 2-bit stream, hashes,
+// sliding minimum, bucket, scan, tally -- is a round trip of that one wave through LDS or memory, and 8 waves per SIMD is all the
+// latency hiding there is.  Here a wavefront takes 64 reads at once and the chain is paid once per 64 reads:
+//
+//   phase 0  lane = read   the read's bytes -> 2-bit codes, packed big-endian, in the lane's LDS slot (itree.c:110-121)
+//   phase A  lane = read   all lanes walk their read base by base IN STEP (position is wave-uniform): rolling 16-mer, hash,
+//                          sliding minimum over the 17 16-mers of a window in REGISTERS (van Herk / Gil-Werman: one suffix
+//                          minimum per block of 17, one prefix minimum, one combine per window), and every maximal run of
+//                          windows that share their minimizer is appended to ONE list for the wave (ballot + mbcnt)
+//   phase B  lane = run    64 runs at a time: minimizer -> bucket (one 64-byte fetch per RUN, the next 64 already in flight);
+//                          every ENTRY of the bucket names the one window it could be the record of (minimizer position minus
+//                          the entry's position field): in the run? same outer 16 bases? -> a hit for the run's read
+//   phase C  lane = read   tally of the read's hits (itree.c:1028-1040): distinct labels ascending with counts, result record
+//
+// The hits a read gets are the same (window, record) pairs classify_short_k finds: it asks, per window, which entry of the
+// minimizer's bucket carries the window's key {hash bits, position, outer bases}; this kernel asks, per entry, which window of
+// the run has that key.  Reads this kernel does not take -- a base other than ACGTacgt, a bucket that continues in an overflow
+// run, more than LANES_HMAX hits, a wave whose run list is full -- go on the batch's list for the wave-per-read kernel
+// (utk_classify_mid), which also remains the kernel for k = 64, u32 labels, both strands, irregular tables and longer reads.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "device_common.hpp"
+#include "wave_common.hpp"
+
+using namespace utk;
+
+#ifndef UTREE_LANES_WAVES
+#define UTREE_LANES_WAVES 4
+#endif
+#ifndef UTREE_LANES_MIN_BLOCKS
+#define UTREE_LANES_MIN_BLOCKS 3
+#endif
+#ifndef UTREE_LANES_HMAX
+#define UTREE_LANES_HMAX 16
+#endif
+
+namespace {
+
+#ifdef UTREE_LANES_TIMERS
+__device__ unsigned long long g_lphase[8];
+#define LT_DECL unsigned long long lt_t = __builtin_readcyclecounter(), lt_acc[6] = {0, 0, 0, 0, 0, 0};
+#define LT(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); lt_acc[i] += n_ - lt_t; lt_t = n_; } while (0)
+#else
+#define LT_DECL
+#define LT(i)
+#endif
+
+constexpr int LANES_WAVES = UTREE_LANES_WAVES;        // waves per workgroup
+constexpr uint32_t LCAP = UTREE_LANES_CAP;            // bases a lane's slot holds
+constexpr uint32_t NWORD = LCAP / 16;                 // stream words with data
+constexpr uint32_t STRIDE = NWORD + 3;                // front pad, data, two tail pads; odd: lane slots fall on different banks
+static_assert(LCAP % 32 == 0 && (STRIDE & 1) == 1, "slot geometry");
+static_assert(LCAP + 16 + 48 <= 256, "positions are 8-bit fields of a run record");
+constexpr uint32_t RUNS_CAP = 1152;                   // runs per 64 reads (mean 14 per 150 bp read: ~900)
+constexpr uint32_t HMAX = UTREE_LANES_HMAX;           // hits per read this kernel keeps
+constexpr int32_t CUT_PENDING = -3, RANK_PENDING = -4;   // as in kernels.hip (vote_k finishes those results)
+
+__device__ __forceinline__ uint32_t low_bytes(uint32_t n) { return n >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n)) - 1u); }
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+
+__device__ __forceinline__ void store_result(utree_result *out, uint32_t label, int32_t cut, uint32_t found, uint32_t uix, uint32_t sl, uint32_t ol) {
+    uint32_t *o = (uint32_t *)out;
+    o[0] = label; o[1] = (uint32_t)cut; o[2] = found; o[3] = uix; o[4] = sl; o[5] = ol;
+}
+
+typedef const __attribute__((address_space(1))) uint32_t *gptr32;
+
+
+__global__ __launch_bounds__(LANES_WAVES * 64, UTREE_LANES_MIN_BLOCKS)
+void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+                      uint32_t n_reads, utree_result *__restrict__ out, utk_workspace ws) {
+    __shared__ uint32_t s_stream[LANES_WAVES][64 * STRIDE];
+    __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
+    __shared__ uint16_t s_hits[LANES_WAVES][64 * HMAX];       // [hit][read]: a lane's walk over its own hits is conflict-free
+    __shared__ uint32_t s_cnt[LANES_WAVES][64];
+    __shared__ uint8_t s_nwin[LANES_WAVES][64];
+    __shared__ uint32_t s_exc[LANES_WAVES][2];
+    __shared__ uint32_t s_pref[LANES_WAVES][64];
+    __shared__ uint4 s_ctx[LANES_WAVES][128];                 // phase B: two batches of 64 runs
+    __shared__ uint64_t s_adr[LANES_WAVES][128];
+    __shared__ uint64_t s_raddr[256];
+    __shared__ uint8_t s_rshift[256];
+    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) {            // region table in the window loop's form (kernels.hip: stage_regions)
+        const uint64_t e = im.regions[x];
+        const uint32_t sft = (uint32_t)e & 0xFFu;
+        s_raddr[x] = (uint64_t)(uintptr_t)im.table + (((e >> 8) - (((uint64_t)x << 24) >> sft)) << 6);
+        s_rshift[x] = (uint8_t)sft;
+    }
+    const uint32_t lane = lane_id();
+    const uint32_t wv = uni32(threadIdx.x >> 6);
+    uint32_t *stream = s_stream[wv];
+    uint32_t *runs = s_runs[wv];
+    uint16_t *hits = s_hits[wv];
+    uint32_t *cnt = s_cnt[wv];
+    uint8_t *nwins = s_nwin[wv];
+    uint32_t *excw = s_exc[wv];
+    uint32_t *pref = s_pref[wv];
+    uint4 *ctxs = s_ctx[wv];
+    uint64_t *adrs = s_adr[wv];
+    uint32_t *sl = stream + lane * STRIDE + 1;                            // the lane's slot, word 0
+    sl[-1] = 0; sl[NWORD] = 0; sl[NWORD + 1] = 0;                         // pads: zero for good
+    __syncthreads();
+
+    unsigned long long chunk_base = 0;
+    uint32_t chunk_left = 0;
+    const uint32_t wave_gid = blockIdx.x * LANES_WAVES + wv;
+    unsigned long long *parts = ws.cursors + 64;
+    const uint32_t part_len = ((n_reads + UTREE_WORK_PARTS - 1) / UTREE_WORK_PARTS + 63u) / 64u * 64u;
+    uint32_t part = wave_gid % UTREE_WORK_PARTS, parts_left = UTREE_WORK_PARTS;
+
+    LT_DECL
+    for (;;) {
+        // ---- the next 64 reads (one atomic per grab; a used-up part is left for good) ----
+        uint32_t item = 0, item_end = 0;
+        bool got = false;
+        while (parts_left) {
+            unsigned long long *ctr = parts + part * UTREE_WORK_STRIDE;
+            const uint64_t lo = (uint64_t)part * part_len;
+            const uint32_t avail = lo >= n_reads ? 0u : (uint32_t)(n_reads - lo < part_len ? n_reads - lo : part_len);
+            unsigned long long g = ~0ull;
+            if (lane == 0 && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < avail) g = atomicAdd(ctr, 64ull);
+            const uint32_t taken = uni32((uint32_t)(g > 0xFFFFFFFFull ? 0xFFFFFFFFull : g));
+            if (taken < avail) {
+                item = (uint32_t)lo + taken;
+                item_end = taken + 64u < avail ? item + 64u : (uint32_t)lo + avail;
+                got = true;
+                break;
+            }
+            part = part + 1 == UTREE_WORK_PARTS ? 0 : part + 1;
+            --parts_left;
+        }
+        if (!got) break;
+        LT(0);
+
+        // ---- phase 0: bytes -> packed 2-bit codes in the lane's slot ----
+        const uint32_t r = item + lane;
+        const bool have = r < item_end;
+        uint32_t L = 0;
+        uint64_t o = 0;
+        if (have) { L = len[r]; o = off[r]; }
+        bool exc = false;
+        if (L > LCAP) { exc = true; L = 0; }
+        {
+            const uint64_t a = (uint64_t)(uintptr_t)bases + o;
+            const uint32_t mf = (uint32_t)a & 3u;                         // the caller's buffer itself need not be aligned
+            const gptr32 p = (gptr32)(a - mf);
+            const uint32_t nd = L ? (L + mf + 3u) >> 2 : 0u;              // a dword is only touched when it holds a byte of the read
+            uint32_t bad = 0;
+            // every dword the read touches, requested before the first is used: one memory round trip for the 64 reads (indices
+            // past the read's last dword repeat it; a lane without a read loads nothing)
+            constexpr uint32_t NRAW = LCAP / 4 + 1;
+            uint32_t raw[NRAW];
+#pragma unroll
+            for (uint32_t d = 0; d < NRAW; ++d) raw[d] = 0u;
+            if (nd) {
+#pragma unroll
+                for (uint32_t d = 0; d < NRAW; ++d) raw[d] = p[umin(d, nd - 1u)];
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < NWORD / 2; ++c) {                    // 32 bases = 8 dwords = 2 stream words per step
+                uint32_t w[2] = {0u, 0u};
+#pragma unroll
+                for (uint32_t g = 0; g < 8; ++g) {
+                    const uint32_t gi = c * 8 + g;
+                    const uint32_t fm = low_bytes(L > 4u * gi ? L - 4u * gi : 0u);                     // bytes of the read
+                    const uint32_t word = __builtin_amdgcn_alignbyte(raw[gi + 1], raw[gi], mf) & fm;    // source bytes 4gi .. 4gi+3
+                    const uint32_t g2 = (word >> 1) & 0x03030303u;
+                    const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, g2);                // 0 1 2 3 -> A C T G
+                    const uint32_t z = (word & 0xDFDFDFDFu) ^ letter;                                  // non-zero byte = not ACGTacgt
+                    const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+                    bad |= nz & fm;
+                    const uint32_t code = g2 ^ ((g2 >> 1) & 0x01010101u);                              // A=0 C=1 G=2 T=3
+                    const uint32_t packed = (code * 0x40100401u) >> 24;                                // c0<<6 | c1<<4 | c2<<2 | c3
+                    w[g >> 2] = (w[g >> 2] << 8) | packed;
+                }
+                sl[2 * c] = w[0]; sl[2 * c + 1] = w[1];
+            }
+            if (bad) { exc = true; L = 0; }
+        }
+        const uint32_t nwin = L >= 32u ? L - 31u : 0u;
+        nwins[lane] = (uint8_t)nwin;
+        cnt[lane] = 0;
+        if (lane < 2) excw[lane] = 0;
+        const uint32_t maxnwin = uni32(wave_max_u32(nwin));
+        wave_lds_fence();
+        LT(1);
+
+        // ---- phase A: minimizer runs of all 64 reads, in step ----
+        uint32_t nruns = 0;
+        if (maxnwin) {
+            uint32_t A[17];
+            uint32_t m16 = sl[0];
+            A[0] = mix32(m16) & ~0x1FFu;
+#pragma unroll
+            for (uint32_t p = 16; p < 32; ++p) {
+                m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
+                A[p - 15] = (mix32(m16) & ~0x1FFu) | (p - 15u);
+            }
+            uint32_t run_first = 0, prev = 0;
+            const uint32_t lanec = lane << 24;
+            for (uint32_t b = 0;; ++b) {
+#pragma unroll
+                for (int rr = 15; rr >= 0; --rr) A[rr] = umin(A[rr], A[rr + 1]);        // suffix minima of the block
+                uint32_t P = 0;
+                bool done = false;
+#pragma unroll
+                for (uint32_t rr = 0; rr < 17; ++rr) {
+                    const uint32_t s = 17u * b + rr;                                  // window (wave-uniform)
+                    uint32_t wmin;
+                    if (rr == 0) wmin = A[0];
+                    else {
+                        const uint32_t p = s + 31u;                                   // the window's last base
+                        m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
+                        const uint32_t k = (mix32(m16) & ~0x1FFu) | (s + 16u);
+                        const uint32_t Sr = A[rr];
+                        A[rr - 1] = k;                                                // next block's key
+                        P = rr == 1 ? k : umin(P, k);                                 // prefix minimum of the next block
+                        wmin = umin(Sr, P);
+                    }
+                    if (s != 0) {
+                        const bool flush = s == maxnwin;
+                        const bool changed = flush || wmin != prev;
+                        const bool emit = changed && run_first < nwin;
+                        const uint64_t em = __ballot(emit);
+                        if (em) {
+                            const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, nruns));
+                            // {read | one past the run's last window | first window | minimizer position}
+                            if (emit && idx < RUNS_CAP) runs[idx] = ((prev & 0xFFu) | (run_first << 8)) + ((s << 16) + lanec);
+                            nruns += (uint32_t)__popcll(em);
+                        }
+                        if (changed) run_first = s;
+                        if (flush) { done = true; break; }
+                    }
+                    prev = wmin;
+                }
+                if (done) break;
+                const uint32_t p = 17u * b + 48u;
+                m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
+                A[16] = (mix32(m16) & ~0x1FFu) | (17u * b + 33u);
+            }
+            nruns = uni32(nruns);
+        }
+        bool wave_full = false;
+        if (nruns > RUNS_CAP) { wave_full = true; nruns = 0; }                         // every read of the grab goes on the list
+        wave_lds_fence();
+        LT(2);
+
+        // ---- phase B: 64 runs at a time.  A lane works out its own run's bucket address and what a scan needs of the run
+        // ({hash bits the bucket does not imply, run record, the 16 bases before and behind the minimizer}) and leaves both in LDS;
+        // the 64 buckets then come in with FOUR loads of 16 buckets each, the four lanes of a quad fetching the four 16-byte
+        // quarters of one bucket (one request per bucket to the memory pipeline instead of four: a lane fetching its whole bucket
+        // halves the chip's random-line rate, profiles/r01/membench_random_lines.txt), and every lane scans its quarter --
+        // two entries -- of four runs.  The next 64 buckets are in flight meanwhile.
+        // (a lane beyond the list repeats the list's last run -- its load stays inside the table -- with a tag no entry has)
+        uint32_t n_ovf = 0;
+        auto prepare = [&](uint32_t it, uint32_t buf) {
+            const uint32_t idx = it * 64u + lane;
+            const bool act = idx < nruns;
+            uint32_t rec = runs[act ? idx : nruns - 1u];
+            const uint32_t q = rec >> 24, ustar = rec & 0xFFu;
+            const uint32_t end = umin((rec >> 16) & 0xFFu, nwins[q]);
+            rec = (rec & 0xFF00FFFFu) | (end << 16);                                   // clipped to the read's windows
+            const uint32_t *sq = stream + q * STRIDE + 1 + (ustar >> 4);
+            const uint32_t rr = ustar & 15u, sh = (32u - 2u * rr) & 31u;
+            const uint32_t w_1 = sq[-1], w0 = sq[0], w1 = sq[1], w2 = sq[2];
+            const uint32_t m = rr ? __builtin_amdgcn_alignbit(w0, w1, sh) : w0;        // the minimizer's 16 bases
+            const uint32_t A = rr ? __builtin_amdgcn_alignbit(w_1, w0, sh) : w_1;      // the 16 bases in front of it
+            const uint32_t B = rr ? __builtin_amdgcn_alignbit(w1, w2, sh) : w1;        // the 16 bases behind it
+            const uint32_t h = mix32(m);
+            const uint32_t sft = s_rshift[h >> 24];
+            const uint32_t hlow = act ? (h & ((1u << sft) - 1u)) : 0xFFFFFFFFu;        // no entry's tag equals that
+            ctxs[buf * 64u + lane] = make_uint4(hlow, rec, A, B);
+            adrs[buf * 64u + lane] = s_raddr[h >> 24] + ((uint64_t)(h >> sft) << 6);
+        };
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) u32x4 *gptr128;
+        auto issue = [&](uint32_t buf, u32x4 (&P)[4]) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) P[k] = *(gptr128)(adrs[buf * 64u + 16u * k + (lane >> 2)] + 16u * (lane & 3u));
+        };
+        auto push = [&](uint32_t q, uint32_t rank) {
+            const uint32_t i = atomicAdd(&cnt[q], 1u);
+            if (i < HMAX) hits[i * 64u + q] = (uint16_t)rank;
+        };
+        auto scan = [&](uint32_t buf, const u32x4 (&P)[4]) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint4 c = ctxs[buf * 64u + 16u * k + (lane >> 2)];               // {hlow, rec, A, B} of the quad's run
+                const uint32_t first = (c.y >> 8) & 0xFFu;
+                const uint32_t d = (c.y & 0xFFu) - first, lenm1 = ((c.y >> 16) & 0xFFu) - 1u - first, q = c.y >> 24;
+                const uint64_t AB = ((uint64_t)c.z << 32) | c.w;
+                // an entry: rest | {flag2 0 hlow8 pos5 rank16}; the window that starts pos bases before the minimizer has the outer bases AB >> 2 pos
+                const uint32_t lo0 = P[k].x, hi0 = P[k].y, lo1 = P[k].z, hi1 = P[k].w;
+                const uint32_t pos0 = (hi0 >> 16) & 31u, pos1 = (hi1 >> 16) & 31u;
+                const bool hit0 = (hi0 >> 21) == c.x && (d - pos0) <= lenm1 && (uint32_t)(AB >> (2u * pos0)) == lo0 && (hi0 & 0xFFFFu) != 0xFFFFu;
+                const bool hit1 = (hi1 >> 21) == c.x && (d - pos1) <= lenm1 && (uint32_t)(AB >> (2u * pos1)) == lo1 && (hi1 & 0xFFFFu) != 0xFFFFu;
+                // The bucket continues in an overflow run (its last entry says so: the quad's fourth lane sees it): its windows are
+                // looked up there after the loop, one lane per WINDOW.  The run's record goes to the front of the run list --
+                // phase B has read that far: the slots of 64 more runs than it has scanned.
+                const uint64_t om = __ballot((lane & 3u) == 3u && c.x != 0xFFFFFFFFu && (hi1 >> 30) == 2u);
+                if (om) {
+                    if ((om >> lane) & 1ull) runs[n_ovf + lanes_below(om)] = c.y;
+                    n_ovf += (uint32_t)__popcll(om);
+                }
+                if (__ballot(hit0 || hit1)) {
+                    if (hit0) push(q, hi0 & 0xFFFFu);
+                    if (hit1) push(q, hi1 & 0xFFFFu);
+                }
+            }
+        };
+        if (nruns) {
+            const uint32_t nit = (nruns + 63u) >> 6;
+            u32x4 P0[4], P1[4];
+            prepare(0u, 0u); wave_lds_fence(); issue(0u, P0);
+            for (uint32_t it = 0; it < nit; it += 2) {                        // no branch around a load: the waits then count them
+                prepare(it + 1, 1u); wave_lds_fence(); issue(1u, P1);
+                scan(0u, P0);
+                wave_lds_fence();
+                prepare(it + 2, 0u); wave_lds_fence(); issue(0u, P0);
+                scan(1u, P1);
+                wave_lds_fence();
+            }
+        }
+        // ---- windows of the runs whose bucket overflows: exact search in the bucket's overflow run (wave_common.hpp: min_find), a lane per window ----
+        for (uint32_t ib = 0; ib < n_ovf; ib += 64) {
+            wave_lds_fence();
+            const uint32_t i = ib + lane;
+            uint32_t wn = 0;                                                       // windows of the lane's item
+            if (i < n_ovf) {
+                const uint32_t rec = runs[i];
+                wn = umin((rec >> 16) & 0xFFu, nwins[rec >> 24]) - ((rec >> 8) & 0xFFu);
+            }
+            uint32_t incl = wn;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(incl, dd); if (lane >= (uint32_t)dd) incl += t; }
+            pref[lane] = incl;
+            const uint32_t total = uni32((uint32_t)__shfl(incl, 63));
+            wave_lds_fence();
+            for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                if (t < total) {
+                    uint32_t lo = 0, hi = 63;                                      // the item whose windows include the t-th: first with pref > t
+#pragma unroll
+                    for (int st = 0; st < 6; ++st) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= t) lo = mid + 1; else hi = mid; }
+                    const uint32_t rec = runs[ib + lo];
+                    const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu;
+                    const uint32_t wnd = first + (t - (lo ? pref[lo - 1] : 0u));   // the window
+                    const uint32_t pos = ustar - wnd;                              // its minimizer's position, 0..16
+                    const uint32_t *sq = stream + q * STRIDE + 1 + (ustar >> 4);
+                    const uint32_t rr = ustar & 15u, sh = (32u - 2u * rr) & 31u;
+                    const uint32_t w_1 = sq[-1], w0 = sq[0], w1 = sq[1], w2 = sq[2];
+                    const uint32_t m = rr ? __builtin_amdgcn_alignbit(w0, w1, sh) : w0;
+                    const uint32_t A = rr ? __builtin_amdgcn_alignbit(w_1, w0, sh) : w_1;
+                    const uint32_t B = rr ? __builtin_amdgcn_alignbit(w1, w2, sh) : w1;
+                    const uint32_t rest = (uint32_t)((((uint64_t)A << 32) | B) >> (2u * pos));
+                    const uint32_t h = mix32(m);
+                    const uint32_t sft = s_rshift[h >> 24];
+                    const uint64_t baddr = s_raddr[h >> 24] + ((uint64_t)(h >> sft) << 6);
+                    const uint32_t hlow = h & ((1u << sft) - 1u);
+                    const uint64_t dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + 56);   // the bucket's last entry
+                    const uint64_t start = dsc & M40, n = (dsc >> 40) & 0x3FFFFFull;
+                    MinKey<8> mk; mk.hi = 0; mk.lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
+                    const uint32_t rank = min_find<8, 2>(im.mrecs, start, start + n, mk);
+                    if (rank != INVALID) push(q, rank);
+                }
+            }
+        }
+        wave_lds_fence();
+        LT(3);
+
+        // ---- phase C: tally (itree.c:1028-1040), result records, the list of reads left to the wave-per-read kernel ----
+        uint32_t F = cnt[lane];
+        if (((excw[lane >> 5] >> (lane & 31u)) & 1u) || F > HMAX || wave_full) exc = true;
+        const uint64_t xm = __ballot(have && exc);
+        if (xm) {
+            unsigned long long xb = 0;
+            if (lane == 0) xb = atomicAdd(&ws.cursors[UTREE_CUR_MID], (unsigned long long)__popcll(xm));
+            xb = uni64(xb);
+            if (have && exc) ws.mid_list[xb + lanes_below(xm)] = r;
+        }
+        const bool live = have && !exc;
+        if (!live) F = 0;
+        const uint32_t maxF = uni32(wave_max_u32(F));
+        // space for the (rank, count) lists: F entries per read with two or more hits, one reservation per wave and TALLY_CHUNK
+        const uint32_t need = F >= 2u ? F : 0u;
+        uint32_t incl = need;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(incl, dd); if (lane >= (uint32_t)dd) incl += t; }
+        const uint32_t total = uni32((uint32_t)__shfl(incl, 63));
+        if (total > chunk_left) {
+            unsigned long long nb = 0;
+            if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)UTREE_TALLY_CHUNK);
+            chunk_base = uni64(nb);
+            chunk_left = UTREE_TALLY_CHUNK;
+        }
+        const unsigned long long my_base = chunk_base + (incl - need);
+        chunk_base += total; chunk_left -= total;
+        const uint16_t *hq = hits + lane;
+        uint32_t cur = INVALID;
+        for (uint32_t j = 0; j < maxF; ++j) { const uint32_t h = j < F ? (uint32_t)hq[j * 64u] : INVALID; cur = umin(cur, h); }
+        const uint32_t first_rank = cur;
+        uint32_t nu = 0;
+        while (__ballot(cur != INVALID)) {                                    // one pass per distinct label, ascending = strcmp order (itree.c:1041)
+            uint32_t c = 0, nxt = INVALID;
+            for (uint32_t j = 0; j < maxF; ++j) {
+                const uint32_t h = j < F ? (uint32_t)hq[j * 64u] : INVALID;
+                c += h == cur ? 1u : 0u;
+                nxt = (h > cur && h < nxt) ? h : nxt;
+            }
+            if (cur != INVALID) {
+                if (need) ws.tally[my_base + nu] = (uint64_t)cur | ((uint64_t)c << 32);
+                ++nu;
+            }
+            cur = nxt;
+        }
+        if (live) {
+            if (F == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0);
+            else if (nu == 1) store_result(&out[r], first_rank, RANK_PENDING, F, 1, 0, 0);
+            else store_result(&out[r], 0, CUT_PENDING, F, nu, (uint32_t)my_base, (uint32_t)(my_base >> 32));
+        }
+        wave_lds_fence();
+        LT(4);
+    }
+#ifdef UTREE_LANES_TIMERS
+    if (lane == 0) { for (int q = 0; q < 5; ++q) atomicAdd(&g_lphase[q], lt_acc[q]); atomicAdd(&g_lphase[7], 1ull); }
+#endif
+}
+
+}  // namespace
+
+extern "C" {
+
+// The image and batch this kernel takes: k = 32, u16 labels, a regular table, forward strand only, no read beyond LCAP bases.
+int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc) {
+    return im->W == 8 && im->I == 2 && !(im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC)) && !do_rc && max_len <= LCAP;
+}
+
+int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
+                       utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+    if (!n_reads) return 0;
+    uint32_t blocks = (n_reads + 64u * LANES_WAVES - 1) / (64u * LANES_WAVES);
+    const uint32_t cap = (uint32_t)n_cu * UTREE_LANES_MIN_BLOCKS;
+    if (blocks > cap) blocks = cap;
+    classify_lanes_k<<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, d_out, *ws);
+    return (int)hipGetLastError();
+}
+
+#ifdef UTREE_LANES_TIMERS
+void utk_lanes_phase_dump(void) {
+    unsigned long long h[8];
+    static const char *nm[5] = {"grab", "phase 0: bytes -> codes", "phase A: minimizer runs", "phase B: buckets", "phase C: tally, results"};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lphase), sizeof h) != hipSuccess) return;
+    unsigned long long tot = 0;
+    for (int q = 0; q < 5; ++q) tot += h[q];
+    fprintf(stderr, "[lanes phase timers] %llu waves, %.4g cycles per wave\n", h[7], h[7] ? (double)tot / h[7] : 0.0);
+    for (int q = 0; q < 5; ++q) fprintf(stderr, "  %-28s %5.1f %%\n", nm[q], tot ? 100.0 * h[q] / tot : 0.0);
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lphase), h, sizeof h);
+}
+#endif
+
+}  // extern "C"

@@ -28,6 +28,7 @@ extern "C" {
 #define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds      */
 #define UTREE_SHORT2_CAP 640u                    /* ... its second size: 250-300 bp reads with the reverse strand */
 #define UTREE_MID_DEFAULT 2112u                  /* = UTREE_MID_CAP: since r01l the wave-per-read pass beats classify_long_k up to its capacity (2100 bp: 65 vs 46 M reads/s); UTREE_MID_LIMIT overrides */
+#define UTREE_LANES_CAP 160u                     /* bases the lane-per-read kernel (lanes_kernel.hip) holds per read */
 #define UTREE_MID_CAP 2112u                      /* ... and its mid-length instantiation; longer: classify_long */
 
 /* image flags */
@@ -103,6 +104,10 @@ typedef struct {
 int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                        uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu,
                        void *stream);
+/* lane-per-read pass (lanes_kernel.hip): whether it takes this image / batch; reads it leaves go on ws->mid_list */
+int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc);
+int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
+                       utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_route(const uint32_t *d_len, uint32_t n_reads, int do_rc, const utk_workspace *ws, void *stream);
 int utk_classify_mid(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                      uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
