@@ -28,6 +28,11 @@ __global__ __launch_bounds__(256) void gather_k(const uint64_t *__restrict__ tab
         if (MODE == 2) { uint64_t l2 = mix(s) & lines_mask; acc += p[0] + tab[l2 * 16]; }
         if (MODE == 3) { uint64_t v = p[0]; uint64_t l2 = (v ^ s) & lines_mask; acc += tab[l2 * 16 + 1]; }
         if (MODE == 4) { const ulonglong2 *q = (const ulonglong2 *)p; ulonglong2 v = q[0]; acc += v.x + v.y; }
+        if (MODE == 6) { const ulonglong2 *q = (const ulonglong2 *)(tab + (mix((tid >> 2) * 0x9E3779B97F4A7C15ull + i + 77) & lines_mask) * 16 + ((mix(tid >> 2) >> 40) & 1) * 8) + (tid & 3); ulonglong2 a = q[0]; acc += a.x + a.y; }
+        if (MODE == 7) { const uint64_t b0 = (mix((tid >> 2) * 0x9E3779B97F4A7C15ull + i * 4 + 77)); 
+            ulonglong2 a[4];
+            for (int k = 0; k < 4; ++k) { const ulonglong2 *q = (const ulonglong2 *)(tab + (mix(b0 + k) & lines_mask) * 16) + (tid & 3); a[k] = q[0]; }
+            acc += a[0].x + a[1].y + a[2].x + a[3].y; }
         if (MODE == 5) { const ulonglong2 *q = (const ulonglong2 *)(p + ((s >> 40) & 1) * 8); ulonglong2 a = q[0], b = q[1], c = q[2], d = q[3]; acc += a.x + b.y + c.x + d.y; }
     }
     out[tid] = acc;
@@ -43,9 +48,9 @@ int main(int argc, char **argv) {
     hipMalloc(&out, (size_t)blocks * threads * 8);
     uint64_t lines_mask = bytes / 128 - 1;
     uint64_t per_thread = 512;
-    const char *names[6] = {"A 1x8B/line", "B 2x8B same 128B line", "C 2x8B two lines", "D 2 dependent loads", "E 1x16B/line", "F 64B sector"};
+    const char *names[8] = {"A 1x8B/line", "B 2x8B same 128B line", "C 2x8B two lines", "D 2 dependent loads", "E 1x16B/line", "F 64B sector", "G 64B sector per QUAD (x4 iters)", "H 4 sectors per quad, 4 loads in flight"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int m = 0; m < 6; ++m) {
+        for (int m = 0; m < 8; ++m) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0);
             switch (m) {
@@ -55,6 +60,8 @@ int main(int argc, char **argv) {
                 case 3: gather_k<3><<<blocks, threads>>>(tab, lines_mask, per_thread, out); break;
                 case 4: gather_k<4><<<blocks, threads>>>(tab, lines_mask, per_thread, out); break;
                 case 5: gather_k<5><<<blocks, threads>>>(tab, lines_mask, per_thread, out); break;
+                case 6: gather_k<6><<<blocks, threads>>>(tab, lines_mask, per_thread, out); break;
+                case 7: gather_k<7><<<blocks, threads>>>(tab, lines_mask, per_thread, out); break;
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);

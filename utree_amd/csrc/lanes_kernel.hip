@@ -55,7 +55,7 @@ constexpr uint32_t NWORD = LCAP / 16;                 // stream words with data
 constexpr uint32_t STRIDE = NWORD + 3;                // front pad, data, two tail pads; odd: lane slots fall on different banks
 static_assert(LCAP % 32 == 0 && (STRIDE & 1) == 1, "slot geometry");
 static_assert(LCAP + 16 + 48 <= 256, "positions are 8-bit fields of a run record");
-constexpr uint32_t RUNS_CAP = 1152;                   // runs per 64 reads (mean 14 per 150 bp read: ~900)
+constexpr uint32_t RUNS_CAP = 1024;                   // runs per 64 reads (mean 14 per 150 bp read: ~900)
 constexpr uint32_t HMAX = UTREE_LANES_HMAX;           // hits per read this kernel keeps
 constexpr int32_t CUT_PENDING = -3, RANK_PENDING = -4;   // as in kernels.hip (vote_k finishes those results)
 
@@ -78,11 +78,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
     __shared__ uint16_t s_hits[LANES_WAVES][64 * HMAX];       // [hit][read]: a lane's walk over its own hits is conflict-free
     __shared__ uint32_t s_cnt[LANES_WAVES][64];
-    __shared__ uint8_t s_nwin[LANES_WAVES][64];
     __shared__ uint32_t s_exc[LANES_WAVES][2];
     __shared__ uint32_t s_pref[LANES_WAVES][64];
-    __shared__ uint4 s_ctx[LANES_WAVES][128];                 // phase B: two batches of 64 runs
-    __shared__ uint64_t s_adr[LANES_WAVES][128];
     __shared__ uint64_t s_raddr[256];
     __shared__ uint8_t s_rshift[256];
     for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) {            // region table in the window loop's form (kernels.hip: stage_regions)
@@ -97,11 +94,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     uint32_t *runs = s_runs[wv];
     uint16_t *hits = s_hits[wv];
     uint32_t *cnt = s_cnt[wv];
-    uint8_t *nwins = s_nwin[wv];
     uint32_t *excw = s_exc[wv];
     uint32_t *pref = s_pref[wv];
-    uint4 *ctxs = s_ctx[wv];
-    uint64_t *adrs = s_adr[wv];
     uint32_t *sl = stream + lane * STRIDE + 1;                            // the lane's slot, word 0
     sl[-1] = 0; sl[NWORD] = 0; sl[NWORD + 1] = 0;                         // pads: zero for good
     __syncthreads();
@@ -145,12 +139,13 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         if (have) { L = len[r]; o = off[r]; }
         bool exc = false;
         if (L > LCAP) { exc = true; L = 0; }
+        uint32_t badpos;                                                  // the read's one base that is not ACGTacgt, or far away
         {
             const uint64_t a = (uint64_t)(uintptr_t)bases + o;
             const uint32_t mf = (uint32_t)a & 3u;                         // the caller's buffer itself need not be aligned
             const gptr32 p = (gptr32)(a - mf);
             const uint32_t nd = L ? (L + mf + 3u) >> 2 : 0u;              // a dword is only touched when it holds a byte of the read
-            uint32_t bad = 0;
+            uint32_t bad = 0, nbad = 0, badg = 0;
             // every dword the read touches, requested before the first is used: one memory round trip for the 64 reads (indices
             // past the read's last dword repeat it; a lane without a read loads nothing)
             constexpr uint32_t NRAW = LCAP / 4 + 1;
@@ -173,17 +168,18 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                     const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, g2);                // 0 1 2 3 -> A C T G
                     const uint32_t z = (word & 0xDFDFDFDFu) ^ letter;                                  // non-zero byte = not ACGTacgt
                     const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
-                    bad |= nz & fm;
+                    bad |= nz & fm;                                                                    // one bad base per read is followed up: where it is
+                    { const uint32_t pc = (uint32_t)__builtin_popcount(nz & fm); nbad += pc; badg += pc * gi; }
                     const uint32_t code = g2 ^ ((g2 >> 1) & 0x01010101u);                              // A=0 C=1 G=2 T=3
                     const uint32_t packed = (code * 0x40100401u) >> 24;                                // c0<<6 | c1<<4 | c2<<2 | c3
                     w[g >> 2] = (w[g >> 2] << 8) | packed;
                 }
                 sl[2 * c] = w[0]; sl[2 * c + 1] = w[1];
             }
-            if (bad) { exc = true; L = 0; }
+            if (nbad > 1u) { exc = true; L = 0; }                          // two or more: left to the wave-per-read kernel
+            badpos = nbad == 1u ? 4u * badg + ((uint32_t)__builtin_ctz(bad) >> 3) : 0xFFFF0000u;
         }
         const uint32_t nwin = L >= 32u ? L - 31u : 0u;
-        nwins[lane] = (uint8_t)nwin;
         cnt[lane] = 0;
         if (lane < 2) excw[lane] = 0;
         const uint32_t maxnwin = uni32(wave_max_u32(nwin));
@@ -201,7 +197,10 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
                 A[p - 15] = (mix32(m16) & ~0x1FFu) | (p - 15u);
             }
-            uint32_t run_first = 0, prev = 0;
+            // A window that does not exist (beyond the read's last) or holds the bad base (itree.c:919-927) carries the key ~0 -- no
+            // 16-mer's -- instead of its minimizer's: the run before it ends there like at any change of minimizer, and a "run" of
+            // such windows is never listed.  `prev` starts as one, and the wave's last step is one for every lane: no flush case.
+            uint32_t run_first = 0, prev = 0xFFFFFFFFu;
             const uint32_t lanec = lane << 24;
             for (uint32_t b = 0;; ++b) {
 #pragma unroll
@@ -222,21 +221,19 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                         P = rr == 1 ? k : umin(P, k);                                 // prefix minimum of the next block
                         wmin = umin(Sr, P);
                     }
-                    if (s != 0) {
-                        const bool flush = s == maxnwin;
-                        const bool changed = flush || wmin != prev;
-                        const bool emit = changed && run_first < nwin;
-                        const uint64_t em = __ballot(emit);
-                        if (em) {
-                            const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, nruns));
-                            // {read | one past the run's last window | first window | minimizer position}
-                            if (emit && idx < RUNS_CAP) runs[idx] = ((prev & 0xFFu) | (run_first << 8)) + ((s << 16) + lanec);
-                            nruns += (uint32_t)__popcll(em);
-                        }
-                        if (changed) run_first = s;
-                        if (flush) { done = true; break; }
+                    const uint32_t wv = ((badpos - s) > 31u && s < nwin) ? wmin : 0xFFFFFFFFu;
+                    const bool changed = wv != prev;
+                    const bool emit = changed && prev != 0xFFFFFFFFu;
+                    const uint64_t em = __ballot(emit);
+                    if (em) {
+                        const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, nruns));
+                        // {read | one past the run's last window | first window | minimizer position}
+                        if (emit && idx < RUNS_CAP) runs[idx] = ((prev & 0xFFu) | (run_first << 8)) + ((s << 16) + lanec);
+                        nruns += (uint32_t)__popcll(em);
                     }
-                    prev = wmin;
+                    if (changed) run_first = s;
+                    prev = wv;
+                    if ((rr % 6u) == 0u && s >= maxnwin) { done = true; break; }      // (every lane's windows from maxnwin on are none)
                 }
                 if (done) break;
                 const uint32_t p = 17u * b + 48u;
@@ -250,82 +247,103 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         wave_lds_fence();
         LT(2);
 
-        // ---- phase B: 64 runs at a time.  A lane works out its own run's bucket address and what a scan needs of the run
-        // ({hash bits the bucket does not imply, run record, the 16 bases before and behind the minimizer}) and leaves both in LDS;
-        // the 64 buckets then come in with FOUR loads of 16 buckets each, the four lanes of a quad fetching the four 16-byte
-        // quarters of one bucket (one request per bucket to the memory pipeline instead of four: a lane fetching its whole bucket
-        // halves the chip's random-line rate, profiles/r01/membench_random_lines.txt), and every lane scans its quarter --
-        // two entries -- of four runs.  The next 64 buckets are in flight meanwhile.
-        // (a lane beyond the list repeats the list's last run -- its load stays inside the table -- with a tag no entry has)
+        // ---- phase B: 64 runs at a time.  A lane works out its own run's bucket address and what a scan needs of the run; the 64
+        // buckets then come in with FOUR loads of 16 buckets each, the four lanes of a quad fetching the four 16-byte quarters of
+        // the bucket of the run ONE of them prepared (one request per bucket to the memory pipeline instead of four: a lane fetching
+        // its whole bucket halves the chip's random-line rate, profiles/r01/membench_random_lines.txt), and every lane scans its
+        // quarter -- two entries -- of its quad's four runs; what it needs of a run it gets from the lane that prepared it by a
+        // quad broadcast (DPP), nothing goes through LDS.  Two more batches of 64 buckets are in flight meanwhile.
+        // (a lane beyond the list repeats the list's last run -- its load stays inside the table -- as a run no entry can belong to)
         uint32_t n_ovf = 0;
-        auto prepare = [&](uint32_t it, uint32_t buf) {
+        // what a scan needs of a run: {minimizer hash, first window | minimizer position - first << 8 | windows - 1 << 13 | read << 18 |
+        // the hash region's shift << 24, the 16 bases before the minimizer, the 16 bases behind it}
+        struct RunRegs { uint32_t h, pk, A, B; };
+        auto prepare = [&](uint32_t it, RunRegs &c) {
             const uint32_t idx = it * 64u + lane;
             const bool act = idx < nruns;
-            uint32_t rec = runs[act ? idx : nruns - 1u];
-            const uint32_t q = rec >> 24, ustar = rec & 0xFFu;
-            const uint32_t end = umin((rec >> 16) & 0xFFu, nwins[q]);
-            rec = (rec & 0xFF00FFFFu) | (end << 16);                                   // clipped to the read's windows
+            const uint32_t rec = runs[act ? idx : nruns - 1u];
+            const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu;
+            const uint32_t end = (rec >> 16) & 0xFFu;
             const uint32_t *sq = stream + q * STRIDE + 1 + (ustar >> 4);
             const uint32_t rr = ustar & 15u, sh = (32u - 2u * rr) & 31u;
             const uint32_t w_1 = sq[-1], w0 = sq[0], w1 = sq[1], w2 = sq[2];
             const uint32_t m = rr ? __builtin_amdgcn_alignbit(w0, w1, sh) : w0;        // the minimizer's 16 bases
-            const uint32_t A = rr ? __builtin_amdgcn_alignbit(w_1, w0, sh) : w_1;      // the 16 bases in front of it
-            const uint32_t B = rr ? __builtin_amdgcn_alignbit(w1, w2, sh) : w1;        // the 16 bases behind it
-            const uint32_t h = mix32(m);
-            const uint32_t sft = s_rshift[h >> 24];
-            const uint32_t hlow = act ? (h & ((1u << sft) - 1u)) : 0xFFFFFFFFu;        // no entry's tag equals that
-            ctxs[buf * 64u + lane] = make_uint4(hlow, rec, A, B);
-            adrs[buf * 64u + lane] = s_raddr[h >> 24] + ((uint64_t)(h >> sft) << 6);
+            c.A = rr ? __builtin_amdgcn_alignbit(w_1, w0, sh) : w_1;                   // the 16 bases in front of it
+            c.B = rr ? __builtin_amdgcn_alignbit(w1, w2, sh) : w1;                     // the 16 bases behind it
+            c.h = mix32(m);
+            // (beyond the list: position 31 with one window -- no entry's position field names a window of that run)
+            const uint32_t dl = act ? ((ustar - first) << 8) | ((end - 1u - first) << 13) : (31u << 8);
+            c.pk = first | dl | (q << 18) | ((uint32_t)s_rshift[c.h >> 24] << 24);
         };
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) u32x4 *gptr128;
-        auto issue = [&](uint32_t buf, u32x4 (&P)[4]) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) P[k] = *(gptr128)(adrs[buf * 64u + 16u * k + (lane >> 2)] + 16u * (lane & 3u));
+#define QUAD_BCAST(v, k) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (k) * 0x55, 0xF, 0xF, true))
+        auto issue = [&](const RunRegs &c, u32x4 (&P)[4]) {
+            const uint64_t a = s_raddr[c.h >> 24] + ((uint64_t)(c.h >> ((c.pk >> 24) & 15u)) << 6);      // 64-byte aligned
+            const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32), mine = 16u * (lane & 3u);
+            P[0] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 0) << 32) | (QUAD_BCAST(alo, 0) | mine));
+            P[1] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 1) << 32) | (QUAD_BCAST(alo, 1) | mine));
+            P[2] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 2) << 32) | (QUAD_BCAST(alo, 2) | mine));
+            P[3] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 3) << 32) | (QUAD_BCAST(alo, 3) | mine));
         };
         auto push = [&](uint32_t q, uint32_t rank) {
             const uint32_t i = atomicAdd(&cnt[q], 1u);
             if (i < HMAX) hits[i * 64u + q] = (uint16_t)rank;
         };
-        auto scan = [&](uint32_t buf, const u32x4 (&P)[4]) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                const uint4 c = ctxs[buf * 64u + 16u * k + (lane >> 2)];               // {hlow, rec, A, B} of the quad's run
-                const uint32_t first = (c.y >> 8) & 0xFFu;
-                const uint32_t d = (c.y & 0xFFu) - first, lenm1 = ((c.y >> 16) & 0xFFu) - 1u - first, q = c.y >> 24;
-                const uint64_t AB = ((uint64_t)c.z << 32) | c.w;
-                // an entry: rest | {flag2 0 hlow8 pos5 rank16}; the window that starts pos bases before the minimizer has the outer bases AB >> 2 pos
-                const uint32_t lo0 = P[k].x, hi0 = P[k].y, lo1 = P[k].z, hi1 = P[k].w;
-                const uint32_t pos0 = (hi0 >> 16) & 31u, pos1 = (hi1 >> 16) & 31u;
-                const bool hit0 = (hi0 >> 21) == c.x && (d - pos0) <= lenm1 && (uint32_t)(AB >> (2u * pos0)) == lo0 && (hi0 & 0xFFFFu) != 0xFFFFu;
-                const bool hit1 = (hi1 >> 21) == c.x && (d - pos1) <= lenm1 && (uint32_t)(AB >> (2u * pos1)) == lo1 && (hi1 & 0xFFFFu) != 0xFFFFu;
-                // The bucket continues in an overflow run (its last entry says so: the quad's fourth lane sees it): its windows are
-                // looked up there after the loop, one lane per WINDOW.  The run's record goes to the front of the run list --
-                // phase B has read that far: the slots of 64 more runs than it has scanned.
-                const uint64_t om = __ballot((lane & 3u) == 3u && c.x != 0xFFFFFFFFu && (hi1 >> 30) == 2u);
-                if (om) {
-                    if ((om >> lane) & 1ull) runs[n_ovf + lanes_below(om)] = c.y;
-                    n_ovf += (uint32_t)__popcll(om);
-                }
-                if (__ballot(hit0 || hit1)) {
-                    if (hit0) push(q, hi0 & 0xFFFFu);
-                    if (hit1) push(q, hi1 & 0xFFFFu);
-                }
+        // hits of a batch wait in two registers per lane (read << 16 | rank, the later one in `p0`) and go to the reads' lists once per
+        // batch
+        auto scan1 = [&](uint32_t ch, uint32_t cpk, uint32_t cA, uint32_t cB, const u32x4 &Pk, uint32_t &p0, uint32_t &p1, uint32_t &np) {
+            const uint32_t d = (cpk >> 8) & 31u, lenm1 = (cpk >> 13) & 31u, sft = (cpk >> 24) & 15u;
+            const uint32_t hlow = ch & ((1u << sft) - 1u);                              // hash bits the bucket does not imply
+            const uint32_t q16 = (cpk >> 2) & 0x3F0000u;                                // read << 16
+            const uint64_t AB = ((uint64_t)cA << 32) | cB;
+            // an entry: rest | {flag2 0 hlow8 pos5 rank16}; the window that starts pos bases before the minimizer has the outer bases AB >> 2 pos
+            const uint32_t lo0 = Pk.x, hi0 = Pk.y, lo1 = Pk.z, hi1 = Pk.w;
+            const uint32_t pos0 = (hi0 >> 16) & 31u, pos1 = (hi1 >> 16) & 31u;
+            const bool hit0 = (hi0 >> 21) == hlow && (d - pos0) <= lenm1 && (uint32_t)(AB >> (2u * pos0)) == lo0 && (hi0 & 0xFFFFu) != 0xFFFFu;
+            const bool hit1 = (hi1 >> 21) == hlow && (d - pos1) <= lenm1 && (uint32_t)(AB >> (2u * pos1)) == lo1 && (hi1 & 0xFFFFu) != 0xFFFFu;
+            // (a third hit of a lane in one batch sends the oldest waiting one to its list first: a fraction of a percent of the lanes)
+            if (__ballot(hit0 && np >= 2u)) { if (hit0 && np >= 2u) push(p1 >> 16, p1 & 0xFFFFu); }
+            p1 = hit0 ? p0 : p1; p0 = hit0 ? (q16 | (hi0 & 0xFFFFu)) : p0; np += hit0 ? 1u : 0u;
+            if (__ballot(hit1 && np >= 2u)) { if (hit1 && np >= 2u) push(p1 >> 16, p1 & 0xFFFFu); }
+            p1 = hit1 ? p0 : p1; p0 = hit1 ? (q16 | (hi1 & 0xFFFFu)) : p0; np += hit1 ? 1u : 0u;
+            // The bucket continues in an overflow run (its last entry says so: the quad's fourth lane sees it): its windows are
+            // looked up there after the loop, one lane per WINDOW.  The run's record goes to the front of the run list --
+            // phase B has read further than that: the slots of at least 64 more runs than it has scanned.
+            const uint64_t om = __ballot((lane & 3u) == 3u && d != 31u && (hi1 >> 30) == 2u);
+            if (om) {
+                const uint32_t first = cpk & 0xFFu, q = (cpk >> 18) & 63u;
+                if ((om >> lane) & 1ull) runs[n_ovf + lanes_below(om)] = (first + d) | (first << 8) | ((first + lenm1 + 1u) << 16) | (q << 24);
+                n_ovf += (uint32_t)__popcll(om);
+            }
+        };
+        auto scan = [&](const RunRegs &c, const u32x4 (&P)[4]) {
+            uint32_t p0 = 0, p1 = 0, np = 0;
+            scan1(QUAD_BCAST(c.h, 0), QUAD_BCAST(c.pk, 0), QUAD_BCAST(c.A, 0), QUAD_BCAST(c.B, 0), P[0], p0, p1, np);
+            scan1(QUAD_BCAST(c.h, 1), QUAD_BCAST(c.pk, 1), QUAD_BCAST(c.A, 1), QUAD_BCAST(c.B, 1), P[1], p0, p1, np);
+            scan1(QUAD_BCAST(c.h, 2), QUAD_BCAST(c.pk, 2), QUAD_BCAST(c.A, 2), QUAD_BCAST(c.B, 2), P[2], p0, p1, np);
+            scan1(QUAD_BCAST(c.h, 3), QUAD_BCAST(c.pk, 3), QUAD_BCAST(c.A, 3), QUAD_BCAST(c.B, 3), P[3], p0, p1, np);
+            if (__ballot(np != 0u)) {
+                if (np >= 1u) push(p0 >> 16, p0 & 0xFFFFu);
+                if (__ballot(np >= 2u)) { if (np >= 2u) push(p1 >> 16, p1 & 0xFFFFu); }
             }
         };
         if (nruns) {
             const uint32_t nit = (nruns + 63u) >> 6;
-            u32x4 P0[4], P1[4];
-            prepare(0u, 0u); wave_lds_fence(); issue(0u, P0);
-            for (uint32_t it = 0; it < nit; it += 2) {                        // no branch around a load: the waits then count them
-                prepare(it + 1, 1u); wave_lds_fence(); issue(1u, P1);
-                scan(0u, P0);
-                wave_lds_fence();
-                prepare(it + 2, 0u); wave_lds_fence(); issue(0u, P0);
-                scan(1u, P1);
-                wave_lds_fence();
+            RunRegs R0, R1, R2;
+            u32x4 P0[4], P1[4], P2[4];
+            prepare(0u, R0); issue(R0, P0);
+            prepare(1u, R1); issue(R1, P1);
+            for (uint32_t it = 0; it < nit; it += 3) {                        // no branch around a load: the waits then count them
+                prepare(it + 2, R2); issue(R2, P2);
+                scan(R0, P0);
+                prepare(it + 3, R0); issue(R0, P0);
+                if (it + 1 < nit) scan(R1, P1);
+                prepare(it + 4, R1); issue(R1, P1);
+                if (it + 2 < nit) scan(R2, P2);
             }
         }
+#undef QUAD_BCAST
         // ---- windows of the runs whose bucket overflows: exact search in the bucket's overflow run (wave_common.hpp: min_find), a lane per window ----
         for (uint32_t ib = 0; ib < n_ovf; ib += 64) {
             wave_lds_fence();
@@ -333,7 +351,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             uint32_t wn = 0;                                                       // windows of the lane's item
             if (i < n_ovf) {
                 const uint32_t rec = runs[i];
-                wn = umin((rec >> 16) & 0xFFu, nwins[rec >> 24]) - ((rec >> 8) & 0xFFu);
+                wn = ((rec >> 16) & 0xFFu) - ((rec >> 8) & 0xFFu);
             }
             uint32_t incl = wn;
 #pragma unroll
