@@ -1,0 +1,165 @@
+"""The lane-per-read pass (csrc/lanes_kernel.hip: 64 reads per wavefront, k = 32 / u16 labels / forward strand / reads up to 160
+bases) against the CPU oracle and against the wave-per-read kernels (UTREE_LANES=0) on the same inputs, with the cases that
+decide which reads it keeps: one bad base (handled in the kernel), several (left to the wave-per-read kernel), reads shorter
+than a window, the longest reads it holds, batches that are not a multiple of 64, buckets that overflow, reads with more hits
+than it keeps, and a database on which it gives up for good.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import orc
+from utree_amd import ctrfile
+from utree_amd.search import CtrDB, DeviceTree, classify_fasta_bytes
+import util
+from test_gpu_parity import fasta_bytes, random_reads, tree_for
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def oracle_text(o, data, tmp_path, threads=8):
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(data)
+    out = tmp_path / "o.txt"
+    code, nr, good, err = o.search_file(str(fa), str(out), threads=threads, rc=False)
+    assert code == 0
+    return out.read_bytes()
+
+
+class OwnDB:
+    """60 000 random 32-mers under a four-rank label tree, written with the package's own .ctr writer (every bin regular)."""
+    k = 32
+
+    def __init__(self, tmp_path, seed=3):
+        rng = np.random.default_rng(seed)
+        lo = np.unique(rng.integers(0, 1 << 63, 60_000, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 60_000, dtype=np.uint64))
+        self.hi, self.lo = np.zeros(len(lo), np.uint64), lo
+        labels = ["k__A;p__P%d;c__C%d;o__O%d" % (a, b, c) for a in range(3) for b in range(3) for c in range(4)]
+        labels += ["k__A;p__P%d;c__C%d" % (a, b) for a in range(3) for b in range(3)] + ["k__A;p__P%d" % a for a in range(3)]
+        ix = rng.integers(0, len(labels), len(lo)).astype(np.uint32)
+        self.ctr = str(tmp_path / "own.ctr")
+        ctrfile.write_ctr(self.ctr, 8, 2, self.hi, self.lo, ix, labels)
+
+    def words(self):
+        return self.hi, self.lo
+
+
+@pytest.mark.parametrize("name", ["own", "vote", "kat"])
+def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path, monkeypatch):
+    if name == "own":
+        d = OwnDB(tmp_path)
+        db = CtrDB.open(d.ctr)
+        tree = DeviceTree.upload(db, 0)
+        o = orc.OracleDB.load(d.ctr)
+    else:
+        d = util.load_db_fixture(name)
+        db, tree = tree_for(name)
+        o = orc.OracleDB.load(util.fixture_ctr(name))
+    if tree.info.irregular_bins or tree.info.generic_mode or d.k != 32:
+        pytest.skip("this fixture's table has irregular bins (COMPRESS' first-bin quirk): the wave-per-read kernels' exact-probe path")
+    rng = np.random.default_rng(77)
+    reads = random_reads(rng, d, 3001, 1, 160) + random_reads(rng, d, 500, 150, 150, hit_frac=0.9)
+    hi, lo = d.words()
+    some = [ctrfile.decode_kmer(int(hi[j]), int(lo[j]), d.k) for j in rng.integers(0, len(lo), 40)]
+    rnd = lambda n: "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
+    reads += [("short%d" % L, rnd(L)) for L in (1, 15, 16, 31)]                                   # no window at all
+    reads += [("k%d" % i, s) for i, s in enumerate(some[:10])]                                    # exactly one window
+    reads += [("full%d" % i, (s + rnd(128))[:160]) for i, s in enumerate(some[10:20])]           # the longest this pass holds
+    reads += [("tail%d" % i, (rnd(128) + s)[-160:]) for i, s in enumerate(some[20:30])]          # hit in the last window
+    reads += [("n_first", "N" + some[30] + rnd(60)), ("n_last", rnd(60) + some[31] + "N"), ("n_mid", some[32] + "N" + some[33]),
+              ("n_two", some[34] + "N" + rnd(5) + "n" + some[35]), ("n_many", "NNNN" + some[36] + "NN" + some[37]),
+              ("x_other", some[38] + "-" + some[39]), ("all_n", "N" * 100), ("lower", (some[0] + rnd(40) + some[1]).lower())]
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    data = fasta_bytes(reads)
+    monkeypatch.setenv("UTREE_LANES", "1")
+    got = classify_fasta_bytes(db, tree, data, rc=False)
+    assert tree.kernel_name() == "classify_lanes_k"
+    monkeypatch.setenv("UTREE_LANES", "0")
+    plain = classify_fasta_bytes(db, tree, data, rc=False)
+    assert "classify_short_k" in tree.kernel_name()
+    assert got == plain
+    assert got == oracle_text(o, data, tmp_path)
+
+
+def test_batch_sizes_around_the_grab_of_64(torch_cuda, tmp_path, monkeypatch):
+    d = OwnDB(tmp_path, seed=4)
+    db = CtrDB.open(d.ctr)
+    tree = DeviceTree.upload(db, 0)
+    o = orc.OracleDB.load(d.ctr)
+    rng = np.random.default_rng(5)
+    reads = random_reads(rng, d, 300, 32, 160, hit_frac=0.8)
+    monkeypatch.setenv("UTREE_LANES", "1")
+    for n in (1, 2, 63, 64, 65, 127, 129, 300):
+        data = fasta_bytes(reads[:n])
+        assert classify_fasta_bytes(db, tree, data, rc=False) == oracle_text(o, data, tmp_path), n
+        assert tree.kernel_name() == "classify_lanes_k"
+    tree.close()
+
+
+def genome_db(tmp_path, rng, n_contigs=12, contig=6000):
+    """Every 32-mer of a few random contigs, one label per contig (plus shared ancestors): reads cut from them hit in every window."""
+    contigs = ["".join("ACGT"[int(x)] for x in rng.integers(0, 4, contig)) for _ in range(n_contigs)]
+    kmers, labs = {}, []
+    for ci, s in enumerate(contigs):
+        labs.append("k__B;p__P%d;c__C%d;o__O%d" % (ci % 2, ci % 4, ci))
+        for i in range(len(s) - 31):
+            kmers.setdefault(s[i:i + 32], ci)
+    ks = sorted(kmers)
+    hi, lo = ctrfile.encode_kmers(ks)
+    ix = np.array([kmers[x] for x in ks], dtype=np.uint32)
+    order = np.lexsort((lo, hi))
+    ctr = str(tmp_path / "genome.ctr")
+    ctrfile.write_ctr(ctr, 8, 2, hi[order], lo[order], ix[order], labs)
+    return ctr, contigs
+
+
+def test_hit_dense_reads_are_left_to_the_wave_per_read_kernel_and_the_pass_turns_itself_off(torch_cuda, tmp_path, monkeypatch):
+    rng = np.random.default_rng(11)
+    ctr, contigs = genome_db(tmp_path, rng)
+    db = CtrDB.open(ctr)
+    tree = DeviceTree.upload(db, 0)
+    o = orc.OracleDB.load(ctr)
+    monkeypatch.setenv("UTREE_LANES", "1")
+
+    def cut(n):
+        out = []
+        for i in range(n):
+            a, b = contigs[int(rng.integers(0, len(contigs)))], contigs[int(rng.integers(0, len(contigs)))]
+            p, q = int(rng.integers(0, len(a) - 150)), int(rng.integers(0, len(b) - 150))
+            s = a[p:p + 150] if i % 3 else a[p:p + 75] + b[q:q + 75]                 # a third are chimeras: two labels, a vote
+            out.append(("g%d" % i, s))
+        return out
+    data = fasta_bytes(cut(4000) + [("sparse%d" % i, "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 150))) for i in range(500)])
+    got = classify_fasta_bytes(db, tree, data, rc=False)
+    assert tree.kernel_name() == "classify_lanes_k"
+    assert got == oracle_text(o, data, tmp_path)
+    big = fasta_bytes(cut(70_000))
+    for _ in range(6):                                                              # > 256 Ki reads, nearly all of them left over
+        classify_fasta_bytes(db, tree, big, rc=False)
+    assert "classify_short_k" in tree.kernel_name()                                 # the pass has given up on this database
+    assert classify_fasta_bytes(db, tree, data, rc=False) == got
+    tree.close()
+
+
+def test_synthetic_config2_shape_lanes_equals_wave_per_read(torch_cuda, monkeypatch):
+    """40 M-node synthetic database (the bench generator), 300 000 x 150 bp reads: records identical with the pass on and off."""
+    torch = torch_cuda
+    from utree_amd import synth
+    sdb = synth.make_db(torch.device("cuda:0"), 40_000_000, W=8)
+    reads = synth.make_reads(sdb, 300_001, 150, seed=synth.READ_SEED + 9)
+    monkeypatch.setenv("UTREE_LANES", "1")
+    a = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=False)
+    assert sdb.tree.kernel_name() == "classify_lanes_k"
+    monkeypatch.setenv("UTREE_LANES", "0")
+    b = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=False)
+    assert torch.equal(a, b)
+    assert int((a[:, 2] > 0).sum()) > 0.9 * 300_001
+    sdb.tree.close()

@@ -369,12 +369,12 @@ def test_overflowing_buckets(torch_cuda, tmp_path, run_max, monkeypatch):
     def mix32(x):
         x = np.uint32(x)
         with np.errstate(over="ignore"):
-            x ^= x >> np.uint32(16); x *= np.uint32(0x85EBCA6B); x ^= x >> np.uint32(13); x *= np.uint32(0xC2B2AE35); x ^= x >> np.uint32(16)
+            x *= np.uint32(0x9E3779B1); x ^= x >> np.uint32(15); x *= np.uint32(0x85EBCA6B)
         return int(x)
     rng = np.random.default_rng(5)
     cand = rng.integers(0, 1 << 32, 6_000_000, dtype=np.uint64).astype(np.uint32)
     with np.errstate(over="ignore"):
-        h = cand.copy(); h ^= h >> np.uint32(16); h *= np.uint32(0x85EBCA6B); h ^= h >> np.uint32(13); h *= np.uint32(0xC2B2AE35); h ^= h >> np.uint32(16)
+        h = cand.copy(); h *= np.uint32(0x9E3779B1); h ^= h >> np.uint32(15); h *= np.uint32(0x85EBCA6B)
     minis = [int(c) for c in cand[np.argsort(h)[:3]]]                 # three 16-mers with tiny hashes: minimizers wherever they occur
     assert all(mix32(m) < 5000 for m in minis)
     for W in (8, 16):

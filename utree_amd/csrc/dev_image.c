@@ -77,7 +77,7 @@ int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
 
 static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     memset(h, 0, sizeof *h);
-    h->magic = UTREE_IMG_MAGIC; h->version = 7;   /* 6: k = 32 / u16-label records keep the rest in their low word (scan_bucket82); 7: the MIN area keeps the overflow runs only */
+    h->magic = UTREE_IMG_MAGIC; h->version = 8;   /* 6: k = 32 / u16-label records keep the rest in their low word (scan_bucket82); 7: the MIN area keeps the overflow runs only; 8: four-instruction minimizer hash */
     h->W = ctr->info.W; h->I = ctr->info.I; h->k = ctr->info.k;
     h->fine_bits = F; h->rec_words = utree_rec_words(h->W, h->I);
     h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
@@ -125,6 +125,7 @@ static void bind_image(utree_dev *d) {
     d->kimg.W = d->hdr.W; d->kimg.I = d->hdr.I;
 }
 
+static void lanes_ring_init(utree_dev *d);
 static int device_ok(int device, int *n_cu) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return UTREE_E_HIP;
@@ -166,6 +167,7 @@ static int build_begin(builder *b, const utree_ctr *ctr, int device, int fine_bi
     if (!d) return UTREE_E_NOMEM;
     b->d = d; b->ctr = ctr; b->stream = stream;
     d->device = device; d->n_cu = n_cu;
+    lanes_ring_init(d);
     layout(ctr, (uint32_t)utree_pick_fine_bits(ctr, fine_bits), &d->hdr);
     if (d_image) {
         if (image_bytes < d->hdr.total_bytes) { rc = UTREE_E_ARG; goto fail; }
@@ -421,8 +423,9 @@ int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t byt
     utree_dev *d = (utree_dev *)calloc(1, sizeof *d);
     if (!d) return UTREE_E_NOMEM;
     d->device = device; d->n_cu = n_cu; d->image = d_image; d->owns = 0;
+    lanes_ring_init(d);
     HIPCHK(hipMemcpy(&d->hdr, d_image, sizeof d->hdr, hipMemcpyDeviceToHost));
-    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 7 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
+    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 8 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
     if (ctr && (ctr->info.W != d->hdr.W || ctr->info.I != d->hdr.I || ctr->info.n_nodes != d->hdr.n_nodes ||
                 ctr->info.n_labels != d->hdr.n_labels)) { rc = UTREE_E_ARG; goto fail; }
     d->image_bytes = d->hdr.total_bytes;
@@ -434,9 +437,18 @@ fail:
     return rc;
 }
 
+static void lanes_ring_init(utree_dev *d) {
+    void *p = NULL;
+    if (hipSetDevice(d->device) == hipSuccess && hipHostMalloc(&p, 64 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) {
+        memset(p, 0xFF, 64 * sizeof(unsigned long long));
+        d->lanes_ring = (volatile unsigned long long *)p;
+    }
+}
+
 void utree_dev_free(utree_dev *d) {
     if (!d) return;
     hipSetDevice(d->device);
+    if (d->lanes_ring) hipHostFree((void *)d->lanes_ring);
     for (int i = 0; i < d->n_events; ++i) hipEventDestroy(d->events[i]);
     if (d->search_ctx) utree_search_ctx_free(d->search_ctx);
     if (d->owns && d->image) hipFree(d->image);
@@ -470,10 +482,22 @@ static uint32_t mid_limit(void) {
 }
 
 /* UTREE_LANES=0 keeps every batch on the wave-per-read kernels (comparison runs) */
-static int lanes_enabled(void) {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("UTREE_LANES"); v = !(e && e[0] == '0'); }
-    return v;
+static int lanes_enabled(void) { const char *e = getenv("UTREE_LANES"); return !(e && e[0] == '0'); }
+
+/* What the lane-per-read pass left to the wave-per-read kernel in earlier batches, as far as the counts have arrived: with more
+ * than a quarter of at least 256 Ki reads left, the pass is a loss for this database (hit-dense reads: more hits per read than it
+ * keeps) and stays off for the handle's lifetime.  Callers on several threads share the handle: atomics only. */
+static void lanes_ring_collect(utree_dev *d) {
+    if (!d->lanes_ring || d->lanes_off) return;
+    for (unsigned i = 0; i < 64; ++i) {
+        unsigned long long v = d->lanes_ring[i];
+        if (v == ~0ull) continue;
+        if (!__atomic_compare_exchange_n((unsigned long long *)&d->lanes_ring[i], &v, ~0ull, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) continue;
+        __atomic_add_fetch(&d->lanes_left, v, __ATOMIC_RELAXED);
+        __atomic_add_fetch(&d->lanes_reads, (unsigned long long)d->lanes_ring_reads[i], __ATOMIC_RELAXED);
+    }
+    const unsigned long long n = __atomic_load_n(&d->lanes_reads, __ATOMIC_RELAXED), l = __atomic_load_n(&d->lanes_left, __ATOMIC_RELAXED);
+    if (n >= (1u << 18) && l * 4 > n) d->lanes_off = 1;
 }
 
 static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc,
@@ -547,12 +571,18 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     d->last_long = dominant == 2; d->last_mid = dominant == 1; d->last_rc = do_rc; d->last_short_cap = w.short_cap;
     if (w.mid_reads) KCHK(utk_route(d_len, n_reads, do_rc, &w, st));
     if (e0 && dominant == 0) HIPCHK(hipEventRecord(e0, st));
-    const int lanes = lanes_enabled() && !w.mid_reads && utk_lanes_ok(&d->kimg, max_len, do_rc);
+    lanes_ring_collect(d);
+    const int lanes = lanes_enabled() && !d->lanes_off && !w.mid_reads && utk_lanes_ok(&d->kimg, max_len, do_rc);
     d->last_lanes = lanes;
     if (lanes) {
-        /* one lane per read; the reads it leaves (bad bases, overflowing buckets, many hits) are listed for the wave-per-read kernel */
+        /* one lane per read; the reads it leaves (several bad bases, more hits than it keeps) are listed for the wave-per-read kernel */
         KCHK(utk_classify_lanes(&d->kimg, d_bases, d_off, d_len, n_reads, d_out, &w, d->n_cu, st));
-        KCHK(utk_classify_mid(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
+        if (d->lanes_ring) {
+            const unsigned slot = __atomic_fetch_add(&d->lanes_ring_next, 1u, __ATOMIC_RELAXED) & 63u;
+            d->lanes_ring[slot] = ~0ull; d->lanes_ring_reads[slot] = n_reads;
+            HIPCHK(hipMemcpyAsync((void *)&d->lanes_ring[slot], w.cursors + UTREE_CUR_MID, 8, hipMemcpyDeviceToHost, st));
+        }
+        KCHK(utk_classify_listed(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
     } else
         KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
     if (e0 && dominant == 0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }

@@ -21,6 +21,13 @@ struct utree_dev {
     /* rank-specific search: the reference's never-cleared hit array as later reads see it (rank.c) */
     void *rank_state;
     uint64_t rank_state_cap;
+    /* lane-per-read pass: reads it left to the wave-per-read kernel, read back without a wait (a ring of pinned words; ~0 =
+     * not arrived or consumed), summed here; a database whose reads mostly exceed what that pass keeps (hit-dense) turns it off */
+    volatile unsigned long long *lanes_ring;
+    uint32_t lanes_ring_reads[64];
+    unsigned lanes_ring_next;
+    unsigned long long lanes_reads, lanes_left;
+    int lanes_off;
     /* whole-file search: per-lane pinned / device buffers, kept between searches (search_dev.c) */
     void *search_ctx;
 };

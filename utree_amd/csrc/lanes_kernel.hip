@@ -60,6 +60,8 @@ constexpr uint32_t HMAX = UTREE_LANES_HMAX;           // hits per read this kern
 constexpr int32_t CUT_PENDING = -3, RANK_PENDING = -4;   // as in kernels.hip (vote_k finishes those results)
 
 __device__ __forceinline__ uint32_t low_bytes(uint32_t n) { return n >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n)) - 1u); }
+// (the lane mask of a condition as the compare leaves it: __ballot() takes an int and costs a select and a second compare)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
 
@@ -156,26 +158,32 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 #pragma unroll
                 for (uint32_t d = 0; d < NRAW; ++d) raw[d] = p[umin(d, nd - 1u)];
             }
+            // (Lm = the read's length for the byte masks: when the grab's reads all have the same length -- the usual case -- it is
+            // a scalar and the masks cost no vector instruction)
+            auto convert = [&](const uint32_t Lm) {
 #pragma unroll
-            for (uint32_t c = 0; c < NWORD / 2; ++c) {                    // 32 bases = 8 dwords = 2 stream words per step
-                uint32_t w[2] = {0u, 0u};
+                for (uint32_t c = 0; c < NWORD / 2; ++c) {                // 32 bases = 8 dwords = 2 stream words per step
+                    uint32_t w[2] = {0u, 0u};
 #pragma unroll
-                for (uint32_t g = 0; g < 8; ++g) {
-                    const uint32_t gi = c * 8 + g;
-                    const uint32_t fm = low_bytes(L > 4u * gi ? L - 4u * gi : 0u);                     // bytes of the read
-                    const uint32_t word = __builtin_amdgcn_alignbyte(raw[gi + 1], raw[gi], mf) & fm;    // source bytes 4gi .. 4gi+3
-                    const uint32_t g2 = (word >> 1) & 0x03030303u;
-                    const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, g2);                // 0 1 2 3 -> A C T G
-                    const uint32_t z = (word & 0xDFDFDFDFu) ^ letter;                                  // non-zero byte = not ACGTacgt
-                    const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
-                    bad |= nz & fm;                                                                    // one bad base per read is followed up: where it is
-                    { const uint32_t pc = (uint32_t)__builtin_popcount(nz & fm); nbad += pc; badg += pc * gi; }
-                    const uint32_t code = g2 ^ ((g2 >> 1) & 0x01010101u);                              // A=0 C=1 G=2 T=3
-                    const uint32_t packed = (code * 0x40100401u) >> 24;                                // c0<<6 | c1<<4 | c2<<2 | c3
-                    w[g >> 2] = (w[g >> 2] << 8) | packed;
+                    for (uint32_t g = 0; g < 8; ++g) {
+                        const uint32_t gi = c * 8 + g;
+                        const uint32_t fm = low_bytes(Lm > 4u * gi ? Lm - 4u * gi : 0u);                   // bytes of the read
+                        const uint32_t word = __builtin_amdgcn_alignbyte(raw[gi + 1], raw[gi], mf) & fm;    // source bytes 4gi .. 4gi+3
+                        const uint32_t g2 = (word >> 1) & 0x03030303u;
+                        const uint32_t letter = __builtin_amdgcn_perm(0u, 0x47544341u, g2);                // 0 1 2 3 -> A C T G
+                        const uint32_t z = (word & 0xDFDFDFDFu) ^ letter;                                  // non-zero byte = not ACGTacgt
+                        const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+                        bad |= nz & fm;                                                                    // one bad base per read is followed up: where it is
+                        { const uint32_t pc = (uint32_t)__builtin_popcount(nz & fm); nbad += pc; badg += pc * gi; }
+                        const uint32_t code = g2 ^ ((g2 >> 1) & 0x01010101u);                              // A=0 C=1 G=2 T=3
+                        const uint32_t packed = (code * 0x40100401u) >> 24;                                // c0<<6 | c1<<4 | c2<<2 | c3
+                        w[g >> 2] = (w[g >> 2] << 8) | packed;
+                    }
+                    sl[2 * c] = w[0]; sl[2 * c + 1] = w[1];
                 }
-                sl[2 * c] = w[0]; sl[2 * c + 1] = w[1];
-            }
+            };
+            const uint32_t L0 = uni32(L);
+            if (ballot64(L != L0) == 0ull) convert(L0); else convert(L);
             if (nbad > 1u) { exc = true; L = 0; }                          // two or more: left to the wave-per-read kernel
             badpos = nbad == 1u ? 4u * badg + ((uint32_t)__builtin_ctz(bad) >> 3) : 0xFFFF0000u;
         }
@@ -224,7 +232,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                     const uint32_t wv = ((badpos - s) > 31u && s < nwin) ? wmin : 0xFFFFFFFFu;
                     const bool changed = wv != prev;
                     const bool emit = changed && prev != 0xFFFFFFFFu;
-                    const uint64_t em = __ballot(emit);
+                    const uint64_t em = ballot64(emit);
                     if (em) {
                         const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, nruns));
                         // {read | one past the run's last window | first window | minimizer position}
@@ -303,14 +311,16 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             const bool hit0 = (hi0 >> 21) == hlow && (d - pos0) <= lenm1 && (uint32_t)(AB >> (2u * pos0)) == lo0 && (hi0 & 0xFFFFu) != 0xFFFFu;
             const bool hit1 = (hi1 >> 21) == hlow && (d - pos1) <= lenm1 && (uint32_t)(AB >> (2u * pos1)) == lo1 && (hi1 & 0xFFFFu) != 0xFFFFu;
             // (a third hit of a lane in one batch sends the oldest waiting one to its list first: a fraction of a percent of the lanes)
-            if (__ballot(hit0 && np >= 2u)) { if (hit0 && np >= 2u) push(p1 >> 16, p1 & 0xFFFFu); }
+            if (ballot64((hit0 || hit1) && np >= 1u)) {
+                if (hit0 && np >= 2u) push(p1 >> 16, p1 & 0xFFFFu);
+                if (hit1 && np + (hit0 ? 1u : 0u) >= 2u) { const uint32_t w = hit0 ? p0 : p1; push(w >> 16, w & 0xFFFFu); }
+            }
             p1 = hit0 ? p0 : p1; p0 = hit0 ? (q16 | (hi0 & 0xFFFFu)) : p0; np += hit0 ? 1u : 0u;
-            if (__ballot(hit1 && np >= 2u)) { if (hit1 && np >= 2u) push(p1 >> 16, p1 & 0xFFFFu); }
             p1 = hit1 ? p0 : p1; p0 = hit1 ? (q16 | (hi1 & 0xFFFFu)) : p0; np += hit1 ? 1u : 0u;
             // The bucket continues in an overflow run (its last entry says so: the quad's fourth lane sees it): its windows are
             // looked up there after the loop, one lane per WINDOW.  The run's record goes to the front of the run list --
             // phase B has read further than that: the slots of at least 64 more runs than it has scanned.
-            const uint64_t om = __ballot((lane & 3u) == 3u && d != 31u && (hi1 >> 30) == 2u);
+            const uint64_t om = ballot64((lane & 3u) == 3u && d != 31u && (hi1 >> 30) == 2u);
             if (om) {
                 const uint32_t first = cpk & 0xFFu, q = (cpk >> 18) & 63u;
                 if ((om >> lane) & 1ull) runs[n_ovf + lanes_below(om)] = (first + d) | (first << 8) | ((first + lenm1 + 1u) << 16) | (q << 24);
@@ -323,9 +333,9 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             scan1(QUAD_BCAST(c.h, 1), QUAD_BCAST(c.pk, 1), QUAD_BCAST(c.A, 1), QUAD_BCAST(c.B, 1), P[1], p0, p1, np);
             scan1(QUAD_BCAST(c.h, 2), QUAD_BCAST(c.pk, 2), QUAD_BCAST(c.A, 2), QUAD_BCAST(c.B, 2), P[2], p0, p1, np);
             scan1(QUAD_BCAST(c.h, 3), QUAD_BCAST(c.pk, 3), QUAD_BCAST(c.A, 3), QUAD_BCAST(c.B, 3), P[3], p0, p1, np);
-            if (__ballot(np != 0u)) {
+            if (ballot64(np != 0u)) {
                 if (np >= 1u) push(p0 >> 16, p0 & 0xFFFFu);
-                if (__ballot(np >= 2u)) { if (np >= 2u) push(p1 >> 16, p1 & 0xFFFFu); }
+                if (ballot64(np >= 2u)) { if (np >= 2u) push(p1 >> 16, p1 & 0xFFFFu); }
             }
         };
         if (nruns) {
@@ -394,7 +404,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // ---- phase C: tally (itree.c:1028-1040), result records, the list of reads left to the wave-per-read kernel ----
         uint32_t F = cnt[lane];
         if (((excw[lane >> 5] >> (lane & 31u)) & 1u) || F > HMAX || wave_full) exc = true;
-        const uint64_t xm = __ballot(have && exc);
+        const uint64_t xm = ballot64(have && exc);
         if (xm) {
             unsigned long long xb = 0;
             if (lane == 0) xb = atomicAdd(&ws.cursors[UTREE_CUR_MID], (unsigned long long)__popcll(xm));
@@ -423,7 +433,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         for (uint32_t j = 0; j < maxF; ++j) { const uint32_t h = j < F ? (uint32_t)hq[j * 64u] : INVALID; cur = umin(cur, h); }
         const uint32_t first_rank = cur;
         uint32_t nu = 0;
-        while (__ballot(cur != INVALID)) {                                    // one pass per distinct label, ascending = strcmp order (itree.c:1041)
+        while (ballot64(cur != INVALID)) {                                    // one pass per distinct label, ascending = strcmp order (itree.c:1041)
             uint32_t c = 0, nxt = INVALID;
             for (uint32_t j = 0; j < maxF; ++j) {
                 const uint32_t h = j < F ? (uint32_t)hq[j * 64u] : INVALID;
