@@ -12,7 +12,7 @@ scaling, no data-path collective); the only collective is the one-off RCCL broad
 from rank 0 before the timed region, issued from C (utree_dev_replicate_rank).  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      dominant kernel (classify_short_k): bytes the kernel must move per launch by the byte model of the image AS
+  roofline      dominant kernel (classify_lanes_k for 150-bp-class forward batches, else classify_short_k / classify_long_k): bytes the kernel must move per launch by the byte model of the image AS
                 BUILT (distinct 64-byte buckets per read, counted on the device) / average launch duration measured with
                 HIP events on the launch stream, against 8 TB/s; next to it the PMC-measured HBM fraction and the VALU / SALU
                 issue fractions from the kept profile (profiles/traffic.json) -- used only when that profile was taken from
@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: peak engine clock
 N_SIMD = 256 * 4               # 256 CUs x 4 SIMD16
+RANDOM_LINE_GBS = 48.6 * 128   # random 128-byte lines/s this chip serves (tools/membench.hip, profiles/r02/membench_random_lines.txt) x 128 B
 
 
 def contract_bytes_per_read(n_nodes: int, W: int, I: int, read_len: int):
@@ -317,8 +318,17 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
                 roof["highest_fraction"] = max(fr, key=fr.get)
                 if e.get("SQ_WAVE_CYCLES_per_launch") and e.get("SQ_WAIT_INST_ANY_per_launch"):
                     roof["wave_cycles_waiting_for_issue"] = e["SQ_WAIT_INST_ANY_per_launch"] / e["SQ_WAVE_CYCLES_per_launch"]
-                roof["limiter_note"] = ("no unit is saturated: the kernel is bound by each wavefront's chain of dependent steps (LDS round trips, two bucket "
-                                        "fetches, the tally) at the hardware's limit of 8 wavefronts per SIMD -- DESIGN.md section 5 has the experiments")
+                # what random 128-byte lines can be fetched at on this chip: 48.6 G lines/s = 6.2 TB/s (tools/membench.hip, one load or
+                # one quad of loads per line; profiles/r02/membench_random_lines.txt) -- the ceiling of a table lookup kernel, below the
+                # 8 TB/s of streaming reads `peak` stands for
+                roof["random_line_ceiling_GBs"] = RANDOM_LINE_GBS
+                roof["random_line_frac"] = e["hbm_bytes_per_launch"] / t_prof / 1e9 / RANDOM_LINE_GBS
+                if "classify_lanes_k" in kernel_sig:
+                    roof["limiter_note"] = ("lane-per-read pass: one 64-byte bucket fetch per minimizer run, each a random 128-byte HBM line; the measured "
+                                            "traffic runs at random_line_frac of the rate at which this chip serves random lines -- DESIGN.md section 5c")
+                else:
+                    roof["limiter_note"] = ("no unit is saturated: the kernel is bound by each wavefront's chain of dependent steps (LDS round trips, two bucket "
+                                            "fetches, the tally) at the hardware's limit of 8 wavefronts per SIMD -- DESIGN.md section 5 has the experiments")
     except Exception as ex:                                   # a broken profile file must not take the line down
         prof["why_not"] = repr(ex)
     roof["profile"] = prof

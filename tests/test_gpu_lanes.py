@@ -25,11 +25,11 @@ def torch_cuda():
     return torch
 
 
-def oracle_text(o, data, tmp_path, threads=8):
+def oracle_text(o, data, tmp_path, threads=8, rc=False):
     fa = tmp_path / "r.fa"
     fa.write_bytes(data)
     out = tmp_path / "o.txt"
-    code, nr, good, err = o.search_file(str(fa), str(out), threads=threads, rc=False)
+    code, nr, good, err = o.search_file(str(fa), str(out), threads=threads, rc=rc)
     assert code == 0
     return out.read_bytes()
 
@@ -79,14 +79,19 @@ def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path
               ("x_other", some[38] + "-" + some[39]), ("all_n", "N" * 100), ("lower", (some[0] + rnd(40) + some[1]).lower())]
     reads = [reads[i] for i in rng.permutation(len(reads))]
     data = fasta_bytes(reads)
-    monkeypatch.setenv("UTREE_LANES", "1")
-    got = classify_fasta_bytes(db, tree, data, rc=False)
-    assert tree.kernel_name() == "classify_lanes_k"
-    monkeypatch.setenv("UTREE_LANES", "0")
-    plain = classify_fasta_bytes(db, tree, data, rc=False)
-    assert "classify_short_k" in tree.kernel_name()
-    assert got == plain
-    assert got == oracle_text(o, data, tmp_path)
+    # reverse complements of database k-mers: hits on the second strand only
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    reads += [("rev%d" % i, rnd(int(rng.integers(0, 60))) + s.translate(comp)[::-1] + rnd(int(rng.integers(0, 60)))) for i, s in enumerate(some)]
+    data = fasta_bytes(reads)
+    for rc in (False, True):
+        monkeypatch.setenv("UTREE_LANES", "1")
+        got = classify_fasta_bytes(db, tree, data, rc=rc)
+        assert tree.kernel_name() == "classify_lanes_k"
+        monkeypatch.setenv("UTREE_LANES", "0")
+        plain = classify_fasta_bytes(db, tree, data, rc=rc)
+        assert "classify_short_k" in tree.kernel_name()
+        assert got == plain
+        assert got == oracle_text(o, data, tmp_path, rc=rc)
 
 
 def test_batch_sizes_around_the_grab_of_64(torch_cuda, tmp_path, monkeypatch):
@@ -155,11 +160,12 @@ def test_synthetic_config2_shape_lanes_equals_wave_per_read(torch_cuda, monkeypa
     from utree_amd import synth
     sdb = synth.make_db(torch.device("cuda:0"), 40_000_000, W=8)
     reads = synth.make_reads(sdb, 300_001, 150, seed=synth.READ_SEED + 9)
-    monkeypatch.setenv("UTREE_LANES", "1")
-    a = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=False)
-    assert sdb.tree.kernel_name() == "classify_lanes_k"
-    monkeypatch.setenv("UTREE_LANES", "0")
-    b = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=False)
-    assert torch.equal(a, b)
-    assert int((a[:, 2] > 0).sum()) > 0.9 * 300_001
+    for rc in (False, True):
+        monkeypatch.setenv("UTREE_LANES", "1")
+        a = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
+        assert sdb.tree.kernel_name() == "classify_lanes_k"
+        monkeypatch.setenv("UTREE_LANES", "0")
+        b = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
+        assert torch.equal(a, b)
+        assert int((a[:, 2] > 0).sum()) > 0.9 * 300_001
     sdb.tree.close()

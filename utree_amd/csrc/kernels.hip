@@ -1054,7 +1054,7 @@ int utk_classify_mid(const utk_image *im, const uint8_t *d_bases, const uint64_t
     });
 }
 
-// what the lane-per-read pass (lanes_kernel.hip) listed: reads of up to SHORT_CAP staged bases, forward strand
+// what the lane-per-read pass (lanes_kernel.hip) listed: reads of up to 160 bases
 int utk_classify_listed(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                         uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
@@ -1062,8 +1062,12 @@ int utk_classify_listed(const utk_image *im, const uint8_t *d_bases, const uint6
     uint32_t cap = (uint32_t)n_cu * 8u;
     if (blocks > cap) blocks = cap;
     return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
-        classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT_CAP, true, 0>
-            <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+        if (do_rc)        // both strands staged: up to 2 x 160 + 1 bases
+            classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT2_CAP, true>
+                <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+        else
+            classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT_CAP, true, 0>
+                <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
     });
 }
 

@@ -75,7 +75,7 @@ typedef const __attribute__((address_space(1))) uint32_t *gptr32;
 
 __global__ __launch_bounds__(LANES_WAVES * 64, UTREE_LANES_MIN_BLOCKS)
 void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
-                      uint32_t n_reads, utree_result *__restrict__ out, utk_workspace ws) {
+                      uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws) {
     __shared__ uint32_t s_stream[LANES_WAVES][64 * STRIDE];
     __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
     __shared__ uint16_t s_hits[LANES_WAVES][64 * HMAX];       // [hit][read]: a lane's walk over its own hits is conflict-free
@@ -194,6 +194,35 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         wave_lds_fence();
         LT(1);
 
+        bool wave_full = false;
+        // With RC the read's reverse complement is a second pass over the same slot (itree.c:891-898 appends it behind a separator
+        // that no window spans: two independent sequences, one list of hits).
+        for (int strand = 0; strand < (do_rc ? 2 : 1); ++strand) {
+        if (strand) {
+            // the slot's bases 0 .. 16 NWORD - 1 reversed and complemented word by word, then moved up by the 16 NWORD - L bases that
+            // now lead; the bad base moves with them
+            uint32_t rw[NWORD];
+#pragma unroll
+            for (uint32_t i = 0; i < NWORD; ++i) {
+                const uint32_t y = __builtin_bitreverse32(sl[NWORD - 1 - i]);                 // groups reversed, the two bits of a group swapped
+                rw[i] = ~(((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1));
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (uint32_t i = 0; i < NWORD; ++i) sl[i] = rw[i];
+            wave_lds_fence();
+            const uint32_t lead = 16u * NWORD - L, lw = lead >> 4, lb = 2u * (lead & 15u);
+#pragma unroll
+            for (uint32_t i = 0; i < NWORD; ++i) {
+                const uint32_t a = sl[i + lw], b = sl[i + lw + 1];                             // (past the slot for the read's last words: bases no window uses)
+                rw[i] = lb ? __builtin_amdgcn_alignbit(a, b, 32u - lb) : a;
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (uint32_t i = 0; i < NWORD; ++i) sl[i] = rw[i];
+            if (badpos < L) badpos = L - 1u - badpos;
+            wave_lds_fence();
+        }
         // ---- phase A: minimizer runs of all 64 reads, in step ----
         uint32_t nruns = 0;
         if (maxnwin) {
@@ -250,7 +279,6 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             }
             nruns = uni32(nruns);
         }
-        bool wave_full = false;
         if (nruns > RUNS_CAP) { wave_full = true; nruns = 0; }                         // every read of the grab goes on the list
         wave_lds_fence();
         LT(2);
@@ -399,6 +427,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             }
         }
         wave_lds_fence();
+        }   // strand
         LT(3);
 
         // ---- phase C: tally (itree.c:1028-1040), result records, the list of reads left to the wave-per-read kernel ----
@@ -463,18 +492,19 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 
 extern "C" {
 
-// The image and batch this kernel takes: k = 32, u16 labels, a regular table, forward strand only, no read beyond LCAP bases.
+// The image and batch this kernel takes: k = 32, u16 labels, a regular table, no read beyond LCAP bases (either strand mode).
 int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc) {
-    return im->W == 8 && im->I == 2 && !(im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC)) && !do_rc && max_len <= LCAP;
+    (void)do_rc;
+    return im->W == 8 && im->I == 2 && !(im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC)) && max_len <= LCAP;
 }
 
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
-                       utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+                       int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
     uint32_t blocks = (n_reads + 64u * LANES_WAVES - 1) / (64u * LANES_WAVES);
     const uint32_t cap = (uint32_t)n_cu * UTREE_LANES_MIN_BLOCKS;
     if (blocks > cap) blocks = cap;
-    classify_lanes_k<<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, d_out, *ws);
+    classify_lanes_k<<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
     return (int)hipGetLastError();
 }
 
