@@ -1058,8 +1058,10 @@ int utk_classify_mid(const utk_image *im, const uint8_t *d_bases, const uint64_t
 int utk_classify_listed(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                         uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
+    // the list is short (a database that makes it long turns the lane-per-read pass off, dev_image.c): a quarter of the resident
+    // grid finds that out sooner than a full one
     uint32_t blocks = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    uint32_t cap = (uint32_t)n_cu * 8u;
+    uint32_t cap = (uint32_t)n_cu * 2u;
     if (blocks > cap) blocks = cap;
     return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
         if (do_rc)        // both strands staged: up to 2 x 160 + 1 bases

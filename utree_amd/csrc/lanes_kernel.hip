@@ -31,8 +31,8 @@ using namespace utk;
 #ifndef UTREE_LANES_WAVES
 #define UTREE_LANES_WAVES 4
 #endif
-#ifndef UTREE_LANES_MIN_BLOCKS
-#define UTREE_LANES_MIN_BLOCKS 3
+#ifndef UTREE_LANES_WPS
+#define UTREE_LANES_WPS 3                             /* wavefronts per SIMD the kernel is compiled for (LDS allows 12 per CU) */
 #endif
 #ifndef UTREE_LANES_HMAX
 #define UTREE_LANES_HMAX 16
@@ -52,7 +52,10 @@ __device__ unsigned long long g_lphase[8];
 constexpr int LANES_WAVES = UTREE_LANES_WAVES;        // waves per workgroup
 constexpr uint32_t LCAP = UTREE_LANES_CAP;            // bases a lane's slot holds
 constexpr uint32_t NWORD = LCAP / 16;                 // stream words with data
-constexpr uint32_t STRIDE = NWORD + 3;                // front pad, data, two tail pads; odd: lane slots fall on different banks
+#ifndef UTREE_LANES_STRIDE
+#define UTREE_LANES_STRIDE (UTREE_LANES_CAP / 16 + 3)
+#endif
+constexpr uint32_t STRIDE = UTREE_LANES_STRIDE;       // front pad, data, two tail pads; odd: lane slots fall on different banks
 static_assert(LCAP % 32 == 0 && (STRIDE & 1) == 1, "slot geometry");
 static_assert(LCAP + 16 + 48 <= 256, "positions are 8-bit fields of a run record");
 constexpr uint32_t RUNS_CAP = 1024;                   // runs per 64 reads (mean 14 per 150 bp read: ~900)
@@ -73,7 +76,7 @@ __device__ __forceinline__ void store_result(utree_result *out, uint32_t label, 
 typedef const __attribute__((address_space(1))) uint32_t *gptr32;
 
 
-__global__ __launch_bounds__(LANES_WAVES * 64, UTREE_LANES_MIN_BLOCKS)
+__global__ __launch_bounds__(LANES_WAVES * 64, UTREE_LANES_WPS)
 void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
                       uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws) {
     __shared__ uint32_t s_stream[LANES_WAVES][64 * STRIDE];
@@ -502,7 +505,7 @@ int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64
                        int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
     uint32_t blocks = (n_reads + 64u * LANES_WAVES - 1) / (64u * LANES_WAVES);
-    const uint32_t cap = (uint32_t)n_cu * UTREE_LANES_MIN_BLOCKS;
+    const uint32_t cap = (uint32_t)n_cu * (4u * UTREE_LANES_WPS / LANES_WAVES);
     if (blocks > cap) blocks = cap;
     classify_lanes_k<<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
     return (int)hipGetLastError();
