@@ -1,5 +1,5 @@
 """The lane-per-read pass (csrc/lanes_kernel.hip: 64 reads per wavefront, k = 32 / u16 labels / forward strand / reads up to 160
-bases) against the CPU oracle and against the wave-per-read kernels (UTREE_LANES=0) on the same inputs, with the cases that
+bases) against the CPU oracle and against the wave-per-read kernels (UTREE_LANE_PASS=0) on the same inputs, with the cases that
 decide which reads it keeps: one bad base (handled in the kernel), several (left to the wave-per-read kernel), reads shorter
 than a window, the longest reads it holds, batches that are not a multiple of 64, buckets that overflow, reads with more hits
 than it keeps, and a database on which it gives up for good.
@@ -84,10 +84,10 @@ def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path
     reads += [("rev%d" % i, rnd(int(rng.integers(0, 60))) + s.translate(comp)[::-1] + rnd(int(rng.integers(0, 60)))) for i, s in enumerate(some)]
     data = fasta_bytes(reads)
     for rc in (False, True):
-        monkeypatch.setenv("UTREE_LANES", "1")
+        monkeypatch.setenv("UTREE_LANE_PASS", "1")
         got = classify_fasta_bytes(db, tree, data, rc=rc)
         assert tree.kernel_name() == "classify_lanes_k"
-        monkeypatch.setenv("UTREE_LANES", "0")
+        monkeypatch.setenv("UTREE_LANE_PASS", "0")
         plain = classify_fasta_bytes(db, tree, data, rc=rc)
         assert "classify_short_k" in tree.kernel_name()
         assert got == plain
@@ -101,7 +101,7 @@ def test_batch_sizes_around_the_grab_of_64(torch_cuda, tmp_path, monkeypatch):
     o = orc.OracleDB.load(d.ctr)
     rng = np.random.default_rng(5)
     reads = random_reads(rng, d, 300, 32, 160, hit_frac=0.8)
-    monkeypatch.setenv("UTREE_LANES", "1")
+    monkeypatch.setenv("UTREE_LANE_PASS", "1")
     for n in (1, 2, 63, 64, 65, 127, 129, 300):
         data = fasta_bytes(reads[:n])
         assert classify_fasta_bytes(db, tree, data, rc=False) == oracle_text(o, data, tmp_path), n
@@ -132,7 +132,7 @@ def test_hit_dense_reads_are_left_to_the_wave_per_read_kernel_and_the_pass_turns
     db = CtrDB.open(ctr)
     tree = DeviceTree.upload(db, 0)
     o = orc.OracleDB.load(ctr)
-    monkeypatch.setenv("UTREE_LANES", "1")
+    monkeypatch.setenv("UTREE_LANE_PASS", "1")
 
     def cut(n):
         out = []
@@ -161,10 +161,10 @@ def test_synthetic_config2_shape_lanes_equals_wave_per_read(torch_cuda, monkeypa
     sdb = synth.make_db(torch.device("cuda:0"), 40_000_000, W=8)
     reads = synth.make_reads(sdb, 300_001, 150, seed=synth.READ_SEED + 9)
     for rc in (False, True):
-        monkeypatch.setenv("UTREE_LANES", "1")
+        monkeypatch.setenv("UTREE_LANE_PASS", "1")
         a = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
         assert sdb.tree.kernel_name() == "classify_lanes_k"
-        monkeypatch.setenv("UTREE_LANES", "0")
+        monkeypatch.setenv("UTREE_LANE_PASS", "0")
         b = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
         assert torch.equal(a, b)
         assert int((a[:, 2] > 0).sum()) > 0.9 * 300_001

@@ -481,8 +481,8 @@ static uint32_t mid_limit(void) {
     return v;
 }
 
-/* UTREE_LANES=0 keeps every batch on the wave-per-read kernels (comparison runs) */
-static int lanes_enabled(void) { const char *e = getenv("UTREE_LANES"); return !(e && e[0] == '0'); }
+/* UTREE_LANE_PASS=0 keeps every batch on the wave-per-read kernels (comparison runs) */
+static int lanes_enabled(void) { const char *e = getenv("UTREE_LANE_PASS"); return !(e && e[0] == '0'); }
 
 /* What the lane-per-read pass left to the wave-per-read kernel in earlier batches, as far as the counts have arrived: with more
  * than a quarter of at least 256 Ki reads left, the pass is a loss for this database (hit-dense reads: more hits per read than it
