@@ -35,27 +35,32 @@ def oracle_text(o, data, tmp_path, threads=8, rc=False):
 
 
 class OwnDB:
-    """60 000 random 32-mers under a four-rank label tree, written with the package's own .ctr writer (every bin regular)."""
-    k = 32
+    """60 000 random k-mers under a four-rank label tree, written with the package's own .ctr writer (every bin regular)."""
 
-    def __init__(self, tmp_path, seed=3):
+    def __init__(self, tmp_path, seed=3, k=32):
+        self.k = k
         rng = np.random.default_rng(seed)
-        lo = np.unique(rng.integers(0, 1 << 63, 60_000, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 60_000, dtype=np.uint64))
-        self.hi, self.lo = np.zeros(len(lo), np.uint64), lo
+        lo = rng.integers(0, 1 << 63, 60_000, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 60_000, dtype=np.uint64)
+        hi = (rng.integers(0, 1 << 63, 60_000, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 60_000, dtype=np.uint64)) if k == 64 \
+            else np.zeros(60_000, np.uint64)
+        order = np.lexsort((lo, hi))
+        keep = np.ones(len(order), bool)
+        keep[1:] = (hi[order][1:] != hi[order][:-1]) | (lo[order][1:] != lo[order][:-1])
+        self.hi, self.lo = hi[order][keep], lo[order][keep]
         labels = ["k__A;p__P%d;c__C%d;o__O%d" % (a, b, c) for a in range(3) for b in range(3) for c in range(4)]
         labels += ["k__A;p__P%d;c__C%d" % (a, b) for a in range(3) for b in range(3)] + ["k__A;p__P%d" % a for a in range(3)]
-        ix = rng.integers(0, len(labels), len(lo)).astype(np.uint32)
-        self.ctr = str(tmp_path / "own.ctr")
-        ctrfile.write_ctr(self.ctr, 8, 2, self.hi, self.lo, ix, labels)
+        ix = rng.integers(0, len(labels), len(self.lo)).astype(np.uint32)
+        self.ctr = str(tmp_path / ("own%d.ctr" % k))
+        ctrfile.write_ctr(self.ctr, k // 4, 2, self.hi, self.lo, ix, labels)
 
     def words(self):
         return self.hi, self.lo
 
 
-@pytest.mark.parametrize("name", ["own", "vote", "kat"])
+@pytest.mark.parametrize("name", ["own", "own64", "vote", "kat"])
 def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path, monkeypatch):
-    if name == "own":
-        d = OwnDB(tmp_path)
+    if name.startswith("own"):
+        d = OwnDB(tmp_path, k=64 if name == "own64" else 32)
         db = CtrDB.open(d.ctr)
         tree = DeviceTree.upload(db, 0)
         o = orc.OracleDB.load(d.ctr)
@@ -63,25 +68,25 @@ def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path
         d = util.load_db_fixture(name)
         db, tree = tree_for(name)
         o = orc.OracleDB.load(util.fixture_ctr(name))
-    if tree.info.irregular_bins or tree.info.generic_mode or d.k != 32:
+    if tree.info.irregular_bins or tree.info.generic_mode:
         pytest.skip("this fixture's table has irregular bins (COMPRESS' first-bin quirk): the wave-per-read kernels' exact-probe path")
     rng = np.random.default_rng(77)
     reads = random_reads(rng, d, 3001, 1, 160) + random_reads(rng, d, 500, 150, 150, hit_frac=0.9)
     hi, lo = d.words()
     some = [ctrfile.decode_kmer(int(hi[j]), int(lo[j]), d.k) for j in rng.integers(0, len(lo), 40)]
     rnd = lambda n: "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
-    reads += [("short%d" % L, rnd(L)) for L in (1, 15, 16, 31)]                                   # no window at all
+    reads += [("short%d" % L, rnd(L)) for L in (1, 15, 16, 31, 63)]                                   # no window at all
     reads += [("k%d" % i, s) for i, s in enumerate(some[:10])]                                    # exactly one window
     reads += [("full%d" % i, (s + rnd(128))[:160]) for i, s in enumerate(some[10:20])]           # the longest this pass holds
     reads += [("tail%d" % i, (rnd(128) + s)[-160:]) for i, s in enumerate(some[20:30])]          # hit in the last window
-    reads += [("n_first", "N" + some[30] + rnd(60)), ("n_last", rnd(60) + some[31] + "N"), ("n_mid", some[32] + "N" + some[33]),
-              ("n_two", some[34] + "N" + rnd(5) + "n" + some[35]), ("n_many", "NNNN" + some[36] + "NN" + some[37]),
-              ("x_other", some[38] + "-" + some[39]), ("all_n", "N" * 100), ("lower", (some[0] + rnd(40) + some[1]).lower())]
+    reads += [("n_first", "N" + some[30] + rnd(50)), ("n_last", rnd(50) + some[31] + "N"), ("n_mid", (some[32] + "N" + some[33])[:160]),
+              ("n_two", (some[34] + "N" + rnd(5) + "n" + some[35])[:160]), ("n_many", ("NNNN" + some[36] + "NN" + some[37])[:160]),
+              ("x_other", (some[38] + "-" + some[39])[:160]), ("all_n", "N" * 100), ("lower", (some[0] + rnd(30) + some[1]).lower()[:160])]
     reads = [reads[i] for i in rng.permutation(len(reads))]
     data = fasta_bytes(reads)
     # reverse complements of database k-mers: hits on the second strand only
     comp = str.maketrans("ACGTacgt", "TGCAtgca")
-    reads += [("rev%d" % i, rnd(int(rng.integers(0, 60))) + s.translate(comp)[::-1] + rnd(int(rng.integers(0, 60)))) for i, s in enumerate(some)]
+    reads += [("rev%d" % i, (rnd(int(rng.integers(0, 48))) + s.translate(comp)[::-1] + rnd(int(rng.integers(0, 48))))[:160]) for i, s in enumerate(some)]
     data = fasta_bytes(reads)
     for rc in (False, True):
         monkeypatch.setenv("UTREE_LANE_PASS", "1")

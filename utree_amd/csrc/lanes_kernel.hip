@@ -34,6 +34,9 @@ using namespace utk;
 #ifndef UTREE_LANES_WPS
 #define UTREE_LANES_WPS 3                             /* wavefronts per SIMD the kernel is compiled for (LDS allows 12 per CU) */
 #endif
+#ifndef UTREE_LANES_WPS64
+#define UTREE_LANES_WPS64 2                           /* ... its k = 64 instantiation (49 keys of a window in registers) */
+#endif
 #ifndef UTREE_LANES_HMAX
 #define UTREE_LANES_HMAX 16
 #endif
@@ -52,13 +55,18 @@ __device__ unsigned long long g_lphase[8];
 constexpr int LANES_WAVES = UTREE_LANES_WAVES;        // waves per workgroup
 constexpr uint32_t LCAP = UTREE_LANES_CAP;            // bases a lane's slot holds
 constexpr uint32_t NWORD = LCAP / 16;                 // stream words with data
-#ifndef UTREE_LANES_STRIDE
-#define UTREE_LANES_STRIDE (UTREE_LANES_CAP / 16 + 3)
-#endif
-constexpr uint32_t STRIDE = UTREE_LANES_STRIDE;       // front pad, data, two tail pads; odd: lane slots fall on different banks
-static_assert(LCAP % 32 == 0 && (STRIDE & 1) == 1, "slot geometry");
+static_assert(LCAP % 32 == 0, "slot geometry");
 static_assert(LCAP + 16 + 48 <= 256, "positions are 8-bit fields of a run record");
-constexpr uint32_t RUNS_CAP = 1024;                   // runs per 64 reads (mean 14 per 150 bp read: ~900)
+// per k-mer length (W = 8: k = 32, W = 16: k = 64)
+template <int W> struct Geo {
+    static constexpr uint32_t K = 4 * W, NB = K - 15;                  // bases, and 16-mers, of a window
+    static constexpr uint32_t NA = W == 16 ? 3 : 1;                    // words of bases in front of / behind the minimizer a k-mer may reach
+    static constexpr uint32_t FRONT = NA;                              // pad words in front of a lane's slot
+    static constexpr uint32_t STRIDE = NWORD + FRONT + 2;              // ... and two behind; odd: lane slots fall on different banks
+    static constexpr uint32_t RUNS = W == 16 ? 512 : 1024;             // runs per 64 reads (150 bp: mean 14 per read for k = 32, 4 for k = 64)
+    static constexpr uint32_t DNONE = 63;                              // minimizer offset no run has (<= 48)
+    static_assert((STRIDE & 1) == 1, "slot geometry");
+};
 constexpr uint32_t HMAX = UTREE_LANES_HMAX;           // hits per read this kernel keeps
 constexpr int32_t CUT_PENDING = -3, RANK_PENDING = -4;   // as in kernels.hip (vote_k finishes those results)
 
@@ -76,15 +84,35 @@ __device__ __forceinline__ void store_result(utree_result *out, uint32_t label, 
 typedef const __attribute__((address_space(1))) uint32_t *gptr32;
 
 
-__global__ __launch_bounds__(LANES_WAVES * 64, UTREE_LANES_WPS)
+// k = 64: the 48 outer bases (96 bits, r0 the top word) of the window that starts `pos` bases (0..48) before its minimizer, from the
+// 48 bases in front of the minimizer (A[0] first) and the 48 behind it: (A:B) >> 2 pos, low 96 bits -- a word shift by two
+// selects, then one funnel shift per word
+__device__ __forceinline__ void rest96(const uint32_t (&A)[3], const uint32_t (&B)[3], uint32_t pos, uint32_t &r0, uint32_t &r1, uint32_t &r2) {
+    const uint32_t sh = 2u * pos, bs = sh & 31u;
+    const bool w1 = (sh & 32u) != 0u, w2 = (sh & 64u) != 0u;
+    const uint32_t v[6] = {A[0], A[1], A[2], B[0], B[1], B[2]};
+    uint32_t y[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) y[t] = w1 ? (t ? v[t - 1] : 0u) : v[t];
+    uint32_t x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = w2 ? y[i] : y[2 + i];
+    r0 = __builtin_amdgcn_alignbit(x[0], x[1], bs); r1 = __builtin_amdgcn_alignbit(x[1], x[2], bs); r2 = __builtin_amdgcn_alignbit(x[2], x[3], bs);
+}
+
+template <int W>
+__global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
 void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
                       uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws) {
+    using G = Geo<W>;
+    constexpr uint32_t K = G::K, NB = G::NB, NA = G::NA, STRIDE = G::STRIDE, FRONT = G::FRONT, RUNS_CAP = G::RUNS;
     __shared__ uint32_t s_stream[LANES_WAVES][64 * STRIDE];
     __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
     __shared__ uint16_t s_hits[LANES_WAVES][64 * HMAX];       // [hit][read]: a lane's walk over its own hits is conflict-free
     __shared__ uint32_t s_cnt[LANES_WAVES][64];
     __shared__ uint32_t s_exc[LANES_WAVES][2];
     __shared__ uint32_t s_pref[LANES_WAVES][64];
+    __shared__ uint64_t s_ost[LANES_WAVES][64];               // overflow descriptors of up to 64 runs
     __shared__ uint64_t s_raddr[256];
     __shared__ uint8_t s_rshift[256];
     for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) {            // region table in the window loop's form (kernels.hip: stage_regions)
@@ -101,8 +129,11 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     uint32_t *cnt = s_cnt[wv];
     uint32_t *excw = s_exc[wv];
     uint32_t *pref = s_pref[wv];
-    uint32_t *sl = stream + lane * STRIDE + 1;                            // the lane's slot, word 0
-    sl[-1] = 0; sl[NWORD] = 0; sl[NWORD + 1] = 0;                         // pads: zero for good
+    uint64_t *ost = s_ost[wv];
+    uint32_t *sl = stream + lane * STRIDE + FRONT;                        // the lane's slot, word 0
+#pragma unroll
+    for (uint32_t i = 1; i <= FRONT; ++i) sl[-(int)i] = 0;                // pads: zero for good
+    sl[NWORD] = 0; sl[NWORD + 1] = 0;
     __syncthreads();
 
     unsigned long long chunk_base = 0;
@@ -190,7 +221,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             if (nbad > 1u) { exc = true; L = 0; }                          // two or more: left to the wave-per-read kernel
             badpos = nbad == 1u ? 4u * badg + ((uint32_t)__builtin_ctz(bad) >> 3) : 0xFFFF0000u;
         }
-        const uint32_t nwin = L >= 32u ? L - 31u : 0u;
+        const uint32_t nwin = L >= K ? L - (K - 1u) : 0u;
         cnt[lane] = 0;
         if (lane < 2) excw[lane] = 0;
         const uint32_t maxnwin = uni32(wave_max_u32(nwin));
@@ -229,11 +260,11 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // ---- phase A: minimizer runs of all 64 reads, in step ----
         uint32_t nruns = 0;
         if (maxnwin) {
-            uint32_t A[17];
+            uint32_t A[NB];
             uint32_t m16 = sl[0];
             A[0] = mix32(m16) & ~0x1FFu;
 #pragma unroll
-            for (uint32_t p = 16; p < 32; ++p) {
+            for (uint32_t p = 16; p < K; ++p) {
                 m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
                 A[p - 15] = (mix32(m16) & ~0x1FFu) | (p - 15u);
             }
@@ -244,24 +275,24 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             const uint32_t lanec = lane << 24;
             for (uint32_t b = 0;; ++b) {
 #pragma unroll
-                for (int rr = 15; rr >= 0; --rr) A[rr] = umin(A[rr], A[rr + 1]);        // suffix minima of the block
+                for (int rr = (int)NB - 2; rr >= 0; --rr) A[rr] = umin(A[rr], A[rr + 1]);   // suffix minima of the block
                 uint32_t P = 0;
                 bool done = false;
 #pragma unroll
-                for (uint32_t rr = 0; rr < 17; ++rr) {
-                    const uint32_t s = 17u * b + rr;                                  // window (wave-uniform)
+                for (uint32_t rr = 0; rr < NB; ++rr) {
+                    const uint32_t s = NB * b + rr;                                   // window (wave-uniform)
                     uint32_t wmin;
                     if (rr == 0) wmin = A[0];
                     else {
-                        const uint32_t p = s + 31u;                                   // the window's last base
+                        const uint32_t p = s + (K - 1u);                              // the window's last base
                         m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
-                        const uint32_t k = (mix32(m16) & ~0x1FFu) | (s + 16u);
+                        const uint32_t k = (mix32(m16) & ~0x1FFu) | (s + (NB - 1u));
                         const uint32_t Sr = A[rr];
                         A[rr - 1] = k;                                                // next block's key
                         P = rr == 1 ? k : umin(P, k);                                 // prefix minimum of the next block
                         wmin = umin(Sr, P);
                     }
-                    const uint32_t wv = ((badpos - s) > 31u && s < nwin) ? wmin : 0xFFFFFFFFu;
+                    const uint32_t wv = ((badpos - s) > (K - 1u) && s < nwin) ? wmin : 0xFFFFFFFFu;
                     const bool changed = wv != prev;
                     const bool emit = changed && prev != 0xFFFFFFFFu;
                     const uint64_t em = ballot64(emit);
@@ -276,9 +307,9 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                     if ((rr % 6u) == 0u && s >= maxnwin) { done = true; break; }      // (every lane's windows from maxnwin on are none)
                 }
                 if (done) break;
-                const uint32_t p = 17u * b + 48u;
+                const uint32_t p = NB * (b + 1u) + (K - 1u);
                 m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
-                A[16] = (mix32(m16) & ~0x1FFu) | (17u * b + 33u);
+                A[NB - 1] = (mix32(m16) & ~0x1FFu) | (NB * (b + 1u) + (NB - 1u));
             }
             nruns = uni32(nruns);
         }
@@ -294,31 +325,42 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // quad broadcast (DPP), nothing goes through LDS.  Two more batches of 64 buckets are in flight meanwhile.
         // (a lane beyond the list repeats the list's last run -- its load stays inside the table -- as a run no entry can belong to)
         uint32_t n_ovf = 0;
-        // what a scan needs of a run: {minimizer hash, first window | minimizer position - first << 8 | windows - 1 << 13 | read << 18 |
-        // the hash region's shift << 24, the 16 bases before the minimizer, the 16 bases behind it}
-        struct RunRegs { uint32_t h, pk, A, B; };
+        // what a scan needs of a run: {minimizer hash, first window | minimizer position - first << 8 | windows - 1 << 14 | read << 20 |
+        // the hash region's shift << 26, the 16 (k = 64: 48) bases before the minimizer, the 16 (48) bases behind it}
+        struct RunRegs { uint32_t h, pk, A[NA], B[NA]; };
+        // a run's context from its record: the words around the minimizer come from the slot of the run's read
+        auto context = [&](uint32_t q, uint32_t ustar, uint32_t &m, uint32_t (&A)[NA], uint32_t (&B)[NA]) {
+            const uint32_t *sq = stream + q * STRIDE + FRONT + (ustar >> 4);
+            const uint32_t rr = ustar & 15u, sh = (32u - 2u * rr) & 31u;
+            uint32_t w[2 * NA + 2];
+#pragma unroll
+            for (uint32_t t = 0; t < 2 * NA + 2; ++t) w[t] = sq[(int)t - (int)NA];
+            // 16 bases from base ustar + 16 t: words w[NA + t], w[NA + t + 1]
+#pragma unroll
+            for (uint32_t i = 0; i < NA; ++i) {
+                A[i] = rr ? __builtin_amdgcn_alignbit(w[i], w[i + 1], sh) : w[i];                         // t = i - NA: in front of the minimizer
+                B[i] = rr ? __builtin_amdgcn_alignbit(w[NA + 1 + i], w[NA + 2 + i], sh) : w[NA + 1 + i];   // t = 1 + i: behind it
+            }
+            m = rr ? __builtin_amdgcn_alignbit(w[NA], w[NA + 1], sh) : w[NA];
+        };
         auto prepare = [&](uint32_t it, RunRegs &c) {
             const uint32_t idx = it * 64u + lane;
             const bool act = idx < nruns;
             const uint32_t rec = runs[act ? idx : nruns - 1u];
             const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu;
             const uint32_t end = (rec >> 16) & 0xFFu;
-            const uint32_t *sq = stream + q * STRIDE + 1 + (ustar >> 4);
-            const uint32_t rr = ustar & 15u, sh = (32u - 2u * rr) & 31u;
-            const uint32_t w_1 = sq[-1], w0 = sq[0], w1 = sq[1], w2 = sq[2];
-            const uint32_t m = rr ? __builtin_amdgcn_alignbit(w0, w1, sh) : w0;        // the minimizer's 16 bases
-            c.A = rr ? __builtin_amdgcn_alignbit(w_1, w0, sh) : w_1;                   // the 16 bases in front of it
-            c.B = rr ? __builtin_amdgcn_alignbit(w1, w2, sh) : w1;                     // the 16 bases behind it
+            uint32_t m;
+            context(q, ustar, m, c.A, c.B);
             c.h = mix32(m);
-            // (beyond the list: position 31 with one window -- no entry's position field names a window of that run)
-            const uint32_t dl = act ? ((ustar - first) << 8) | ((end - 1u - first) << 13) : (31u << 8);
-            c.pk = first | dl | (q << 18) | ((uint32_t)s_rshift[c.h >> 24] << 24);
+            // (beyond the list: an offset no run has -- no entry's position field names a window of that run)
+            const uint32_t dl = act ? ((ustar - first) << 8) | ((end - 1u - first) << 14) : (G::DNONE << 8);
+            c.pk = first | dl | (q << 20) | ((uint32_t)s_rshift[c.h >> 24] << 26);
         };
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) u32x4 *gptr128;
 #define QUAD_BCAST(v, k) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (k) * 0x55, 0xF, 0xF, true))
         auto issue = [&](const RunRegs &c, u32x4 (&P)[4]) {
-            const uint64_t a = s_raddr[c.h >> 24] + ((uint64_t)(c.h >> ((c.pk >> 24) & 15u)) << 6);      // 64-byte aligned
+            const uint64_t a = s_raddr[c.h >> 24] + ((uint64_t)(c.h >> ((c.pk >> 26) & 15u)) << 6);      // 64-byte aligned
             const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32), mine = 16u * (lane & 3u);
             P[0] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 0) << 32) | (QUAD_BCAST(alo, 0) | mine));
             P[1] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 1) << 32) | (QUAD_BCAST(alo, 1) | mine));
@@ -331,39 +373,56 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         };
         // hits of a batch wait in two registers per lane (read << 16 | rank, the later one in `p0`) and go to the reads' lists once per
         // batch
-        auto scan1 = [&](uint32_t ch, uint32_t cpk, uint32_t cA, uint32_t cB, const u32x4 &Pk, uint32_t &p0, uint32_t &p1, uint32_t &np) {
-            const uint32_t d = (cpk >> 8) & 31u, lenm1 = (cpk >> 13) & 31u, sft = (cpk >> 24) & 15u;
+        auto scan1 = [&](uint32_t ch, uint32_t cpk, const uint32_t (&cA)[NA], const uint32_t (&cB)[NA], const u32x4 &Pk, uint32_t &p0, uint32_t &p1, uint32_t &np) {
+            const uint32_t d = (cpk >> 8) & 63u, lenm1 = (cpk >> 14) & 63u, sft = (cpk >> 26) & 15u;
             const uint32_t hlow = ch & ((1u << sft) - 1u);                              // hash bits the bucket does not imply
-            const uint32_t q16 = (cpk >> 2) & 0x3F0000u;                                // read << 16
-            const uint64_t AB = ((uint64_t)cA << 32) | cB;
-            // an entry: rest | {flag2 0 hlow8 pos5 rank16}; the window that starts pos bases before the minimizer has the outer bases AB >> 2 pos
-            const uint32_t lo0 = Pk.x, hi0 = Pk.y, lo1 = Pk.z, hi1 = Pk.w;
-            const uint32_t pos0 = (hi0 >> 16) & 31u, pos1 = (hi1 >> 16) & 31u;
-            const bool hit0 = (hi0 >> 21) == hlow && (d - pos0) <= lenm1 && (uint32_t)(AB >> (2u * pos0)) == lo0 && (hi0 & 0xFFFFu) != 0xFFFFu;
-            const bool hit1 = (hi1 >> 21) == hlow && (d - pos1) <= lenm1 && (uint32_t)(AB >> (2u * pos1)) == lo1 && (hi1 & 0xFFFFu) != 0xFFFFu;
+            const uint32_t q16 = (cpk >> 4) & 0x3F0000u;                                // read << 16
+            bool hit0, hit1, more;
+            uint32_t rank0, rank1;
+            if constexpr (W == 8) {
+                // two entries, each rest | {flag2 0 hlow8 pos5 rank16}; the window that starts pos bases before the minimizer has the outer bases AB >> 2 pos
+                const uint64_t AB = ((uint64_t)cA[0] << 32) | cB[0];
+                const uint32_t lo0 = Pk.x, hi0 = Pk.y, lo1 = Pk.z, hi1 = Pk.w;
+                const uint32_t pos0 = (hi0 >> 16) & 31u, pos1 = (hi1 >> 16) & 31u;
+                hit0 = (hi0 >> 21) == hlow && (d - pos0) <= lenm1 && (uint32_t)(AB >> (2u * pos0)) == lo0 && (hi0 & 0xFFFFu) != 0xFFFFu;
+                hit1 = (hi1 >> 21) == hlow && (d - pos1) <= lenm1 && (uint32_t)(AB >> (2u * pos1)) == lo1 && (hi1 & 0xFFFFu) != 0xFFFFu;
+                rank0 = hi0 & 0xFFFFu; rank1 = hi1 & 0xFFFFu;
+                more = (hi1 >> 30) == 2u;
+            } else {
+                // one entry: {rest low 64}{flag2 | hlow8 pos6 rest-high 32 | rank16}
+                const uint32_t pos = (Pk.w >> 16) & 63u;
+                uint32_t r0, r1, r2;
+                rest96(cA, cB, pos, r0, r1, r2);
+                hit0 = (Pk.w >> 22) == hlow && (d - pos) <= lenm1 && r0 == __builtin_amdgcn_alignbit(Pk.w, Pk.z, 16u) && r1 == Pk.y && r2 == Pk.x &&
+                       (Pk.z & 0xFFFFu) != 0xFFFFu;
+                hit1 = false;
+                rank0 = Pk.z & 0xFFFFu; rank1 = 0;
+                more = (Pk.w >> 30) == 2u;
+            }
             // (a third hit of a lane in one batch sends the oldest waiting one to its list first: a fraction of a percent of the lanes)
             if (ballot64((hit0 || hit1) && np >= 1u)) {
                 if (hit0 && np >= 2u) push(p1 >> 16, p1 & 0xFFFFu);
                 if (hit1 && np + (hit0 ? 1u : 0u) >= 2u) { const uint32_t w = hit0 ? p0 : p1; push(w >> 16, w & 0xFFFFu); }
             }
-            p1 = hit0 ? p0 : p1; p0 = hit0 ? (q16 | (hi0 & 0xFFFFu)) : p0; np += hit0 ? 1u : 0u;
-            p1 = hit1 ? p0 : p1; p0 = hit1 ? (q16 | (hi1 & 0xFFFFu)) : p0; np += hit1 ? 1u : 0u;
+            p1 = hit0 ? p0 : p1; p0 = hit0 ? (q16 | rank0) : p0; np += hit0 ? 1u : 0u;
+            if constexpr (W == 8) { p1 = hit1 ? p0 : p1; p0 = hit1 ? (q16 | rank1) : p0; np += hit1 ? 1u : 0u; }
             // The bucket continues in an overflow run (its last entry says so: the quad's fourth lane sees it): its windows are
             // looked up there after the loop, one lane per WINDOW.  The run's record goes to the front of the run list --
             // phase B has read further than that: the slots of at least 64 more runs than it has scanned.
-            const uint64_t om = ballot64((lane & 3u) == 3u && d != 31u && (hi1 >> 30) == 2u);
+            const uint64_t om = ballot64((lane & 3u) == 3u && d != G::DNONE && more);
             if (om) {
-                const uint32_t first = cpk & 0xFFu, q = (cpk >> 18) & 63u;
+                const uint32_t first = cpk & 0xFFu, q = (cpk >> 20) & 63u;
                 if ((om >> lane) & 1ull) runs[n_ovf + lanes_below(om)] = (first + d) | (first << 8) | ((first + lenm1 + 1u) << 16) | (q << 24);
                 n_ovf += (uint32_t)__popcll(om);
             }
         };
         auto scan = [&](const RunRegs &c, const u32x4 (&P)[4]) {
             uint32_t p0 = 0, p1 = 0, np = 0;
-            scan1(QUAD_BCAST(c.h, 0), QUAD_BCAST(c.pk, 0), QUAD_BCAST(c.A, 0), QUAD_BCAST(c.B, 0), P[0], p0, p1, np);
-            scan1(QUAD_BCAST(c.h, 1), QUAD_BCAST(c.pk, 1), QUAD_BCAST(c.A, 1), QUAD_BCAST(c.B, 1), P[1], p0, p1, np);
-            scan1(QUAD_BCAST(c.h, 2), QUAD_BCAST(c.pk, 2), QUAD_BCAST(c.A, 2), QUAD_BCAST(c.B, 2), P[2], p0, p1, np);
-            scan1(QUAD_BCAST(c.h, 3), QUAD_BCAST(c.pk, 3), QUAD_BCAST(c.A, 3), QUAD_BCAST(c.B, 3), P[3], p0, p1, np);
+#define SCAN_K(k) { uint32_t bA[NA], bB[NA]; \
+                    _Pragma("unroll") for (uint32_t i = 0; i < NA; ++i) { bA[i] = QUAD_BCAST(c.A[i], k); bB[i] = QUAD_BCAST(c.B[i], k); } \
+                    scan1(QUAD_BCAST(c.h, k), QUAD_BCAST(c.pk, k), bA, bB, P[k], p0, p1, np); }
+            SCAN_K(0) SCAN_K(1) SCAN_K(2) SCAN_K(3)
+#undef SCAN_K
             if (ballot64(np != 0u)) {
                 if (np >= 1u) push(p0 >> 16, p0 & 0xFFFFu);
                 if (ballot64(np >= 2u)) { if (np >= 2u) push(p1 >> 16, p1 & 0xFFFFu); }
@@ -385,46 +444,99 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             }
         }
 #undef QUAD_BCAST
-        // ---- windows of the runs whose bucket overflows: exact search in the bucket's overflow run (wave_common.hpp: min_find), a lane per window ----
+        // ---- runs whose bucket overflows.  The bucket's last entry names the run of MIN records that holds the rest of its nodes.  A
+        // short run (the rule: up to OVF_SCAN records) is read whole, one lane per RECORD, and every record treated like a bucket entry
+        // -- which window of the run is it the record of? -- : two round trips (descriptor, records) however many windows the run
+        // has.  A longer one is searched per window, one lane per WINDOW, by bisection (wave_common.hpp: min_find) like the
+        // wave-per-read kernel does. ----
+        constexpr uint32_t OVF_SCAN = 512;
         for (uint32_t ib = 0; ib < n_ovf; ib += 64) {
             wave_lds_fence();
             const uint32_t i = ib + lane;
-            uint32_t wn = 0;                                                       // windows of the lane's item
+            uint32_t nrec = 0, wn = 0;                                             // records to scan / windows to search of the lane's item
             if (i < n_ovf) {
                 const uint32_t rec = runs[i];
-                wn = ((rec >> 16) & 0xFFu) - ((rec >> 8) & 0xFFu);
+                uint32_t m, A[NA], B[NA];
+                context(rec >> 24, rec & 0xFFu, m, A, B);
+                const uint32_t h = mix32(m);
+                const uint64_t baddr = s_raddr[h >> 24] + ((uint64_t)(h >> s_rshift[h >> 24]) << 6);
+                const uint64_t dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + 56);   // the key word of the bucket's last entry
+                const uint64_t n = (dsc >> 40) & 0x3FFFFFull;
+                ost[lane] = dsc;
+                if (n <= OVF_SCAN) nrec = (uint32_t)n; else wn = ((rec >> 16) & 0xFFu) - ((rec >> 8) & 0xFFu);
             }
-            uint32_t incl = wn;
+            // (t-th unit of work -> item: inclusive prefix sums in LDS, first item whose sum exceeds t)
+            auto spread = [&](uint32_t mine) -> uint32_t {
+                uint32_t incl = mine;
 #pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(incl, dd); if (lane >= (uint32_t)dd) incl += t; }
-            pref[lane] = incl;
-            const uint32_t total = uni32((uint32_t)__shfl(incl, 63));
-            wave_lds_fence();
-            for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+                for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(incl, dd); if (lane >= (uint32_t)dd) incl += t; }
+                wave_lds_fence();
+                pref[lane] = incl;
+                wave_lds_fence();
+                return uni32((uint32_t)__shfl(incl, 63));
+            };
+            auto item_of = [&](uint32_t t, uint32_t &within) -> uint32_t {
+                uint32_t lo = 0, hi = 63;
+#pragma unroll
+                for (int st = 0; st < 6; ++st) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= t) lo = mid + 1; else hi = mid; }
+                within = t - (lo ? pref[lo - 1] : 0u);
+                return lo;
+            };
+            const uint32_t total_rec = spread(nrec);
+            for (uint32_t t0 = 0; t0 < total_rec; t0 += 64) {
                 const uint32_t t = t0 + lane;
-                if (t < total) {
-                    uint32_t lo = 0, hi = 63;                                      // the item whose windows include the t-th: first with pref > t
-#pragma unroll
-                    for (int st = 0; st < 6; ++st) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= t) lo = mid + 1; else hi = mid; }
-                    const uint32_t rec = runs[ib + lo];
-                    const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu;
-                    const uint32_t wnd = first + (t - (lo ? pref[lo - 1] : 0u));   // the window
-                    const uint32_t pos = ustar - wnd;                              // its minimizer's position, 0..16
-                    const uint32_t *sq = stream + q * STRIDE + 1 + (ustar >> 4);
-                    const uint32_t rr = ustar & 15u, sh = (32u - 2u * rr) & 31u;
-                    const uint32_t w_1 = sq[-1], w0 = sq[0], w1 = sq[1], w2 = sq[2];
-                    const uint32_t m = rr ? __builtin_amdgcn_alignbit(w0, w1, sh) : w0;
-                    const uint32_t A = rr ? __builtin_amdgcn_alignbit(w_1, w0, sh) : w_1;
-                    const uint32_t B = rr ? __builtin_amdgcn_alignbit(w1, w2, sh) : w1;
-                    const uint32_t rest = (uint32_t)((((uint64_t)A << 32) | B) >> (2u * pos));
+                if (t < total_rec) {
+                    uint32_t j;
+                    const uint32_t it_ = item_of(t, j);
+                    const uint32_t rec = runs[ib + it_];
+                    const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu, lenm1 = ((rec >> 16) & 0xFFu) - 1u - first;
+                    const Entry<W, 2> e = load_entry<W, 2>(im.mrecs, (ost[it_] & M40) + j);
+                    uint32_t m, A[NA], B[NA];
+                    context(q, ustar, m, A, B);
                     const uint32_t h = mix32(m);
-                    const uint32_t sft = s_rshift[h >> 24];
-                    const uint64_t baddr = s_raddr[h >> 24] + ((uint64_t)(h >> sft) << 6);
-                    const uint32_t hlow = h & ((1u << sft) - 1u);
-                    const uint64_t dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + 56);   // the bucket's last entry
+                    const uint32_t hlow = h & ((1u << s_rshift[h >> 24]) - 1u);
+                    bool hit;
+                    uint32_t rank;
+                    if constexpr (W == 8) {
+                        const uint32_t lo = (uint32_t)e.w[0], hi = (uint32_t)(e.w[0] >> 32), pos = (hi >> 16) & 31u;
+                        hit = (hi >> 21) == hlow && (ustar - first - pos) <= lenm1 && (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos)) == lo;
+                        rank = hi & 0xFFFFu;
+                    } else {
+                        const uint32_t z = (uint32_t)e.w[1], wq = (uint32_t)(e.w[1] >> 32), pos = (wq >> 16) & 63u;
+                        uint32_t r0, r1, r2;
+                        rest96(A, B, pos, r0, r1, r2);
+                        hit = (wq >> 22) == hlow && (ustar - first - pos) <= lenm1 && r0 == __builtin_amdgcn_alignbit(wq, z, 16u) &&
+                              r1 == (uint32_t)(e.w[0] >> 32) && r2 == (uint32_t)e.w[0];
+                        rank = z & 0xFFFFu;
+                    }
+                    if (hit && rank != 0xFFFFu) push(q, rank);
+                }
+            }
+            const uint32_t total_win = spread(wn);
+            for (uint32_t t0 = 0; t0 < total_win; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                if (t < total_win) {
+                    uint32_t j;
+                    const uint32_t it_ = item_of(t, j);
+                    const uint32_t rec = runs[ib + it_];
+                    const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu;
+                    const uint32_t pos = ustar - (first + j);                      // the window's minimizer position, 0..K-16
+                    uint32_t m, A[NA], B[NA];
+                    context(q, ustar, m, A, B);
+                    const uint32_t h = mix32(m);
+                    const uint32_t hlow = h & ((1u << s_rshift[h >> 24]) - 1u);
+                    const uint64_t dsc = ost[it_];
                     const uint64_t start = dsc & M40, n = (dsc >> 40) & 0x3FFFFFull;
-                    MinKey<8> mk; mk.hi = 0; mk.lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
-                    const uint32_t rank = min_find<8, 2>(im.mrecs, start, start + n, mk);
+                    MinKey<W> mk;
+                    if constexpr (W == 8) {
+                        const uint32_t rest = (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos));
+                        mk.hi = 0; mk.lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
+                    } else {
+                        uint32_t r0, r1, r2;
+                        rest96(A, B, pos, r0, r1, r2);
+                        mk.lo = ((uint64_t)r1 << 32) | r2; mk.hi = ((uint64_t)hlow << 38) | ((uint64_t)pos << 32) | r0;
+                    }
+                    const uint32_t rank = min_find<W, 2>(im.mrecs, start, start + n, mk);
                     if (rank != INVALID) push(q, rank);
                 }
             }
@@ -495,19 +607,23 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 
 extern "C" {
 
-// The image and batch this kernel takes: k = 32, u16 labels, a regular table, no read beyond LCAP bases (either strand mode).
+// The image and batch this kernel takes: k = 32 or 64, u16 labels, a regular table, no read beyond LCAP bases (either strand mode).
 int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc) {
     (void)do_rc;
-    return im->W == 8 && im->I == 2 && !(im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC)) && max_len <= LCAP;
+    return (im->W == 8 || im->W == 16) && im->I == 2 && !(im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC)) && max_len <= LCAP;
 }
 
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                        int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
     uint32_t blocks = (n_reads + 64u * LANES_WAVES - 1) / (64u * LANES_WAVES);
-    const uint32_t cap = (uint32_t)n_cu * (4u * UTREE_LANES_WPS / LANES_WAVES);
+    const uint32_t wps = im->W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS;
+    const uint32_t cap = (uint32_t)n_cu * (4u * wps / LANES_WAVES > 0 ? 4u * wps / LANES_WAVES : 1u);
     if (blocks > cap) blocks = cap;
-    classify_lanes_k<<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+    if (im->W == 16)
+        classify_lanes_k<16><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+    else
+        classify_lanes_k<8><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
     return (int)hipGetLastError();
 }
 
