@@ -35,7 +35,7 @@ using namespace utk;
 #define UTREE_LANES_WPS 3                             /* wavefronts per SIMD the kernel is compiled for (LDS allows 12 per CU) */
 #endif
 #ifndef UTREE_LANES_WPS64
-#define UTREE_LANES_WPS64 2                           /* ... its k = 64 instantiation (49 keys of a window in registers) */
+#define UTREE_LANES_WPS64 3                           /* ... its k = 64 instantiation (same-box: 2 per SIMD 1.66 ms, 3 per SIMD 1.41 ms per 4 M reads) */
 #endif
 #ifndef UTREE_LANES_HMAX
 #define UTREE_LANES_HMAX 16
