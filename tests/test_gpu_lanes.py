@@ -91,7 +91,7 @@ def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path
     for rc in (False, True):
         monkeypatch.setenv("UTREE_LANE_PASS", "1")
         got = classify_fasta_bytes(db, tree, data, rc=rc)
-        assert tree.kernel_name() == "classify_lanes_k"
+        assert tree.kernel_name().startswith("classify_lanes_k<")
         monkeypatch.setenv("UTREE_LANE_PASS", "0")
         plain = classify_fasta_bytes(db, tree, data, rc=rc)
         assert "classify_short_k" in tree.kernel_name()
@@ -110,7 +110,7 @@ def test_batch_sizes_around_the_grab_of_64(torch_cuda, tmp_path, monkeypatch):
     for n in (1, 2, 63, 64, 65, 127, 129, 300):
         data = fasta_bytes(reads[:n])
         assert classify_fasta_bytes(db, tree, data, rc=False) == oracle_text(o, data, tmp_path), n
-        assert tree.kernel_name() == "classify_lanes_k"
+        assert tree.kernel_name().startswith("classify_lanes_k<")
     tree.close()
 
 
@@ -149,7 +149,7 @@ def test_hit_dense_reads_are_left_to_the_wave_per_read_kernel_and_the_pass_turns
         return out
     data = fasta_bytes(cut(4000) + [("sparse%d" % i, "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 150))) for i in range(500)])
     got = classify_fasta_bytes(db, tree, data, rc=False)
-    assert tree.kernel_name() == "classify_lanes_k"
+    assert tree.kernel_name().startswith("classify_lanes_k<")
     assert got == oracle_text(o, data, tmp_path)
     big = fasta_bytes(cut(70_000))
     for _ in range(6):                                                              # > 256 Ki reads, nearly all of them left over
@@ -168,7 +168,7 @@ def test_synthetic_config2_shape_lanes_equals_wave_per_read(torch_cuda, monkeypa
     for rc in (False, True):
         monkeypatch.setenv("UTREE_LANE_PASS", "1")
         a = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
-        assert sdb.tree.kernel_name() == "classify_lanes_k"
+        assert sdb.tree.kernel_name().startswith("classify_lanes_k<")
         monkeypatch.setenv("UTREE_LANE_PASS", "0")
         b = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
         assert torch.equal(a, b)

@@ -620,7 +620,7 @@ fail:
 const char *utree_classify_kernel_name(const utree_dev *dc) {
     if (!dc) return "";
     utree_dev *d = (utree_dev *)dc;                       /* the signature string lives in the handle */
-    if (d->last_lanes && !d->last_long && !d->last_mid) return "classify_lanes_k";
+    if (d->last_lanes && !d->last_long && !d->last_mid) return d->hdr.W == 16 ? "classify_lanes_k<16>" : "classify_lanes_k<8>";
     return d->last_long ? utk_classify_long_name(&d->kimg, d->kernel_sig, sizeof d->kernel_sig)
                         : utk_classify_short_name(&d->kimg, d->last_short_cap ? d->last_short_cap : UTREE_SHORT_CAP, d->last_mid, d->last_rc,
                                                   d->kernel_sig, sizeof d->kernel_sig);
