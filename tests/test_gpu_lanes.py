@@ -99,6 +99,24 @@ def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path
         assert got == oracle_text(o, data, tmp_path, rc=rc)
 
 
+@pytest.mark.parametrize("name", ["vote", "kat"])
+def test_reference_golden_lines_through_the_lane_pass(torch_cuda, name, monkeypatch):
+    """The genuine reference's committed output (tests/golden) for the fixture reads this pass takes (up to 160 bases), on the two
+    fixture databases whose bin tables are regular (the others carry COMPRESS' first-bin quirk and stay on the wave-per-read kernels)."""
+    db, tree = tree_for(name)
+    assert not tree.info.irregular_bins and not tree.info.generic_mode
+    lines = util.fixture_bytes(name + "_reads.fa.gz").split(b"\n")
+    recs = [(lines[i], lines[i + 1]) for i in range(0, len(lines) - 1, 2)]
+    keep = [(h, q) for h, q in recs if len(q.rstrip(b"\r")) <= 160]
+    assert len(keep) > 900
+    names = {h[1:].split(b" ")[0] for h, q in keep}
+    want = b"".join(l + b"\n" for l in util.fixture_bytes(name + "_out.txt.gz").split(b"\n") if l and l.split(b"\t")[0] in names)
+    monkeypatch.setenv("UTREE_LANE_PASS", "1")
+    got = classify_fasta_bytes(db, tree, b"".join(h + b"\n" + q + b"\n" for h, q in keep), rc=False)
+    assert tree.kernel_name().startswith("classify_lanes_k<")
+    assert got == want and len(want) > 0
+
+
 def test_batch_sizes_around_the_grab_of_64(torch_cuda, tmp_path, monkeypatch):
     d = OwnDB(tmp_path, seed=4)
     db = CtrDB.open(d.ctr)

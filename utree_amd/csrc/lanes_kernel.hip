@@ -1,4 +1,4 @@
-// lanes_kernel.hip -- classify_lanes_k: the 150-bp-class pass of the SEARCH_GG path with ONE LANE PER READ (gfx950 / wave64).
+// lanes_kernel.hip -- classify_lanes_k<W>: the 150-bp-class pass of the SEARCH_GG path with ONE LANE PER READ (gfx950 / wave64).
 //
 // classify_short_k (kernels.hip) gives a read to a wavefront: every step of the read's chain -- bytes, 2-bit stream, hashes,
 // sliding minimum, bucket, scan, tally -- is a round trip of that one wave through LDS or memory, and 8 waves per SIMD is all the
@@ -6,19 +6,22 @@
 //
 //   phase 0  lane = read   the read's bytes -> 2-bit codes, packed big-endian, in the lane's LDS slot (itree.c:110-121)
 //   phase A  lane = read   all lanes walk their read base by base IN STEP (position is wave-uniform): rolling 16-mer, hash,
-//                          sliding minimum over the 17 16-mers of a window in REGISTERS (van Herk / Gil-Werman: one suffix
-//                          minimum per block of 17, one prefix minimum, one combine per window), and every maximal run of
-//                          windows that share their minimizer is appended to ONE list for the wave (ballot + mbcnt)
-//   phase B  lane = run    64 runs at a time: minimizer -> bucket (one 64-byte fetch per RUN, the next 64 already in flight);
-//                          every ENTRY of the bucket names the one window it could be the record of (minimizer position minus
-//                          the entry's position field): in the run? same outer 16 bases? -> a hit for the run's read
+//                          sliding minimum over the K-15 16-mers of a window in REGISTERS (van Herk / Gil-Werman: one suffix
+//                          minimum per block of K-15 keys, one prefix minimum, one combine per window), and every maximal run
+//                          of windows that share their minimizer is appended to ONE list for the wave (ballot + mbcnt)
+//   phase B  lane = run    64 runs at a time: minimizer -> bucket (one 64-byte fetch per RUN, a quad of lanes per bucket, two
+//                          more batches in flight); every ENTRY of the bucket names the one window it could be the record of
+//                          (minimizer position minus the entry's position field): in the run? same outer bases? -> a hit for
+//                          the run's read.  Buckets that continue in an overflow run: short runs are read whole, a lane per
+//                          record, longer ones searched per window
 //   phase C  lane = read   tally of the read's hits (itree.c:1028-1040): distinct labels ascending with counts, result record
 //
-// The hits a read gets are the same (window, record) pairs classify_short_k finds: it asks, per window, which entry of the
-// minimizer's bucket carries the window's key {hash bits, position, outer bases}; this kernel asks, per entry, which window of
-// the run has that key.  Reads this kernel does not take -- a base other than ACGTacgt, a bucket that continues in an overflow
-// run, more than LANES_HMAX hits, a wave whose run list is full -- go on the batch's list for the wave-per-read kernel
-// (utk_classify_mid), which also remains the kernel for k = 64, u32 labels, both strands, irregular tables and longer reads.
+// With RC the read's reverse complement takes phases A and B a second time in the same slot.  The hits a read gets are the same
+// (window, record) pairs classify_short_k finds: it asks, per window, which entry of the minimizer's bucket carries the window's
+// key {hash bits, position, outer bases}; this kernel asks, per entry, which window of the run has that key.  Reads this kernel
+// does not finish -- two or more bases other than ACGTacgt, more than LANES_HMAX hits, a wave whose run list is full -- go on the
+// batch's list for the wave-per-read kernel (utk_classify_listed), which also remains the kernel for u32 labels, irregular tables,
+// longer reads and databases whose reads hit in most windows (DESIGN.md sections 5c, 11).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -110,7 +113,6 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
     __shared__ uint16_t s_hits[LANES_WAVES][64 * HMAX];       // [hit][read]: a lane's walk over its own hits is conflict-free
     __shared__ uint32_t s_cnt[LANES_WAVES][64];
-    __shared__ uint32_t s_exc[LANES_WAVES][2];
     __shared__ uint32_t s_pref[LANES_WAVES][64];
     __shared__ uint64_t s_ost[LANES_WAVES][64];               // overflow descriptors of up to 64 runs
     __shared__ uint64_t s_raddr[256];
@@ -127,7 +129,6 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     uint32_t *runs = s_runs[wv];
     uint16_t *hits = s_hits[wv];
     uint32_t *cnt = s_cnt[wv];
-    uint32_t *excw = s_exc[wv];
     uint32_t *pref = s_pref[wv];
     uint64_t *ost = s_ost[wv];
     uint32_t *sl = stream + lane * STRIDE + FRONT;                        // the lane's slot, word 0
@@ -223,7 +224,6 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         }
         const uint32_t nwin = L >= K ? L - (K - 1u) : 0u;
         cnt[lane] = 0;
-        if (lane < 2) excw[lane] = 0;
         const uint32_t maxnwin = uni32(wave_max_u32(nwin));
         wave_lds_fence();
         LT(1);
@@ -547,7 +547,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 
         // ---- phase C: tally (itree.c:1028-1040), result records, the list of reads left to the wave-per-read kernel ----
         uint32_t F = cnt[lane];
-        if (((excw[lane >> 5] >> (lane & 31u)) & 1u) || F > HMAX || wave_full) exc = true;
+        if (F > HMAX || wave_full) exc = true;
         const uint64_t xm = ballot64(have && exc);
         if (xm) {
             unsigned long long xb = 0;
