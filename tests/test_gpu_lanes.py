@@ -117,6 +117,38 @@ def test_reference_golden_lines_through_the_lane_pass(torch_cuda, name, monkeypa
     assert got == want and len(want) > 0
 
 
+@pytest.mark.parametrize("k,max_len", [(32, 161), (32, 250), (32, 289), (32, 290), (32, 301), (32, 547), (64, 257), (64, 258), (64, 451)])
+def test_longer_reads_take_two_or_four_lanes(torch_cuda, k, max_len, tmp_path, monkeypatch):
+    """A lane holds 160 bases = 129 windows (k = 64: 97); longer reads are cut into such pieces, one lane each, up to four."""
+    d = OwnDB(tmp_path, seed=8, k=k)
+    db = CtrDB.open(d.ctr)
+    tree = DeviceTree.upload(db, 0)
+    o = orc.OracleDB.load(d.ctr)
+    rng = np.random.default_rng(max_len)
+    reads = random_reads(rng, d, 1200, 1, max_len, hit_frac=0.7) + random_reads(rng, d, 300, max_len, max_len, hit_frac=0.9)
+    hi, lo = d.words()
+    some = [ctrfile.decode_kmer(int(hi[j]), int(lo[j]), d.k) for j in rng.integers(0, len(lo), 60)]
+    rnd = lambda n: "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
+    # a database k-mer across every piece boundary (window 128 / 129 of k = 32, 96 / 97 of k = 64, and their multiples), one at the very end
+    sw = 160 - k + 1
+    for i, s in enumerate(some):
+        at = (1 + i % 3) * sw - (i % 7)
+        r = (rnd(max(0, at)) + s + rnd(max_len))[:max_len]
+        reads.append(("edge%d" % i, r))
+        reads.append(("end%d" % i, (rnd(max_len) + s)[-max_len:]))
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    data = fasta_bytes(reads)
+    for rc in (False, True):
+        monkeypatch.setenv("UTREE_LANE_PASS", "1")
+        got = classify_fasta_bytes(db, tree, data, rc=rc)
+        if not rc or 2 * max_len + 1 <= 640:
+            assert tree.kernel_name().startswith("classify_lanes_k<")
+        monkeypatch.setenv("UTREE_LANE_PASS", "0")
+        assert got == classify_fasta_bytes(db, tree, data, rc=rc)
+        assert got == oracle_text(o, data, tmp_path, rc=rc)
+    tree.close()
+
+
 def test_batch_sizes_around_the_grab_of_64(torch_cuda, tmp_path, monkeypatch):
     d = OwnDB(tmp_path, seed=4)
     db = CtrDB.open(d.ctr)

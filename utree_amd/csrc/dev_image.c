@@ -511,8 +511,9 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
      * (8 per SIMD: 32 per CU) and, in a batch that has mid-length reads, those of the mid pass (5 workgroups of 4 per CU) on top:
      * both passes draw from the same cursor.  The kernels do not check the cursor; this bound is what makes that safe. */
     const uint64_t max_total_ = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
-    /* (a batch of the lane-per-read pass runs fewer waves of its own, but leaves reads to the mid pass's kernel: both terms) */
-    const uint64_t waves_per_cu = 32 + (max_total_ > UTREE_SHORT_CAP || max_len <= UTREE_LANES_CAP ? 20 : 0);
+    /* (a batch of the lane-per-read pass runs fewer waves of its own, but leaves reads to a listed pass: both terms, always) */
+    const uint64_t waves_per_cu = 32 + 20;
+    (void)max_total_;
     w->tally_cap = ((do_rc ? 2 : 1) * total_bases + (uint64_t)n_reads) * 9 / 8 + (uint64_t)d->n_cu * waves_per_cu * UTREE_TALLY_CHUNK + 4096;
     w->tally = (uint64_t *)(b + off); off = align_up(off + w->tally_cap * 8, 256);
     w->long_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
@@ -576,13 +577,13 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     d->last_lanes = lanes;
     if (lanes) {
         /* one lane per read; the reads it leaves (several bad bases, more hits than it keeps) are listed for the wave-per-read kernel */
-        KCHK(utk_classify_lanes(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
+        KCHK(utk_classify_lanes(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
         if (d->lanes_ring) {
             const unsigned slot = __atomic_fetch_add(&d->lanes_ring_next, 1u, __ATOMIC_RELAXED) & 63u;
             d->lanes_ring[slot] = ~0ull; d->lanes_ring_reads[slot] = n_reads;
             HIPCHK(hipMemcpyAsync((void *)&d->lanes_ring[slot], w.cursors + UTREE_CUR_MID, 8, hipMemcpyDeviceToHost, st));
         }
-        KCHK(utk_classify_listed(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
+        KCHK(utk_classify_listed(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
     } else
         KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
     if (e0 && dominant == 0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }

@@ -1054,17 +1054,21 @@ int utk_classify_mid(const utk_image *im, const uint8_t *d_bases, const uint64_t
     });
 }
 
-// what the lane-per-read pass (lanes_kernel.hip) listed: reads of up to 160 bases
+// what the lane-per-read pass (lanes_kernel.hip) listed, with the wave-per-read instantiation the batch's longest read needs
 int utk_classify_listed(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
-                        uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+                        uint32_t n_reads, uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
     // the list is short (a database that makes it long turns the lane-per-read pass off, dev_image.c): a quarter of the resident
     // grid finds that out sooner than a full one
     uint32_t blocks = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     uint32_t cap = (uint32_t)n_cu * 2u;
     if (blocks > cap) blocks = cap;
+    const uint64_t total = do_rc ? 2ull * max_len + 1 : max_len;                    // staged bases of the longest read
     return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
-        if (do_rc)        // both strands staged: up to 2 x 160 + 1 bases
+        if (total > SHORT2_CAP)
+            classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), MID_CAP, true>
+                <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+        else if (do_rc || total > SHORT_CAP)
             classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT2_CAP, true>
                 <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
         else

@@ -103,12 +103,16 @@ __device__ __forceinline__ void rest96(const uint32_t (&A)[3], const uint32_t (&
     r0 = __builtin_amdgcn_alignbit(x[0], x[1], bs); r1 = __builtin_amdgcn_alignbit(x[1], x[2], bs); r2 = __builtin_amdgcn_alignbit(x[2], x[3], bs);
 }
 
-template <int W>
+// SEGS lanes per read (1, 2 or 4): lane s of a read takes its windows s SW .. s SW + SW - 1 (SW = LCAP - K + 1: what a slot's bases
+// hold) and the LCAP bases from s SW on that they lie in -- reads of up to (SEGS - 1) SW + LCAP bases, 64 / SEGS of them per wavefront
+template <int W, int SEGS>
 __global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
 void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
                       uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws) {
     using G = Geo<W>;
     constexpr uint32_t K = G::K, NB = G::NB, NA = G::NA, STRIDE = G::STRIDE, FRONT = G::FRONT, RUNS_CAP = G::RUNS;
+    constexpr uint32_t SW = LCAP - K + 1, RPW = 64 / SEGS, SEGSH = SEGS == 4 ? 2 : SEGS == 2 ? 1 : 0;   // windows per lane; reads per wavefront
+    static_assert(SEGS == 1 || SEGS == 2 || SEGS == 4, "lanes per read");
     __shared__ uint32_t s_stream[LANES_WAVES][64 * STRIDE];
     __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
     __shared__ uint16_t s_hits[LANES_WAVES][64 * HMAX];       // [hit][read]: a lane's walk over its own hits is conflict-free
@@ -146,7 +150,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 
     LT_DECL
     for (;;) {
-        // ---- the next 64 reads (one atomic per grab; a used-up part is left for good) ----
+        // ---- the next 64 / SEGS reads (one atomic per grab; a used-up part is left for good) ----
         uint32_t item = 0, item_end = 0;
         bool got = false;
         while (parts_left) {
@@ -154,11 +158,11 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             const uint64_t lo = (uint64_t)part * part_len;
             const uint32_t avail = lo >= n_reads ? 0u : (uint32_t)(n_reads - lo < part_len ? n_reads - lo : part_len);
             unsigned long long g = ~0ull;
-            if (lane == 0 && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < avail) g = atomicAdd(ctr, 64ull);
+            if (lane == 0 && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < avail) g = atomicAdd(ctr, (unsigned long long)RPW);
             const uint32_t taken = uni32((uint32_t)(g > 0xFFFFFFFFull ? 0xFFFFFFFFull : g));
             if (taken < avail) {
                 item = (uint32_t)lo + taken;
-                item_end = taken + 64u < avail ? item + 64u : (uint32_t)lo + avail;
+                item_end = taken + RPW < avail ? item + RPW : (uint32_t)lo + avail;
                 got = true;
                 break;
             }
@@ -169,13 +173,18 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         LT(0);
 
         // ---- phase 0: bytes -> packed 2-bit codes in the lane's slot ----
-        const uint32_t r = item + lane;
-        const bool have = r < item_end;
+        // (L, o: the lane's piece of its read -- the whole read with one lane per read)
         uint32_t L = 0;
         uint64_t o = 0;
-        if (have) { L = len[r]; o = off[r]; }
         bool exc = false;
-        if (L > LCAP) { exc = true; L = 0; }
+        {
+            const uint32_t r0 = item + (lane >> SEGSH), piece = lane & (SEGS - 1u);
+            if (r0 < item_end) {
+                const uint32_t Lr = len[r0];
+                if (Lr > (SEGS - 1u) * SW + LCAP) exc = true;                     // longer than this instantiation holds
+                else if (Lr > piece * SW) { L = umin(LCAP, Lr - piece * SW); o = off[r0] + piece * SW; }
+            }
+        }
         uint32_t badpos;                                                  // the read's one base that is not ACGTacgt, or far away
         {
             const uint64_t a = (uint64_t)(uintptr_t)bases + o;
@@ -367,9 +376,10 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             P[2] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 2) << 32) | (QUAD_BCAST(alo, 2) | mine));
             P[3] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 3) << 32) | (QUAD_BCAST(alo, 3) | mine));
         };
-        auto push = [&](uint32_t q, uint32_t rank) {
-            const uint32_t i = atomicAdd(&cnt[q], 1u);
-            if (i < HMAX) hits[i * 64u + q] = (uint16_t)rank;
+        auto push = [&](uint32_t q, uint32_t rank) {                  // q: the lane whose slot the hit was found in
+            const uint32_t rd = q >> SEGSH;
+            const uint32_t i = atomicAdd(&cnt[rd], 1u);
+            if (i < HMAX) hits[i * 64u + rd] = (uint16_t)rank;
         };
         // hits of a batch wait in two registers per lane (read << 16 | rank, the later one in `p0`) and go to the reads' lists once per
         // batch
@@ -546,8 +556,12 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         LT(3);
 
         // ---- phase C: tally (itree.c:1028-1040), result records, the list of reads left to the wave-per-read kernel ----
-        uint32_t F = cnt[lane];
-        if (F > HMAX || wave_full) exc = true;
+        // (lane i < 64 / SEGS finishes read i of the grab; what its lanes could not take is in their `exc`)
+        const uint64_t excm = ballot64(exc);
+        const uint32_t r = item + lane;
+        const bool have = lane < RPW && r < item_end;
+        uint32_t F = have ? cnt[lane] : 0u;
+        exc = ((excm >> ((lane * SEGS) & 63u)) & ((1ull << SEGS) - 1ull)) != 0ull || F > HMAX || wave_full;
         const uint64_t xm = ballot64(have && exc);
         if (xm) {
             unsigned long long xb = 0;
@@ -603,28 +617,41 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 #endif
 }
 
+template <int W, int SEGS>
+static int launch_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
+                        int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+    uint32_t blocks = (n_reads + (64u / SEGS) * LANES_WAVES - 1) / ((64u / SEGS) * LANES_WAVES);
+    const uint32_t wps = W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS;
+    const uint32_t cap = (uint32_t)n_cu * (4u * wps / LANES_WAVES > 0 ? 4u * wps / LANES_WAVES : 1u);
+    if (blocks > cap) blocks = cap;
+    classify_lanes_k<W, SEGS><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
 
-// The image and batch this kernel takes: k = 32 or 64, u16 labels, a regular table, no read beyond LCAP bases (either strand mode).
+// The image and batch this kernel takes: k = 32 or 64, u16 labels, a regular table, and no read longer than four lanes hold (547 bases
+// for k = 32, 451 for k = 64), either strand mode.
 int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc) {
     (void)do_rc;
-    return (im->W == 8 || im->W == 16) && im->I == 2 && !(im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC)) && max_len <= LCAP;
+    if (!((im->W == 8 || im->W == 16) && im->I == 2) || (im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC))) return 0;
+    return max_len <= 3u * (LCAP - 4u * im->W + 1u) + LCAP;
 }
 
+// max_len: the batch's longest read -- one, two or four lanes per read
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
-                       int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+                       uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
-    uint32_t blocks = (n_reads + 64u * LANES_WAVES - 1) / (64u * LANES_WAVES);
-    const uint32_t wps = im->W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS;
-    const uint32_t cap = (uint32_t)n_cu * (4u * wps / LANES_WAVES > 0 ? 4u * wps / LANES_WAVES : 1u);
-    if (blocks > cap) blocks = cap;
-    if (im->W == 16)
-        classify_lanes_k<16><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
-    else
-        classify_lanes_k<8><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
-    return (int)hipGetLastError();
+    const uint32_t sw = LCAP - 4u * im->W + 1u;
+    const int segs = max_len <= LCAP ? 1 : (max_len <= sw + LCAP ? 2 : 4);
+#define GO(W_, S_) return launch_lanes<W_, S_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream)
+    if (im->W == 16) { if (segs == 1) GO(16, 1); if (segs == 2) GO(16, 2); GO(16, 4); }
+    if (segs == 1) GO(8, 1);
+    if (segs == 2) GO(8, 2);
+    GO(8, 4);
+#undef GO
 }
 
 #ifdef UTREE_LANES_TIMERS

@@ -107,13 +107,13 @@ int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64
 /* lane-per-read pass (lanes_kernel.hip): whether it takes this image / batch; reads it leaves go on ws->mid_list */
 int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc);
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
-                       int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
+                       uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_route(const uint32_t *d_len, uint32_t n_reads, int do_rc, const utk_workspace *ws, void *stream);
 int utk_classify_mid(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                      uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 /* the reads on ws->mid_list with the 150-bp-class wave-per-read kernel (what the lane-per-read pass left) */
 int utk_classify_listed(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
-                        uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
+                        uint32_t n_reads, uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_classify_long(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                       int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_vote(const utk_image *im, utree_result *d_out, const utk_workspace *ws, uint32_t n_reads, void *stream);
