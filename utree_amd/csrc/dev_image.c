@@ -574,7 +574,7 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     if (e0 && dominant == 0) HIPCHK(hipEventRecord(e0, st));
     lanes_ring_collect(d);
     const int lanes = lanes_enabled() && !d->lanes_off && !w.mid_reads && utk_lanes_ok(&d->kimg, max_len, do_rc);
-    d->last_lanes = lanes;
+    d->last_lanes = lanes ? utk_lanes_segs(&d->kimg, max_len) : 0;          /* 0, or the lanes per read */
     if (lanes) {
         /* one lane per read; the reads it leaves (several bad bases, more hits than it keeps) are listed for the wave-per-read kernel */
         KCHK(utk_classify_lanes(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
@@ -621,7 +621,10 @@ fail:
 const char *utree_classify_kernel_name(const utree_dev *dc) {
     if (!dc) return "";
     utree_dev *d = (utree_dev *)dc;                       /* the signature string lives in the handle */
-    if (d->last_lanes && !d->last_long && !d->last_mid) return d->hdr.W == 16 ? "classify_lanes_k<16>" : "classify_lanes_k<8>";
+    if (d->last_lanes && !d->last_long && !d->last_mid) {
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %d>", d->hdr.W, d->last_lanes);
+        return d->kernel_sig;
+    }
     return d->last_long ? utk_classify_long_name(&d->kimg, d->kernel_sig, sizeof d->kernel_sig)
                         : utk_classify_short_name(&d->kimg, d->last_short_cap ? d->last_short_cap : UTREE_SHORT_CAP, d->last_mid, d->last_rc,
                                                   d->kernel_sig, sizeof d->kernel_sig);

@@ -640,12 +640,16 @@ int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc) {
     return max_len <= 3u * (LCAP - 4u * im->W + 1u) + LCAP;
 }
 
-// max_len: the batch's longest read -- one, two or four lanes per read
+// lanes per read for a batch whose longest read has max_len bases
+int utk_lanes_segs(const utk_image *im, uint32_t max_len) {
+    const uint32_t sw = LCAP - 4u * im->W + 1u;
+    return max_len <= LCAP ? 1 : (max_len <= sw + LCAP ? 2 : 4);
+}
+
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                        uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
-    const uint32_t sw = LCAP - 4u * im->W + 1u;
-    const int segs = max_len <= LCAP ? 1 : (max_len <= sw + LCAP ? 2 : 4);
+    const int segs = utk_lanes_segs(im, max_len);
 #define GO(W_, S_) return launch_lanes<W_, S_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream)
     if (im->W == 16) { if (segs == 1) GO(16, 1); if (segs == 2) GO(16, 2); GO(16, 4); }
     if (segs == 1) GO(8, 1);

@@ -106,6 +106,7 @@ int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64
                        void *stream);
 /* lane-per-read pass (lanes_kernel.hip): whether it takes this image / batch; reads it leaves go on ws->mid_list */
 int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc);
+int utk_lanes_segs(const utk_image *im, uint32_t max_len);      /* lanes per read (1, 2, 4) for a batch's longest read */
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                        uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_route(const uint32_t *d_len, uint32_t n_reads, int do_rc, const utk_workspace *ws, void *stream);
