@@ -57,7 +57,7 @@ class OwnDB:
         return self.hi, self.lo
 
 
-@pytest.mark.parametrize("name", ["own", "own64", "vote", "kat"])
+@pytest.mark.parametrize("name", ["own", "own64", "vote", "kat", "toy", "k64", "katq2"])
 def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path, monkeypatch):
     if name.startswith("own"):
         d = OwnDB(tmp_path, k=64 if name == "own64" else 32)
@@ -68,8 +68,7 @@ def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path
         d = util.load_db_fixture(name)
         db, tree = tree_for(name)
         o = orc.OracleDB.load(util.fixture_ctr(name))
-    if tree.info.irregular_bins or tree.info.generic_mode:
-        pytest.skip("this fixture's table has irregular bins (COMPRESS' first-bin quirk): the wave-per-read kernels' exact-probe path")
+    assert not tree.info.generic_mode
     rng = np.random.default_rng(77)
     reads = random_reads(rng, d, 3001, 1, 160) + random_reads(rng, d, 500, 150, 150, hit_frac=0.9)
     hi, lo = d.words()
@@ -99,20 +98,22 @@ def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path
         assert got == oracle_text(o, data, tmp_path, rc=rc)
 
 
-@pytest.mark.parametrize("name", ["vote", "kat"])
-def test_reference_golden_lines_through_the_lane_pass(torch_cuda, name, monkeypatch):
-    """The genuine reference's committed output (tests/golden) for the fixture reads this pass takes (up to 160 bases), on the two
-    fixture databases whose bin tables are regular (the others carry COMPRESS' first-bin quirk and stay on the wave-per-read kernels)."""
+@pytest.mark.parametrize("name,rc", [("vote", 0), ("kat", 0), ("toy", 0), ("toy", 1), ("k64", 0), ("k64", 1), ("katq", 0), ("katq2", 0)])
+def test_reference_golden_lines_through_the_lane_pass(torch_cuda, name, rc, monkeypatch):
+    """The genuine reference's committed output (tests/golden) for the fixture reads this pass takes, k = 32 and 64, both strand
+    modes.  toy / k64 / katq2 carry COMPRESS' first-bin quirk: one or two irregular bins, whose reads the pass leaves to the
+    wave-per-read kernel's exact-probe path."""
     db, tree = tree_for(name)
-    assert not tree.info.irregular_bins and not tree.info.generic_mode
-    lines = util.fixture_bytes(name + "_reads.fa.gz").split(b"\n")
+    assert not tree.info.generic_mode and tree.info.irregular_bins <= 4
+    lines = util.fixture_bytes(util.READS_OF.get(name, name) + "_reads.fa.gz").split(b"\n")
     recs = [(lines[i], lines[i + 1]) for i in range(0, len(lines) - 1, 2)]
-    keep = [(h, q) for h, q in recs if len(q.rstrip(b"\r")) <= 160]
-    assert len(keep) > 900
+    keep = [(h, q) for h, q in recs if len(q.rstrip(b"\r")) <= (319 if rc else 547 if db.k == 32 else 451)]
+    assert len(keep) > 100
     names = {h[1:].split(b" ")[0] for h, q in keep}
-    want = b"".join(l + b"\n" for l in util.fixture_bytes(name + "_out.txt.gz").split(b"\n") if l and l.split(b"\t")[0] in names)
+    out = util.fixture_bytes("%s_out%s.txt.gz" % (name, "_rc" if rc else ""))
+    want = b"".join(l + b"\n" for l in out.split(b"\n") if l and l.split(b"\t")[0] in names)
     monkeypatch.setenv("UTREE_LANE_PASS", "1")
-    got = classify_fasta_bytes(db, tree, b"".join(h + b"\n" + q + b"\n" for h, q in keep), rc=False)
+    got = classify_fasta_bytes(db, tree, b"".join(h + b"\n" + q + b"\n" for h, q in keep), rc=bool(rc))
     assert tree.kernel_name().startswith("classify_lanes_k<")
     assert got == want and len(want) > 0
 

@@ -123,6 +123,21 @@ static void bind_image(utree_dev *d) {
     d->kimg.fine_bits = d->hdr.fine_bits;
     d->kimg.flags = d->hdr.flags;
     d->kimg.W = d->hdr.W; d->kimg.I = d->hdr.I;
+    d->kimg.irr_n = 0;
+    for (int i = 0; i < 4; ++i) d->kimg.irr_p[i] = 0xFFFFFFFFu;
+    if (d->hdr.flags & UTREE_F_GENERIC) d->kimg.irr_n = 0xFFFFFFFFu;
+    else if (d->hdr.flags & UTREE_F_IRREGULAR) {
+        /* list the irregular bins if they are few (one pass over the 2 MB bitmap, once per handle) */
+        d->kimg.irr_n = 0xFFFFFFFFu;
+        uint32_t *bm = d->hdr.n_irregular <= 4 ? (uint32_t *)malloc((1u << 24) / 8) : NULL;
+        if (bm && hipMemcpy(bm, d->kimg.irreg, (1u << 24) / 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            uint32_t n = 0, p[4] = {0, 0, 0, 0};
+            for (uint32_t w = 0; w < (1u << 24) / 32 && n <= 4; ++w)
+                for (uint32_t x = bm[w]; x && n <= 4; x &= x - 1) { if (n < 4) p[n] = w * 32 + (uint32_t)__builtin_ctz(x); ++n; }
+            if (n <= 4) { d->kimg.irr_n = n; for (uint32_t i = 0; i < n; ++i) d->kimg.irr_p[i] = p[i]; }
+        } else (void)hipGetLastError();
+        free(bm);
+    }
 }
 
 static void lanes_ring_init(utree_dev *d);

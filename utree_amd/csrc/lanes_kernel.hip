@@ -105,7 +105,9 @@ __device__ __forceinline__ void rest96(const uint32_t (&A)[3], const uint32_t (&
 
 // SEGS lanes per read (1, 2 or 4): lane s of a read takes its windows s SW .. s SW + SW - 1 (SW = LCAP - K + 1: what a slot's bases
 // hold) and the LCAP bases from s SW on that they lie in -- reads of up to (SEGS - 1) SW + LCAP bases, 64 / SEGS of them per wavefront
-template <int W, int SEGS>
+// IRR: the table has a few irregular bins (COMPRESS' first-bin quirk): their words need the reference's own probe sequence
+// (wave_common.hpp: resolve_bucket), so a read with a window in one of them is left to the wave-per-read kernel
+template <int W, int SEGS, bool IRR>
 __global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
 void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
                       uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws) {
@@ -271,10 +273,19 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         if (maxnwin) {
             uint32_t A[NB];
             uint32_t m16 = sl[0];
+            // (a window's bin is its first 12 bases: the top 24 bits of the 16-mer it starts with -- every 16-mer passes here)
+            auto irregular = [&](uint32_t m, uint32_t u) {                  // u: the 16-mer's first base = the window it starts
+                if constexpr (IRR) {
+                    const uint32_t pf = m >> 8;
+                    if (u < nwin && (pf == im.irr_p[0] || pf == im.irr_p[1] || pf == im.irr_p[2] || pf == im.irr_p[3])) exc = true;
+                }
+            };
+            irregular(m16, 0u);
             A[0] = mix32(m16) & ~0x1FFu;
 #pragma unroll
             for (uint32_t p = 16; p < K; ++p) {
                 m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
+                irregular(m16, p - 15u);
                 A[p - 15] = (mix32(m16) & ~0x1FFu) | (p - 15u);
             }
             // A window that does not exist (beyond the read's last) or holds the bad base (itree.c:919-927) carries the key ~0 -- no
@@ -295,6 +306,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                     else {
                         const uint32_t p = s + (K - 1u);                              // the window's last base
                         m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
+                        irregular(m16, s + (NB - 1u));
                         const uint32_t k = (mix32(m16) & ~0x1FFu) | (s + (NB - 1u));
                         const uint32_t Sr = A[rr];
                         A[rr - 1] = k;                                                // next block's key
@@ -318,6 +330,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 if (done) break;
                 const uint32_t p = NB * (b + 1u) + (K - 1u);
                 m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
+                irregular(m16, NB * (b + 1u) + (NB - 1u));
                 A[NB - 1] = (mix32(m16) & ~0x1FFu) | (NB * (b + 1u) + (NB - 1u));
             }
             nruns = uni32(nruns);
@@ -617,14 +630,14 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 #endif
 }
 
-template <int W, int SEGS>
+template <int W, int SEGS, bool IRR>
 static int launch_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                         int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     uint32_t blocks = (n_reads + (64u / SEGS) * LANES_WAVES - 1) / ((64u / SEGS) * LANES_WAVES);
     const uint32_t wps = W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS;
     const uint32_t cap = (uint32_t)n_cu * (4u * wps / LANES_WAVES > 0 ? 4u * wps / LANES_WAVES : 1u);
     if (blocks > cap) blocks = cap;
-    classify_lanes_k<W, SEGS><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+    classify_lanes_k<W, SEGS, IRR><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
     return (int)hipGetLastError();
 }
 
@@ -632,11 +645,11 @@ static int launch_lanes(const utk_image *im, const uint8_t *d_bases, const uint6
 
 extern "C" {
 
-// The image and batch this kernel takes: k = 32 or 64, u16 labels, a regular table, and no read longer than four lanes hold (547 bases
-// for k = 32, 451 for k = 64), either strand mode.
+// The image and batch this kernel takes: k = 32 or 64, u16 labels, a table with at most four irregular bins, and no read longer than
+// four lanes hold (547 bases for k = 32, 451 for k = 64), either strand mode.
 int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc) {
     (void)do_rc;
-    if (!((im->W == 8 || im->W == 16) && im->I == 2) || (im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC))) return 0;
+    if (!((im->W == 8 || im->W == 16) && im->I == 2) || im->irr_n > 4u) return 0;       // (more irregular bins than the kernel tests for, or every bin)
     return max_len <= 3u * (LCAP - 4u * im->W + 1u) + LCAP;
 }
 
@@ -650,7 +663,8 @@ int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64
                        uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
     const int segs = utk_lanes_segs(im, max_len);
-#define GO(W_, S_) return launch_lanes<W_, S_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream)
+#define GO(W_, S_) return im->irr_n ? launch_lanes<W_, S_, true>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream) \
+                                   : launch_lanes<W_, S_, false>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream)
     if (im->W == 16) { if (segs == 1) GO(16, 1); if (segs == 2) GO(16, 2); GO(16, 4); }
     if (segs == 1) GO(8, 1);
     if (segs == 2) GO(8, 2);

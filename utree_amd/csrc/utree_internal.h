@@ -67,6 +67,9 @@ typedef struct {
     const uint32_t *rank2ix;
     uint64_t n_nodes;
     uint32_t n_labels, fine_bits, flags, W, I;
+    /* the 24-bit prefixes of the irregular bins when there are at most four of them (COMPRESS' first-bin quirk makes one or two;
+     * unused entries are ~0), else irr_n = ~0: what lets the lane-per-read pass tell the reads it must leave alone */
+    uint32_t irr_n, irr_p[4];
 } utk_image;
 
 static inline uint32_t utree_rec_words(uint32_t W, uint32_t I) { return (W == 16 ? 2u : 1u) * (I == 4 ? 2u : 1u); }
