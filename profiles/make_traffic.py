@@ -17,10 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 c = json.load(open(os.path.join(d, "counters.json")))
 line = c["bench_line"]
 sig = line["roofline"]["kernel"]
-name = [k for k in c["counters"] if sig in k]
+name = [k for k in c["counters"] if sig in k or (sig.endswith(">") and k.startswith(sig[:-1] + ","))]   # (a signature recorded with fewer template arguments)
 assert len(name) == 1, (sig, list(c["counters"]))
 cn = c["counters"][name[0]]
-st = [v for k, v in c["kernel_stats"].items() if sig in k]
+st = [v for k, v in c["kernel_stats"].items() if sig in k or (sig.endswith(">") and (sig[:-1] + ",") in k)]
 assert len(st) == 1
 a = dict(x.split("=") for x in [])
 ap = line["config"]["workload"]

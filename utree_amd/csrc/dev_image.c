@@ -637,7 +637,7 @@ const char *utree_classify_kernel_name(const utree_dev *dc) {
     if (!dc) return "";
     utree_dev *d = (utree_dev *)dc;                       /* the signature string lives in the handle */
     if (d->last_lanes && !d->last_long && !d->last_mid) {
-        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %d>", d->hdr.W, d->last_lanes);
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %d, %s>", d->hdr.W, d->last_lanes, d->kimg.irr_n ? "true" : "false");
         return d->kernel_sig;
     }
     return d->last_long ? utk_classify_long_name(&d->kimg, d->kernel_sig, sizeof d->kernel_sig)
