@@ -2,7 +2,7 @@
 bases) against the CPU oracle and against the wave-per-read kernels (UTREE_LANE_PASS=0) on the same inputs, with the cases that
 decide which reads it keeps: one bad base (handled in the kernel), several (left to the wave-per-read kernel), reads shorter
 than a window, the longest reads it holds, batches that are not a multiple of 64, buckets that overflow, reads with more hits
-than it keeps, and a database on which it gives up for good.
+than a lane's slot holds, hit-dense reads, reads with more labels than its tally table, and a workload on which it gives up for good.
 
 Run on the MI355X box:  python -m pytest tests -m gpu -x -q
 """
@@ -182,9 +182,12 @@ def genome_db(tmp_path, rng, n_contigs=12, contig=6000):
     return ctr, contigs
 
 
-def test_hit_dense_reads_are_left_to_the_wave_per_read_kernel_and_the_pass_turns_itself_off(torch_cuda, tmp_path, monkeypatch):
+def test_hit_dense_reads_and_reads_with_more_labels_than_the_tally_table(torch_cuda, tmp_path, monkeypatch):
+    """Reads cut from the database's own contigs hit in every window (119 hits, buckets that overflow): tallied in the kernel.  Reads
+    pieced together from 17 contigs carry more distinct labels than a read's tally table has slots: those are left to the
+    wave-per-read kernel, and a workload made of them turns the pass off for the handle."""
     rng = np.random.default_rng(11)
-    ctr, contigs = genome_db(tmp_path, rng)
+    ctr, contigs = genome_db(tmp_path, rng, n_contigs=24)
     db = CtrDB.open(ctr)
     tree = DeviceTree.upload(db, 0)
     o = orc.OracleDB.load(ctr)
@@ -198,15 +201,30 @@ def test_hit_dense_reads_are_left_to_the_wave_per_read_kernel_and_the_pass_turns
             s = a[p:p + 150] if i % 3 else a[p:p + 75] + b[q:q + 75]                 # a third are chimeras: two labels, a vote
             out.append(("g%d" % i, s))
         return out
-    data = fasta_bytes(cut(4000) + [("sparse%d" % i, "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 150))) for i in range(500)])
-    got = classify_fasta_bytes(db, tree, data, rc=False)
-    assert tree.kernel_name().startswith("classify_lanes_k<")
-    assert got == oracle_text(o, data, tmp_path)
-    big = fasta_bytes(cut(70_000))
-    for _ in range(6):                                                              # > 256 Ki reads, nearly all of them left over
+
+    def patchwork(n):                                                                # 17 x 32 bases, each from another contig
+        out = []
+        for i in range(n):
+            parts = []
+            for c in rng.permutation(len(contigs))[:17]:
+                p = int(rng.integers(0, len(contigs[c]) - 32))
+                parts.append(contigs[c][p:p + 32])
+            out.append(("w%d" % i, "".join(parts)))
+        return out
+    for rc in (False, True):
+        data = fasta_bytes(cut(4000) + [("sparse%d" % i, "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 150))) for i in range(500)])
+        got = classify_fasta_bytes(db, tree, data, rc=rc)
+        assert tree.kernel_name().startswith("classify_lanes_k<")
+        assert got == oracle_text(o, data, tmp_path, rc=rc)
+    mixed = fasta_bytes(cut(300) + patchwork(300))
+    got = classify_fasta_bytes(db, tree, mixed, rc=False)
+    assert tree.kernel_name().startswith("classify_lanes_k<8, 4")
+    assert got == oracle_text(o, mixed, tmp_path)
+    big = fasta_bytes(patchwork(70_000))
+    for _ in range(6):                                                              # > 256 Ki reads, all of them left over
         classify_fasta_bytes(db, tree, big, rc=False)
-    assert "classify_short_k" in tree.kernel_name()                                 # the pass has given up on this database
-    assert classify_fasta_bytes(db, tree, data, rc=False) == got
+    assert "classify_short_k" in tree.kernel_name()                                 # the pass has given up on this handle
+    assert classify_fasta_bytes(db, tree, mixed, rc=False) == got
     tree.close()
 
 

@@ -19,7 +19,7 @@
 // With RC the read's reverse complement takes phases A and B a second time in the same slot.  The hits a read gets are the same
 // (window, record) pairs classify_short_k finds: it asks, per window, which entry of the minimizer's bucket carries the window's
 // key {hash bits, position, outer bases}; this kernel asks, per entry, which window of the run has that key.  Reads this kernel
-// does not finish -- two or more bases other than ACGTacgt, more than LANES_HMAX hits, a wave whose run list is full -- go on the
+// does not finish -- two or more bases other than ACGTacgt, more distinct labels than LANES_TSLOTS, a wave whose run list is full -- go on the
 // batch's list for the wave-per-read kernel (utk_classify_listed), which also remains the kernel for u32 labels, irregular tables,
 // longer reads and databases whose reads hit in most windows (DESIGN.md sections 5c, 11).
 #include <hip/hip_runtime.h>
@@ -40,8 +40,8 @@ using namespace utk;
 #ifndef UTREE_LANES_WPS64
 #define UTREE_LANES_WPS64 3                           /* ... its k = 64 instantiation (same-box: 2 per SIMD 1.66 ms, 3 per SIMD 1.41 ms per 4 M reads) */
 #endif
-#ifndef UTREE_LANES_HMAX
-#define UTREE_LANES_HMAX 16
+#ifndef UTREE_LANES_TSLOTS
+#define UTREE_LANES_TSLOTS 12                         /* distinct labels a read's tally table holds */
 #endif
 
 namespace {
@@ -70,7 +70,8 @@ template <int W> struct Geo {
     static constexpr uint32_t DNONE = 63;                              // minimizer offset no run has (<= 48)
     static_assert((STRIDE & 1) == 1, "slot geometry");
 };
-constexpr uint32_t HMAX = UTREE_LANES_HMAX;           // hits per read this kernel keeps
+constexpr uint32_t TSLOTS = UTREE_LANES_TSLOTS;       // distinct labels per read this kernel keeps count of
+constexpr uint32_t T_EMPTY = 0xFFFFFFFFu;             // an unused slot of a tally table (rank 0xFFFF is no label's)
 constexpr int32_t CUT_PENDING = -3, RANK_PENDING = -4;   // as in kernels.hip (vote_k finishes those results)
 
 __device__ __forceinline__ uint32_t low_bytes(uint32_t n) { return n >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n)) - 1u); }
@@ -117,8 +118,10 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     static_assert(SEGS == 1 || SEGS == 2 || SEGS == 4, "lanes per read");
     __shared__ uint32_t s_stream[LANES_WAVES][64 * STRIDE];
     __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
-    __shared__ uint16_t s_hits[LANES_WAVES][64 * HMAX];       // [hit][read]: a lane's walk over its own hits is conflict-free
-    __shared__ uint32_t s_cnt[LANES_WAVES][64];
+    // a read's hits are tallied as they are found: TSLOTS slots {rank << 16 | count} per read, filled from slot 0 (itree.c:1031-1040
+    // needs the distinct labels with their counts, in any order); [slot][read]: a lane's walk over its own slots is conflict-free
+    __shared__ uint32_t s_tab[LANES_WAVES][64 * TSLOTS];
+    __shared__ uint32_t s_full[LANES_WAVES][2];               // reads with more distinct labels than slots
     __shared__ uint32_t s_pref[LANES_WAVES][64];
     __shared__ uint64_t s_ost[LANES_WAVES][64];               // overflow descriptors of up to 64 runs
     __shared__ uint64_t s_raddr[256];
@@ -133,8 +136,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     const uint32_t wv = uni32(threadIdx.x >> 6);
     uint32_t *stream = s_stream[wv];
     uint32_t *runs = s_runs[wv];
-    uint16_t *hits = s_hits[wv];
-    uint32_t *cnt = s_cnt[wv];
+    uint32_t *tab = s_tab[wv];
+    uint32_t *full = s_full[wv];
     uint32_t *pref = s_pref[wv];
     uint64_t *ost = s_ost[wv];
     uint32_t *sl = stream + lane * STRIDE + FRONT;                        // the lane's slot, word 0
@@ -234,7 +237,9 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             badpos = nbad == 1u ? 4u * badg + ((uint32_t)__builtin_ctz(bad) >> 3) : 0xFFFF0000u;
         }
         const uint32_t nwin = L >= K ? L - (K - 1u) : 0u;
-        cnt[lane] = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < TSLOTS; ++i) tab[i * 64u + lane] = T_EMPTY;
+        if (lane < 2) full[lane] = 0;
         const uint32_t maxnwin = uni32(wave_max_u32(nwin));
         wave_lds_fence();
         LT(1);
@@ -391,8 +396,17 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         };
         auto push = [&](uint32_t q, uint32_t rank) {                  // q: the lane whose slot the hit was found in
             const uint32_t rd = q >> SEGSH;
-            const uint32_t i = atomicAdd(&cnt[rd], 1u);
-            if (i < HMAX) hits[i * 64u + rd] = (uint16_t)rank;
+            uint32_t *t = tab + rd;
+            uint32_t i = 0;
+            for (; i < TSLOTS; ++i) {                                 // (a slot's rank never changes once it is set)
+                uint32_t cur = t[i * 64u];
+                if (cur == T_EMPTY) {
+                    cur = atomicCAS(&t[i * 64u], T_EMPTY, (rank << 16) | 1u);
+                    if (cur == T_EMPTY) break;
+                }
+                if ((cur >> 16) == rank) { atomicAdd(&t[i * 64u], 1u); break; }
+            }
+            if (i == TSLOTS) atomicOr(&full[rd >> 5], 1u << (rd & 31u));
         };
         // hits of a batch wait in two registers per lane (read << 16 | rank, the later one in `p0`) and go to the reads' lists once per
         // batch
@@ -468,11 +482,18 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         }
 #undef QUAD_BCAST
         // ---- runs whose bucket overflows.  The bucket's last entry names the run of MIN records that holds the rest of its nodes.  A
-        // short run (the rule: up to OVF_SCAN records) is read whole, one lane per RECORD, and every record treated like a bucket entry
-        // -- which window of the run is it the record of? -- : two round trips (descriptor, records) however many windows the run
-        // has.  A longer one is searched per window, one lane per WINDOW, by bisection (wave_common.hpp: min_find) like the
-        // wave-per-read kernel does. ----
-        constexpr uint32_t OVF_SCAN = 512;
+        // short run (up to OVF_SCAN records: a minimizer with a few more nodes than a bucket holds) is read whole, one lane per RECORD,
+        // and every record treated like a bucket entry -- which window of the run is it the record of? --: two round trips
+        // (descriptor, records) however many windows the run has.  A long one (a minimizer shared by the k-mers of many related
+        // genomes) is searched per window by bisection like the wave-per-read kernel does (wave_common.hpp: min_find), one lane per
+        // WINDOW and OVF_WAYS windows per lane at a time: the searches' dependent loads overlap. ----
+#ifndef UTREE_LANES_OVF_SCAN
+#define UTREE_LANES_OVF_SCAN 32
+#endif
+#ifndef UTREE_LANES_OVF_WAYS
+#define UTREE_LANES_OVF_WAYS 4
+#endif
+        constexpr uint32_t OVF_SCAN = UTREE_LANES_OVF_SCAN, OVF_WAYS = UTREE_LANES_OVF_WAYS;
         for (uint32_t ib = 0; ib < n_ovf; ib += 64) {
             wave_lds_fence();
             const uint32_t i = ib + lane;
@@ -536,31 +557,55 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 }
             }
             const uint32_t total_win = spread(wn);
-            for (uint32_t t0 = 0; t0 < total_win; t0 += 64) {
-                const uint32_t t = t0 + lane;
-                if (t < total_win) {
-                    uint32_t j;
-                    const uint32_t it_ = item_of(t, j);
-                    const uint32_t rec = runs[ib + it_];
-                    const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu;
-                    const uint32_t pos = ustar - (first + j);                      // the window's minimizer position, 0..K-16
-                    uint32_t m, A[NA], B[NA];
-                    context(q, ustar, m, A, B);
-                    const uint32_t h = mix32(m);
-                    const uint32_t hlow = h & ((1u << s_rshift[h >> 24]) - 1u);
-                    const uint64_t dsc = ost[it_];
-                    const uint64_t start = dsc & M40, n = (dsc >> 40) & 0x3FFFFFull;
-                    MinKey<W> mk;
-                    if constexpr (W == 8) {
-                        const uint32_t rest = (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos));
-                        mk.hi = 0; mk.lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
-                    } else {
-                        uint32_t r0, r1, r2;
-                        rest96(A, B, pos, r0, r1, r2);
-                        mk.lo = ((uint64_t)r1 << 32) | r2; mk.hi = ((uint64_t)hlow << 38) | ((uint64_t)pos << 32) | r0;
+            for (uint32_t t0 = 0; t0 < total_win; t0 += 64 * OVF_WAYS) {
+                uint64_t lo[OVF_WAYS], hi[OVF_WAYS];                               // the searches' ranges (empty: done or no window)
+                MinKey<W> mk[OVF_WAYS];
+                uint32_t qs[OVF_WAYS];
+#pragma unroll
+                for (uint32_t u = 0; u < OVF_WAYS; ++u) {
+                    const uint32_t t = t0 + 64u * u + lane;
+                    lo[u] = hi[u] = 0; qs[u] = 0; mk[u].lo = mk[u].hi = 0;
+                    if (t < total_win) {
+                        uint32_t j;
+                        const uint32_t it_ = item_of(t, j);
+                        const uint32_t rec = runs[ib + it_];
+                        const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu;
+                        const uint32_t pos = ustar - (first + j);                  // the window's minimizer position, 0..K-16
+                        uint32_t m, A[NA], B[NA];
+                        context(q, ustar, m, A, B);
+                        const uint32_t h = mix32(m);
+                        const uint32_t hlow = h & ((1u << s_rshift[h >> 24]) - 1u);
+                        const uint64_t dsc = ost[it_];
+                        lo[u] = dsc & M40; hi[u] = lo[u] + ((dsc >> 40) & 0x3FFFFFull); qs[u] = q;
+                        if constexpr (W == 8) {
+                            const uint32_t rest = (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos));
+                            mk[u].hi = 0; mk[u].lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
+                        } else {
+                            uint32_t r0, r1, r2;
+                            rest96(A, B, pos, r0, r1, r2);
+                            mk[u].lo = ((uint64_t)r1 << 32) | r2; mk[u].hi = ((uint64_t)hlow << 38) | ((uint64_t)pos << 32) | r0;
+                        }
                     }
-                    const uint32_t rank = min_find<W, 2>(im.mrecs, start, start + n, mk);
-                    if (rank != INVALID) push(q, rank);
+                }
+                // exact-match bisection in runs that ascend by key, OVF_WAYS searches per lane in step (a finished one reads record 0 of its range again: no branch around a load)
+                for (;;) {
+                    bool any = false;
+#pragma unroll
+                    for (uint32_t u = 0; u < OVF_WAYS; ++u) any = any || lo[u] < hi[u];
+                    if (!ballot64(any)) break;
+                    Entry<W, 2> e[OVF_WAYS];
+                    uint64_t mid[OVF_WAYS];
+#pragma unroll
+                    for (uint32_t u = 0; u < OVF_WAYS; ++u) { mid[u] = lo[u] + ((hi[u] - lo[u]) >> 1); e[u] = load_entry<W, 2>(im.mrecs, mid[u]); }
+#pragma unroll
+                    for (uint32_t u = 0; u < OVF_WAYS; ++u) {
+                        if (lo[u] < hi[u]) {
+                            const MinKey<W> k = mrec_key<W, 2>(e[u]);
+                            if (mkey_lt<W>(k, mk[u])) lo[u] = mid[u] + 1;
+                            else if (mkey_eq<W>(k, mk[u])) { const uint32_t rank = mrec_rank<W, 2>(e[u]); if (rank != INVALID) push(qs[u], rank); hi[u] = lo[u]; }
+                            else hi[u] = mid[u];
+                        }
+                    }
                 }
             }
         }
@@ -573,8 +618,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         const uint64_t excm = ballot64(exc);
         const uint32_t r = item + lane;
         const bool have = lane < RPW && r < item_end;
-        uint32_t F = have ? cnt[lane] : 0u;
-        exc = ((excm >> ((lane * SEGS) & 63u)) & ((1ull << SEGS) - 1ull)) != 0ull || F > HMAX || wave_full;
+        exc = ((excm >> ((lane * SEGS) & 63u)) & ((1ull << SEGS) - 1ull)) != 0ull || ((full[lane >> 5] >> (lane & 31u)) & 1u) != 0u || wave_full;
         const uint64_t xm = ballot64(have && exc);
         if (xm) {
             unsigned long long xb = 0;
@@ -583,10 +627,17 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             if (have && exc) ws.mid_list[xb + lanes_below(xm)] = r;
         }
         const bool live = have && !exc;
-        if (!live) F = 0;
-        const uint32_t maxF = uni32(wave_max_u32(F));
-        // space for the (rank, count) lists: F entries per read with two or more hits, one reservation per wave and TALLY_CHUNK
-        const uint32_t need = F >= 2u ? F : 0u;
+        // the read's table: nu distinct labels (slots 0 .. nu-1), F hits in all
+        const uint32_t *tq = tab + lane;
+        uint32_t nu = 0, F = 0;
+        if (live) {
+#pragma unroll
+            for (uint32_t i = 0; i < TSLOTS; ++i) { const uint32_t e = tq[i * 64u]; if (e != T_EMPTY) { ++nu; F += e & 0xFFFFu; } }
+        }
+        const uint32_t first_rank = tq[0] >> 16;
+        const uint32_t maxnu = uni32(wave_max_u32(nu));
+        // space for the (rank, count) lists of the reads with two or more labels: one reservation per wave and TALLY_CHUNK
+        const uint32_t need = nu >= 2u ? nu : 0u;
         uint32_t incl = need;
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(incl, dd); if (lane >= (uint32_t)dd) incl += t; }
@@ -599,23 +650,14 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         }
         const unsigned long long my_base = chunk_base + (incl - need);
         chunk_base += total; chunk_left -= total;
-        const uint16_t *hq = hits + lane;
-        uint32_t cur = INVALID;
-        for (uint32_t j = 0; j < maxF; ++j) { const uint32_t h = j < F ? (uint32_t)hq[j * 64u] : INVALID; cur = umin(cur, h); }
-        const uint32_t first_rank = cur;
-        uint32_t nu = 0;
-        while (ballot64(cur != INVALID)) {                                    // one pass per distinct label, ascending = strcmp order (itree.c:1041)
-            uint32_t c = 0, nxt = INVALID;
-            for (uint32_t j = 0; j < maxF; ++j) {
-                const uint32_t h = j < F ? (uint32_t)hq[j * 64u] : INVALID;
-                c += h == cur ? 1u : 0u;
-                nxt = (h > cur && h < nxt) ? h : nxt;
+        // ascending rank = strcmp order (itree.c:1041): an entry's place is the number of the read's labels below its own
+        if (maxnu >= 2u) {
+            for (uint32_t i = 0; i < maxnu; ++i) {
+                const uint32_t e = tq[i * 64u];
+                uint32_t place = 0;
+                for (uint32_t j = 0; j < maxnu; ++j) { const uint32_t x = tq[j * 64u]; place += (j < nu && (x >> 16) < (e >> 16)) ? 1u : 0u; }
+                if (need && i < nu) ws.tally[my_base + place] = (uint64_t)(e >> 16) | ((uint64_t)(e & 0xFFFFu) << 32);
             }
-            if (cur != INVALID) {
-                if (need) ws.tally[my_base + nu] = (uint64_t)cur | ((uint64_t)c << 32);
-                ++nu;
-            }
-            cur = nxt;
         }
         if (live) {
             if (F == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0);
