@@ -448,6 +448,7 @@ int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t byt
     *out = d;
     return UTREE_OK;
 fail:
+    if (d->lanes_ring) hipHostFree((void *)d->lanes_ring);
     free(d);
     return rc;
 }
