@@ -225,6 +225,7 @@ fail:
     if (b->d_ix2rank) hipFree(b->d_ix2rank);
     if (d->owns && d->image) hipFree(d->image);
     if (d->rank_state) hipFree(d->rank_state);
+    if (d->lanes_ring) hipHostFree((void *)d->lanes_ring);
     free(d);
     b->d = NULL;
     return rc;
