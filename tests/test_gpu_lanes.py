@@ -107,7 +107,7 @@ def test_reference_golden_lines_through_the_lane_pass(torch_cuda, name, rc, monk
     assert not tree.info.generic_mode and tree.info.irregular_bins <= 4
     lines = util.fixture_bytes(util.READS_OF.get(name, name) + "_reads.fa.gz").split(b"\n")
     recs = [(lines[i], lines[i + 1]) for i in range(0, len(lines) - 1, 2)]
-    keep = [(h, q) for h, q in recs if len(q.rstrip(b"\r")) <= (319 if rc else 547 if db.k == 32 else 451)]
+    keep = [(h, q) for h, q in recs if len(q.rstrip(b"\r")) <= (1055 if rc else 2095 if db.k == 32 else 1615)]
     assert len(keep) > 100
     names = {h[1:].split(b" ")[0] for h, q in keep}
     out = util.fixture_bytes("%s_out%s.txt.gz" % (name, "_rc" if rc else ""))
@@ -118,22 +118,24 @@ def test_reference_golden_lines_through_the_lane_pass(torch_cuda, name, rc, monk
     assert got == want and len(want) > 0
 
 
-@pytest.mark.parametrize("k,max_len", [(32, 161), (32, 250), (32, 289), (32, 290), (32, 301), (32, 547), (64, 257), (64, 258), (64, 451)])
-def test_longer_reads_take_two_or_four_lanes(torch_cuda, k, max_len, tmp_path, monkeypatch):
-    """A lane holds 160 bases = 129 windows (k = 64: 97); longer reads are cut into such pieces, one lane each, up to four."""
+@pytest.mark.parametrize("k,max_len", [(32, 161), (32, 250), (32, 289), (32, 290), (32, 301), (32, 547), (32, 548), (32, 1063), (32, 1064), (32, 2095),
+                                       (64, 257), (64, 258), (64, 451), (64, 839), (64, 1615)])
+def test_longer_reads_take_two_to_sixteen_lanes(torch_cuda, k, max_len, tmp_path, monkeypatch):
+    """A lane holds 160 bases = 129 windows (k = 64: 97); longer reads are cut into such pieces, one lane each, up to sixteen."""
     d = OwnDB(tmp_path, seed=8, k=k)
     db = CtrDB.open(d.ctr)
     tree = DeviceTree.upload(db, 0)
     o = orc.OracleDB.load(d.ctr)
     rng = np.random.default_rng(max_len)
-    reads = random_reads(rng, d, 1200, 1, max_len, hit_frac=0.7) + random_reads(rng, d, 300, max_len, max_len, hit_frac=0.9)
+    nr = 1200 if max_len <= 600 else 400
+    reads = random_reads(rng, d, nr, 1, max_len, hit_frac=0.7) + random_reads(rng, d, nr // 4, max_len, max_len, hit_frac=0.9)
     hi, lo = d.words()
     some = [ctrfile.decode_kmer(int(hi[j]), int(lo[j]), d.k) for j in rng.integers(0, len(lo), 60)]
     rnd = lambda n: "".join("ACGT"[int(x)] for x in rng.integers(0, 4, n))
     # a database k-mer across every piece boundary (window 128 / 129 of k = 32, 96 / 97 of k = 64, and their multiples), one at the very end
     sw = 160 - k + 1
     for i, s in enumerate(some):
-        at = (1 + i % 3) * sw - (i % 7)
+        at = (1 + i % 15) * sw - (i % 7)
         r = (rnd(max(0, at)) + s + rnd(max_len))[:max_len]
         reads.append(("edge%d" % i, r))
         reads.append(("end%d" % i, (rnd(max_len) + s)[-max_len:]))
@@ -142,7 +144,7 @@ def test_longer_reads_take_two_or_four_lanes(torch_cuda, k, max_len, tmp_path, m
     for rc in (False, True):
         monkeypatch.setenv("UTREE_LANE_PASS", "1")
         got = classify_fasta_bytes(db, tree, data, rc=rc)
-        if not rc or 2 * max_len + 1 <= 640:
+        if 2 * max_len + 1 <= 2112 or not rc:
             assert tree.kernel_name().startswith("classify_lanes_k<")
         monkeypatch.setenv("UTREE_LANE_PASS", "0")
         assert got == classify_fasta_bytes(db, tree, data, rc=rc)
@@ -218,7 +220,7 @@ def test_hit_dense_reads_and_reads_with_more_labels_than_the_tally_table(torch_c
         assert got == oracle_text(o, data, tmp_path, rc=rc)
     mixed = fasta_bytes(cut(300) + patchwork(300))
     got = classify_fasta_bytes(db, tree, mixed, rc=False)
-    assert tree.kernel_name().startswith("classify_lanes_k<8, 4")
+    assert tree.kernel_name().startswith("classify_lanes_k<8, 4")   # 17 x 32 = 544 bases: four lanes per read
     assert got == oracle_text(o, mixed, tmp_path)
     big = fasta_bytes(patchwork(70_000))
     for _ in range(6):                                                              # > 256 Ki reads, all of them left over

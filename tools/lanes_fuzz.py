@@ -25,9 +25,9 @@ def main():
         os.environ["UTREE_FINE_BITS"] = str(int(rng.choice([8, 8, 6, 4, 2, 0])))
         sdb = synth.make_db(dev, nodes, W=W)
         for sub in range(3):
-            cap = (547 if W == 8 else 451)
-            L = int(rng.choice([k, k + 1, 100, 150, 151, 160, 161, 250, 289 if W == 8 else 257, 300, cap]))
-            n = int(rng.integers(1, 40_000))
+            cap = (2095 if W == 8 else 1615)
+            L = int(rng.choice([k, k + 1, 100, 150, 151, 160, 161, 250, 289 if W == 8 else 257, 300, 547 if W == 8 else 451, 700, 1063 if W == 8 else 839, 1200, cap]))
+            n = int(rng.integers(1, 40_000 if L <= 600 else 8_000))
             reads = synth.make_reads(sdb, n, L, seed=int(rng.integers(1, 1 << 30)))
             bases = reads.bases.clone().view(n, L)
             g = torch.Generator(device=dev); g.manual_seed(int(rng.integers(1, 1 << 30)))

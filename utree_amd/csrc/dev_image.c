@@ -583,14 +583,17 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
         }
         e0 = d->events[2 * d->n_pending]; e1 = d->events[2 * d->n_pending + 1];
     }
+    /* The lane-per-read pass takes the whole batch when image and lengths allow (reads of up to 2095 bases, sixteen lanes each; what
+     * it leaves over must fit the listed wave-per-read pass: 2112 staged bases); then nothing is routed. */
+    lanes_ring_collect(d);
+    const uint64_t staged_max = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
+    const int lanes = lanes_enabled() && !d->lanes_off && !w.long_blocks && staged_max <= UTREE_MID_CAP && utk_lanes_ok(&d->kimg, max_len, do_rc);
     /* the bracket goes around the batch's dominant kernel: the long-read kernel when the batch has long reads,
      * else the mid-length pass when it has mid-length reads, else the 150-bp-class kernel */
-    const int dominant = w.long_blocks ? 2 : (w.mid_reads ? 1 : 0);
+    const int dominant = lanes ? 0 : (w.long_blocks ? 2 : (w.mid_reads ? 1 : 0));
     d->last_long = dominant == 2; d->last_mid = dominant == 1; d->last_rc = do_rc; d->last_short_cap = w.short_cap;
-    if (w.mid_reads) KCHK(utk_route(d_len, n_reads, do_rc, &w, st));
+    if (w.mid_reads && !lanes) KCHK(utk_route(d_len, n_reads, do_rc, &w, st));
     if (e0 && dominant == 0) HIPCHK(hipEventRecord(e0, st));
-    lanes_ring_collect(d);
-    const int lanes = lanes_enabled() && !d->lanes_off && !w.mid_reads && utk_lanes_ok(&d->kimg, max_len, do_rc);
     d->last_lanes = lanes ? utk_lanes_segs(&d->kimg, max_len) : 0;          /* 0, or the lanes per read */
     if (lanes) {
         /* one lane per read; the reads it leaves (several bad bases, more hits than it keeps) are listed for the wave-per-read kernel */
@@ -604,7 +607,7 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     } else
         KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
     if (e0 && dominant == 0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
-    if (w.mid_reads) {
+    if (w.mid_reads && !lanes) {
         if (e0 && dominant == 1) HIPCHK(hipEventRecord(e0, st));
         KCHK(utk_classify_mid(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
         if (e0 && dominant == 1) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }

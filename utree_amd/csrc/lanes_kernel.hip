@@ -104,7 +104,7 @@ __device__ __forceinline__ void rest96(const uint32_t (&A)[3], const uint32_t (&
     r0 = __builtin_amdgcn_alignbit(x[0], x[1], bs); r1 = __builtin_amdgcn_alignbit(x[1], x[2], bs); r2 = __builtin_amdgcn_alignbit(x[2], x[3], bs);
 }
 
-// SEGS lanes per read (1, 2 or 4): lane s of a read takes its windows s SW .. s SW + SW - 1 (SW = LCAP - K + 1: what a slot's bases
+// SEGS lanes per read (1, 2, 4, 8 or 16): lane s of a read takes its windows s SW .. s SW + SW - 1 (SW = LCAP - K + 1: what a slot's bases
 // hold) and the LCAP bases from s SW on that they lie in -- reads of up to (SEGS - 1) SW + LCAP bases, 64 / SEGS of them per wavefront
 // IRR: the table has a few irregular bins (COMPRESS' first-bin quirk): their words need the reference's own probe sequence
 // (wave_common.hpp: resolve_bucket), so a read with a window in one of them is left to the wave-per-read kernel
@@ -114,8 +114,9 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                       uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws) {
     using G = Geo<W>;
     constexpr uint32_t K = G::K, NB = G::NB, NA = G::NA, STRIDE = G::STRIDE, FRONT = G::FRONT, RUNS_CAP = G::RUNS;
-    constexpr uint32_t SW = LCAP - K + 1, RPW = 64 / SEGS, SEGSH = SEGS == 4 ? 2 : SEGS == 2 ? 1 : 0;   // windows per lane; reads per wavefront
-    static_assert(SEGS == 1 || SEGS == 2 || SEGS == 4, "lanes per read");
+    constexpr uint32_t SW = LCAP - K + 1, RPW = 64 / SEGS;            // windows per lane; reads per wavefront
+    constexpr uint32_t SEGSH = SEGS == 16 ? 4 : SEGS == 8 ? 3 : SEGS == 4 ? 2 : SEGS == 2 ? 1 : 0;
+    static_assert(SEGS == 1 || SEGS == 2 || SEGS == 4 || SEGS == 8 || SEGS == 16, "lanes per read");
     __shared__ uint32_t s_stream[LANES_WAVES][64 * STRIDE];
     __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
     // a read's hits are tallied as they are found: TSLOTS slots {rank << 16 | count} per read, filled from slot 0 (itree.c:1031-1040
@@ -688,17 +689,17 @@ static int launch_lanes(const utk_image *im, const uint8_t *d_bases, const uint6
 extern "C" {
 
 // The image and batch this kernel takes: k = 32 or 64, u16 labels, a table with at most four irregular bins, and no read longer than
-// four lanes hold (547 bases for k = 32, 451 for k = 64), either strand mode.
+// sixteen lanes hold (2095 bases for k = 32, 1615 for k = 64), either strand mode.
 int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc) {
     (void)do_rc;
     if (!((im->W == 8 || im->W == 16) && im->I == 2) || im->irr_n > 4u) return 0;       // (more irregular bins than the kernel tests for, or every bin)
-    return max_len <= 3u * (LCAP - 4u * im->W + 1u) + LCAP;
+    return max_len <= 15u * (LCAP - 4u * im->W + 1u) + LCAP;
 }
 
-// lanes per read for a batch whose longest read has max_len bases
+// lanes per read for a batch whose longest read has max_len bases (1, 2, 4, 8, 16)
 int utk_lanes_segs(const utk_image *im, uint32_t max_len) {
     const uint32_t sw = LCAP - 4u * im->W + 1u;
-    return max_len <= LCAP ? 1 : (max_len <= sw + LCAP ? 2 : 4);
+    return max_len <= LCAP ? 1 : max_len <= sw + LCAP ? 2 : max_len <= 3u * sw + LCAP ? 4 : max_len <= 7u * sw + LCAP ? 8 : 16;
 }
 
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
@@ -707,10 +708,12 @@ int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64
     const int segs = utk_lanes_segs(im, max_len);
 #define GO(W_, S_) return im->irr_n ? launch_lanes<W_, S_, true>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream) \
                                    : launch_lanes<W_, S_, false>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream)
-    if (im->W == 16) { if (segs == 1) GO(16, 1); if (segs == 2) GO(16, 2); GO(16, 4); }
+    if (im->W == 16) { if (segs == 1) GO(16, 1); if (segs == 2) GO(16, 2); if (segs == 4) GO(16, 4); if (segs == 8) GO(16, 8); GO(16, 16); }
     if (segs == 1) GO(8, 1);
     if (segs == 2) GO(8, 2);
-    GO(8, 4);
+    if (segs == 4) GO(8, 4);
+    if (segs == 8) GO(8, 8);
+    GO(8, 16);
 #undef GO
 }
 
