@@ -26,8 +26,8 @@ def main():
         sdb = synth.make_db(dev, nodes, W=W)
         for sub in range(3):
             cap = (2095 if W == 8 else 1615)
-            L = int(rng.choice([k, k + 1, 100, 150, 151, 160, 161, 250, 289 if W == 8 else 257, 300, 547 if W == 8 else 451, 700, 1063 if W == 8 else 839, 1200, cap]))
-            n = int(rng.integers(1, 40_000 if L <= 600 else 8_000))
+            L = int(rng.choice([k, k + 1, 100, 150, 151, 160, 161, 250, 289 if W == 8 else 257, 300, 547 if W == 8 else 451, 700, 1063 if W == 8 else 839, 1200, cap, cap + 1, 2113, 3000, 5000, 12000]))
+            n = int(rng.integers(1, 40_000 if L <= 600 else 8_000 if L <= 2200 else 1_500))
             reads = synth.make_reads(sdb, n, L, seed=int(rng.integers(1, 1 << 30)))
             bases = reads.bases.clone().view(n, L)
             g = torch.Generator(device=dev); g.manual_seed(int(rng.integers(1, 1 << 30)))

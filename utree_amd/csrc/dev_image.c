@@ -547,6 +547,21 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
         w->hist = (uint32_t *)(b + off); off = align_up(off + (uint64_t)w->long_blocks * d->hdr.n_labels * 4, 256);
         w->touch = (uint32_t *)(b + off); off = align_up(off + (uint64_t)w->long_blocks * ((d->hdr.n_labels + 31) / 32) * 4, 256);
     }
+    /* long reads in pieces through the lane-per-read pass: a tally table per read that can be long, the list of pieces */
+    w->pieces = NULL; w->ltab_rank = w->ltab_cnt = w->lflag = w->long_left = NULL; w->n_long_cap = 0;
+    if (w->long_blocks && utk_lanes_image_ok(&d->kimg)) {
+        const uint64_t staged = (do_rc ? 2 : 1) * total_bases + n_reads;
+        uint64_t cap = staged / ((uint64_t)w->mid_limit + 1) + 1;
+        if (cap > n_reads) cap = n_reads;
+        const uint64_t piece_windows = 16ull * (UTREE_LANES_CAP - 4 * d->hdr.W + 1);
+        const uint64_t n_pieces = total_bases / piece_windows + cap + 1;
+        w->n_long_cap = (uint32_t)cap;
+        w->pieces = (uint64_t *)(b + off); off = align_up(off + n_pieces * 8, 256);
+        w->ltab_rank = (uint32_t *)(b + off); off = align_up(off + cap * UTREE_LONG_SLOTS * 4, 256);
+        w->ltab_cnt = (uint32_t *)(b + off); off = align_up(off + cap * UTREE_LONG_SLOTS * 4, 256);
+        w->lflag = (uint32_t *)(b + off); off = align_up(off + cap * 4, 256);
+        w->long_left = (uint32_t *)(b + off); off = align_up(off + cap * 4, 256);
+    }
     *bytes = (size_t)off;
 }
 
@@ -614,7 +629,18 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     }
     if (w.long_blocks) {
         if (e0) HIPCHK(hipEventRecord(e0, st));
-        KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &w, d->n_cu, st));
+        utk_workspace wl = w;
+        d->last_pieces = 0;
+        if (w.pieces && lanes_enabled() && !d->lanes_off) {
+            /* the long reads in pieces of sixteen lanes through the lane-per-read pass; classify_long_k takes what that leaves */
+            HIPCHK(hipMemsetAsync(w.ltab_rank, 0xFF, (size_t)w.n_long_cap * UTREE_LONG_SLOTS * 4, st));
+            HIPCHK(hipMemsetAsync(w.ltab_cnt, 0, (size_t)w.n_long_cap * UTREE_LONG_SLOTS * 4, st));
+            HIPCHK(hipMemsetAsync(w.lflag, 0, (size_t)w.n_long_cap * 4, st));
+            KCHK(utk_classify_long_pieces(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &w, d->n_cu, st));
+            wl.long_list = w.long_left;
+            d->last_pieces = 1;
+        }
+        KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &wl, d->n_cu, st));
         if (e0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
     }
     KCHK(utk_vote(&d->kimg, d_out, &w, n_reads, st));
@@ -641,8 +667,12 @@ fail:
 const char *utree_classify_kernel_name(const utree_dev *dc) {
     if (!dc) return "";
     utree_dev *d = (utree_dev *)dc;                       /* the signature string lives in the handle */
+    if (d->last_long && d->last_pieces) {
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, 16, %s, true>", d->hdr.W, d->kimg.irr_n ? "true" : "false");
+        return d->kernel_sig;
+    }
     if (d->last_lanes && !d->last_long && !d->last_mid) {
-        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %d, %s>", d->hdr.W, d->last_lanes, d->kimg.irr_n ? "true" : "false");
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %d, %s, false>", d->hdr.W, d->last_lanes, d->kimg.irr_n ? "true" : "false");
         return d->kernel_sig;
     }
     return d->last_long ? utk_classify_long_name(&d->kimg, d->kernel_sig, sizeof d->kernel_sig)

@@ -108,7 +108,9 @@ __device__ __forceinline__ void rest96(const uint32_t (&A)[3], const uint32_t (&
 // hold) and the LCAP bases from s SW on that they lie in -- reads of up to (SEGS - 1) SW + LCAP bases, 64 / SEGS of them per wavefront
 // IRR: the table has a few irregular bins (COMPRESS' first-bin quirk): their words need the reference's own probe sequence
 // (wave_common.hpp: resolve_bucket), so a read with a window in one of them is left to the wave-per-read kernel
-template <int W, int SEGS, bool IRR>
+// PIECE: the items are not reads but pieces of long reads (ws.pieces: SEGS SW windows of a read on ws.long_list each); a piece's
+// tally goes into its read's table in HBM (ws.ltab_*), which finish_long_k turns into the read's result
+template <int W, int SEGS, bool IRR, bool PIECE>
 __global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
 void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
                       uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws) {
@@ -116,10 +118,11 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     constexpr uint32_t K = G::K, NB = G::NB, NA = G::NA, STRIDE = G::STRIDE, FRONT = G::FRONT, RUNS_CAP = G::RUNS;
     constexpr uint32_t SW = LCAP - K + 1, RPW = 64 / SEGS;            // windows per lane; reads per wavefront
     constexpr uint32_t SEGSH = SEGS == 16 ? 4 : SEGS == 8 ? 3 : SEGS == 4 ? 2 : SEGS == 2 ? 1 : 0;
+    constexpr uint32_t TSR = TSLOTS * SEGS < 48u ? TSLOTS * SEGS : 48u;   // tally slots per read: the table space of its lanes, up to 48 labels
     static_assert(SEGS == 1 || SEGS == 2 || SEGS == 4 || SEGS == 8 || SEGS == 16, "lanes per read");
     __shared__ uint32_t s_stream[LANES_WAVES][64 * STRIDE];
     __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
-    // a read's hits are tallied as they are found: TSLOTS slots {rank << 16 | count} per read, filled from slot 0 (itree.c:1031-1040
+    // a read's hits are tallied as they are found: TSR slots {rank << 16 | count} per read, filled from slot 0 (itree.c:1031-1040
     // needs the distinct labels with their counts, in any order); [slot][read]: a lane's walk over its own slots is conflict-free
     __shared__ uint32_t s_tab[LANES_WAVES][64 * TSLOTS];
     __shared__ uint32_t s_full[LANES_WAVES][2];               // reads with more distinct labels than slots
@@ -150,7 +153,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     unsigned long long chunk_base = 0;
     uint32_t chunk_left = 0;
     const uint32_t wave_gid = blockIdx.x * LANES_WAVES + wv;
-    unsigned long long *parts = ws.cursors + 64;
+    if constexpr (PIECE) n_reads = (uint32_t)ws.cursors[UTREE_CUR_PIECES];    // (the items: pieces)
+    unsigned long long *parts = ws.cursors + 64 + (PIECE ? 2 * UTREE_WORK_PARTS * UTREE_WORK_STRIDE : 0);
     const uint32_t part_len = ((n_reads + UTREE_WORK_PARTS - 1) / UTREE_WORK_PARTS + 63u) / 64u * 64u;
     uint32_t part = wave_gid % UTREE_WORK_PARTS, parts_left = UTREE_WORK_PARTS;
 
@@ -186,9 +190,17 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         {
             const uint32_t r0 = item + (lane >> SEGSH), piece = lane & (SEGS - 1u);
             if (r0 < item_end) {
-                const uint32_t Lr = len[r0];
-                if (Lr > (SEGS - 1u) * SW + LCAP) exc = true;                     // longer than this instantiation holds
-                else if (Lr > piece * SW) { L = umin(LCAP, Lr - piece * SW); o = off[r0] + piece * SW; }
+                if constexpr (PIECE) {
+                    const uint64_t pr = ws.pieces[r0];                                // {entry of long_list, piece of that read}
+                    const uint32_t rd = ws.long_list[(uint32_t)(pr >> 32)];
+                    const uint64_t at = (uint64_t)(uint32_t)pr * (SEGS * SW) + piece * SW;   // the lane's first base in the read
+                    const uint64_t Lr = len[rd];
+                    if (Lr > at) { L = (uint32_t)(Lr - at < LCAP ? Lr - at : LCAP); o = off[rd] + at; }
+                } else {
+                    const uint32_t Lr = len[r0];
+                    if (Lr > (SEGS - 1u) * SW + LCAP) exc = true;                 // longer than this instantiation holds
+                    else if (Lr > piece * SW) { L = umin(LCAP, Lr - piece * SW); o = off[r0] + piece * SW; }
+                }
             }
         }
         uint32_t badpos;                                                  // the read's one base that is not ACGTacgt, or far away
@@ -239,7 +251,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         }
         const uint32_t nwin = L >= K ? L - (K - 1u) : 0u;
 #pragma unroll
-        for (uint32_t i = 0; i < TSLOTS; ++i) tab[i * 64u + lane] = T_EMPTY;
+        for (uint32_t i = 0; i < TSLOTS; ++i) tab[i * 64u + lane] = T_EMPTY;      // (the whole table space, whatever its division)
         if (lane < 2) full[lane] = 0;
         const uint32_t maxnwin = uni32(wave_max_u32(nwin));
         wave_lds_fence();
@@ -399,15 +411,15 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             const uint32_t rd = q >> SEGSH;
             uint32_t *t = tab + rd;
             uint32_t i = 0;
-            for (; i < TSLOTS; ++i) {                                 // (a slot's rank never changes once it is set)
-                uint32_t cur = t[i * 64u];
+            for (; i < TSR; ++i) {                                    // (a slot's rank never changes once it is set)
+                uint32_t cur = t[i * RPW];
                 if (cur == T_EMPTY) {
-                    cur = atomicCAS(&t[i * 64u], T_EMPTY, (rank << 16) | 1u);
+                    cur = atomicCAS(&t[i * RPW], T_EMPTY, (rank << 16) | 1u);
                     if (cur == T_EMPTY) break;
                 }
-                if ((cur >> 16) == rank) { atomicAdd(&t[i * 64u], 1u); break; }
+                if ((cur >> 16) == rank) { atomicAdd(&t[i * RPW], 1u); break; }
             }
-            if (i == TSLOTS) atomicOr(&full[rd >> 5], 1u << (rd & 31u));
+            if (i == TSR) atomicOr(&full[rd >> 5], 1u << (rd & 31u));
         };
         // hits of a batch wait in two registers per lane (read << 16 | rank, the later one in `p0`) and go to the reads' lists once per
         // batch
@@ -620,6 +632,33 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         const uint32_t r = item + lane;
         const bool have = lane < RPW && r < item_end;
         exc = ((excm >> ((lane * SEGS) & 63u)) & ((1ull << SEGS) - 1ull)) != 0ull || ((full[lane >> 5] >> (lane & 31u)) & 1u) != 0u || wave_full;
+        if constexpr (PIECE) {
+            // a piece's table is added to its read's: one lane per (piece, slot), claim-or-find the rank, add the count
+            if (have) pref[lane] = (uint32_t)(ws.pieces[r] >> 32);               // the read's entry of long_list
+            if (have && exc) ws.lflag[pref[lane]] = 1u;                            // the whole read is classify_long_k's
+            const uint64_t okm = ballot64(have && !exc);
+            wave_lds_fence();
+            for (uint32_t x0 = 0; x0 < RPW * TSR; x0 += 64) {
+                const uint32_t x = x0 + lane, pc = x / TSR, slot = x % TSR;
+                if (x < RPW * TSR && ((okm >> pc) & 1ull)) {
+                    const uint32_t e = tab[slot * RPW + pc];
+                    if (e != T_EMPTY) {
+                        const uint32_t li = pref[pc], rank = e >> 16;
+                        uint32_t *tr = ws.ltab_rank + (size_t)li * UTREE_LONG_SLOTS, *tc = ws.ltab_cnt + (size_t)li * UTREE_LONG_SLOTS;
+                        uint32_t sidx = (rank * 0x9E3779B1u) >> 26, tries = 0;     // 64 slots, linear probing
+                        for (; tries < UTREE_LONG_SLOTS; ++tries, sidx = (sidx + 1u) & (UTREE_LONG_SLOTS - 1u)) {
+                            uint32_t cur = __hip_atomic_load(&tr[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (cur == 0xFFFFFFFFu) cur = atomicCAS(&tr[sidx], 0xFFFFFFFFu, rank);
+                            if (cur == 0xFFFFFFFFu || cur == rank) { atomicAdd(&tc[sidx], e & 0xFFFFu); break; }
+                        }
+                        if (tries == UTREE_LONG_SLOTS) ws.lflag[li] = 1u;          // more labels than the read's table holds
+                    }
+                }
+            }
+            wave_lds_fence();
+            LT(4);
+            continue;
+        }
         const uint64_t xm = ballot64(have && exc);
         if (xm) {
             unsigned long long xb = 0;
@@ -629,11 +668,11 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         }
         const bool live = have && !exc;
         // the read's table: nu distinct labels (slots 0 .. nu-1), F hits in all
-        const uint32_t *tq = tab + lane;
+        const uint32_t *tq = tab + (lane < RPW ? lane : 0u);
         uint32_t nu = 0, F = 0;
         if (live) {
 #pragma unroll
-            for (uint32_t i = 0; i < TSLOTS; ++i) { const uint32_t e = tq[i * 64u]; if (e != T_EMPTY) { ++nu; F += e & 0xFFFFu; } }
+            for (uint32_t i = 0; i < TSR; ++i) { const uint32_t e = tq[i * RPW]; if (e != T_EMPTY) { ++nu; F += e & 0xFFFFu; } }
         }
         const uint32_t first_rank = tq[0] >> 16;
         const uint32_t maxnu = uni32(wave_max_u32(nu));
@@ -654,9 +693,9 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // ascending rank = strcmp order (itree.c:1041): an entry's place is the number of the read's labels below its own
         if (maxnu >= 2u) {
             for (uint32_t i = 0; i < maxnu; ++i) {
-                const uint32_t e = tq[i * 64u];
+                const uint32_t e = tq[i * RPW];
                 uint32_t place = 0;
-                for (uint32_t j = 0; j < maxnu; ++j) { const uint32_t x = tq[j * 64u]; place += (j < nu && (x >> 16) < (e >> 16)) ? 1u : 0u; }
+                for (uint32_t j = 0; j < maxnu; ++j) { const uint32_t x = tq[j * RPW]; place += (j < nu && (x >> 16) < (e >> 16)) ? 1u : 0u; }
                 if (need && i < nu) ws.tally[my_base + place] = (uint64_t)(e >> 16) | ((uint64_t)(e & 0xFFFFu) << 32);
             }
         }
@@ -673,20 +712,91 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 #endif
 }
 
-template <int W, int SEGS, bool IRR>
+template <int W, int SEGS, bool IRR, bool PIECE = false>
 static int launch_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                         int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     uint32_t blocks = (n_reads + (64u / SEGS) * LANES_WAVES - 1) / ((64u / SEGS) * LANES_WAVES);
     const uint32_t wps = W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS;
     const uint32_t cap = (uint32_t)n_cu * (4u * wps / LANES_WAVES > 0 ? 4u * wps / LANES_WAVES : 1u);
     if (blocks > cap) blocks = cap;
-    classify_lanes_k<W, SEGS, IRR><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+    classify_lanes_k<W, SEGS, IRR, PIECE><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
     return (int)hipGetLastError();
 }
+
+// ---- long reads in pieces (PIECE instantiations above) -------------------------------------------------------------------------
+// pieces_k: every entry of ws.long_list is cut into pieces of PW windows; one atomic per read reserves its places on ws.pieces
+__global__ __launch_bounds__(256) void pieces_k(const uint32_t *__restrict__ len, uint32_t K, uint32_t PW, utk_workspace ws) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
+    if (i >= n_long) return;
+    if (i >= ws.n_long_cap) return;                                         // (cannot happen: the capacity is the bound on such reads)
+    const uint64_t L = len[ws.long_list[i]];
+    const uint64_t nwin = L >= K ? L - K + 1 : 0;
+    const uint32_t np = (uint32_t)((nwin + PW - 1) / PW);
+    if (!np) return;
+    const unsigned long long at = atomicAdd(&ws.cursors[UTREE_CUR_PIECES], (unsigned long long)np);
+    for (uint32_t p = 0; p < np; ++p) ws.pieces[at + p] = ((uint64_t)i << 32) | p;
+}
+
+// finish_long_k: one wavefront per long read, a lane per slot of its table: the distinct labels in strcmp order (= ascending rank) with
+// their counts go on the tally list like a wave-per-read kernel's, vote_k does the rest; a read the pieces pass could not finish goes
+// on ws.long_left for classify_long_k
+__global__ __launch_bounds__(256) void finish_long_k(utree_result *__restrict__ out, utk_workspace ws) {
+    const uint32_t lane = lane_id();
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
+    if (i >= n_long) return;
+    const uint32_t r = ws.long_list[i];
+    if (ws.lflag[i]) {
+        if (lane == 0) ws.long_left[atomicAdd(&ws.cursors[UTREE_CUR_LEFT], 1ull)] = r;
+        return;
+    }
+    const uint32_t rank = ws.ltab_rank[(size_t)i * UTREE_LONG_SLOTS + lane], cnt = ws.ltab_cnt[(size_t)i * UTREE_LONG_SLOTS + lane];
+    const bool valid = rank != 0xFFFFFFFFu;
+    const uint64_t vm = ballot64(valid);
+    const uint32_t nu = (uint32_t)__popcll(vm);
+    const uint32_t F = wave_sum_u32(valid ? cnt : 0u);
+    if (nu == 0) { if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); return; }
+    if (nu == 1) { if (valid) store_result(&out[r], rank, RANK_PENDING, F, 1, 0, 0); return; }
+    uint32_t place = 0;
+    for (uint64_t m = vm; m; m &= m - 1) {
+        const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)__builtin_ctzll(m));
+        place += other < rank ? 1u : 0u;
+    }
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&ws.cursors[0], (unsigned long long)nu);
+    base = uni64(base);
+    if (valid) ws.tally[base + place] = (uint64_t)rank | ((uint64_t)cnt << 32);
+    if (lane == 0) store_result(&out[r], 0, CUT_PENDING, F, nu, (uint32_t)base, (uint32_t)(base >> 32));
+}
+
+// what classify_long_k is left with: its list is ws.long_left from here on, its count takes the place of the long-read count
+__global__ void left_count_k(utk_workspace ws) { ws.cursors[UTREE_CUR_LONG] = ws.cursors[UTREE_CUR_LEFT]; }
 
 }  // namespace
 
 extern "C" {
+
+int utk_lanes_image_ok(const utk_image *im) { return (im->W == 8 || im->W == 16) && im->I == 2 && im->irr_n <= 4u; }
+
+int utk_classify_long_pieces(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, int do_rc,
+                             utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+    if (!ws->pieces || !ws->n_long_cap) return (int)hipErrorInvalidValue;
+    const uint32_t K = 4u * im->W, PW = 16u * (LCAP - K + 1u);
+    hipStream_t st = (hipStream_t)stream;
+    pieces_k<<<dim3((ws->n_long_cap + 255) / 256), dim3(256), 0, st>>>(d_len, K, PW, *ws);
+    // (the grid of the pieces pass is the resident one: the number of pieces is on the device)
+    const uint32_t many = 0x40000000u;
+    int rc;
+    if (im->W == 16) rc = im->irr_n ? launch_lanes<16, 16, true, true>(im, d_bases, d_off, d_len, many, do_rc, d_out, ws, n_cu, stream)
+                                    : launch_lanes<16, 16, false, true>(im, d_bases, d_off, d_len, many, do_rc, d_out, ws, n_cu, stream);
+    else rc = im->irr_n ? launch_lanes<8, 16, true, true>(im, d_bases, d_off, d_len, many, do_rc, d_out, ws, n_cu, stream)
+                        : launch_lanes<8, 16, false, true>(im, d_bases, d_off, d_len, many, do_rc, d_out, ws, n_cu, stream);
+    if (rc) return rc;
+    finish_long_k<<<dim3((ws->n_long_cap + 3) / 4), dim3(256), 0, st>>>(d_out, *ws);
+    left_count_k<<<dim3(1), dim3(1), 0, st>>>(*ws);
+    return (int)hipGetLastError();
+}
 
 // The image and batch this kernel takes: k = 32 or 64, u16 labels, a table with at most four irregular bins, and no read longer than
 // sixteen lanes hold (2095 bases for k = 32, 1615 for k = 64), either strand mode.

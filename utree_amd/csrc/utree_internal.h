@@ -24,7 +24,10 @@ extern "C" {
  * costs a wave ~14 us, measured); a wave starts at part (its index mod PARTS) and moves on when a part is used up. */
 #define UTREE_WORK_PARTS 64
 #define UTREE_WORK_STRIDE 16                     /* 8-byte words between two counters                            */
-#define UTREE_CURSOR_BYTES (512 + 2 * UTREE_WORK_PARTS * UTREE_WORK_STRIDE * 8)   /* cursors[] + part counters (main, mid) */
+#define UTREE_CUR_PIECES 8                       /* ... of the pieces of long reads listed for the lane-per-read pass */
+#define UTREE_CUR_LEFT 24                        /* ... of the long reads that pass left to classify_long_k            */
+#define UTREE_CURSOR_BYTES (512 + 3 * UTREE_WORK_PARTS * UTREE_WORK_STRIDE * 8)   /* cursors[] + part counters (main, mid, pieces) */
+#define UTREE_LONG_SLOTS 64u                     /* {rank, count} slots of a long read's tally table in HBM (pieces mode) */
 #define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds      */
 #define UTREE_SHORT2_CAP 640u                    /* ... its second size: 250-300 bp reads with the reverse strand */
 #define UTREE_MID_DEFAULT 2112u                  /* = UTREE_MID_CAP: since r01l the wave-per-read pass beats classify_long_k up to its capacity (2100 bp: 65 vs 46 M reads/s); UTREE_MID_LIMIT overrides */
@@ -102,6 +105,12 @@ typedef struct {
     uint32_t long_blocks, mid_reads; /* mid_reads != 0: the batch may hold mid-length reads                   */
     uint32_t short_cap;              /* UTREE_SHORT_CAP or UTREE_SHORT2_CAP: what the batch's main wave-per-read pass holds */
     uint32_t mid_limit;              /* staged bases up to which the wave-per-read mid pass is used (<= UTREE_MID_CAP) */
+    /* long reads through the lane-per-read pass, cut into pieces of sixteen lanes (lanes_kernel.hip); NULL: not for this batch */
+    uint64_t *pieces;                /* {index in long_list << 32 | piece}                                      */
+    uint32_t *ltab_rank, *ltab_cnt;  /* per long_list entry: UTREE_LONG_SLOTS ranks (~0: free) and hit counts    */
+    uint32_t *lflag;                 /* per long_list entry: 1 = left to classify_long_k                        */
+    uint32_t *long_left;             /* the reads so left                                                       */
+    uint32_t n_long_cap;             /* long_list entries the tables above hold                                  */
 } utk_workspace;
 
 int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
@@ -109,7 +118,12 @@ int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64
                        void *stream);
 /* lane-per-read pass (lanes_kernel.hip): whether it takes this image / batch; reads it leaves go on ws->mid_list */
 int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc);
-int utk_lanes_segs(const utk_image *im, uint32_t max_len);      /* lanes per read (1, 2, 4) for a batch's longest read */
+int utk_lanes_segs(const utk_image *im, uint32_t max_len);      /* lanes per read (1 .. 16) for a batch's longest read */
+/* long reads (ws->long_list) in pieces through the lane-per-read pass; what it cannot finish ends up on ws->long_left with its
+ * count in cursors[UTREE_CUR_LONG], for utk_classify_long with long_list = long_left */
+int utk_lanes_image_ok(const utk_image *im);
+int utk_classify_long_pieces(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, int do_rc,
+                             utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                        uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_route(const uint32_t *d_len, uint32_t n_reads, int do_rc, const utk_workspace *ws, void *stream);
