@@ -186,10 +186,10 @@ def genome_db(tmp_path, rng, n_contigs=12, contig=6000):
 
 def test_hit_dense_reads_and_reads_with_more_labels_than_the_tally_table(torch_cuda, tmp_path, monkeypatch):
     """Reads cut from the database's own contigs hit in every window (119 hits, buckets that overflow): tallied in the kernel.  Reads
-    pieced together from 17 contigs carry more distinct labels than a read's tally table has slots: those are left to the
+    pieced together from 60 contigs carry more distinct labels than a read's tally table has slots (48): those are left to the
     wave-per-read kernel, and a workload made of them turns the pass off for the handle."""
     rng = np.random.default_rng(11)
-    ctr, contigs = genome_db(tmp_path, rng, n_contigs=24)
+    ctr, contigs = genome_db(tmp_path, rng, n_contigs=72, contig=3000)
     db = CtrDB.open(ctr)
     tree = DeviceTree.upload(db, 0)
     o = orc.OracleDB.load(ctr)
@@ -204,11 +204,11 @@ def test_hit_dense_reads_and_reads_with_more_labels_than_the_tally_table(torch_c
             out.append(("g%d" % i, s))
         return out
 
-    def patchwork(n):                                                                # 17 x 32 bases, each from another contig
+    def patchwork(n):                                                                # 60 x 32 bases, each from another contig
         out = []
         for i in range(n):
             parts = []
-            for c in rng.permutation(len(contigs))[:17]:
+            for c in rng.permutation(len(contigs))[:60]:
                 p = int(rng.integers(0, len(contigs[c]) - 32))
                 parts.append(contigs[c][p:p + 32])
             out.append(("w%d" % i, "".join(parts)))
@@ -220,10 +220,10 @@ def test_hit_dense_reads_and_reads_with_more_labels_than_the_tally_table(torch_c
         assert got == oracle_text(o, data, tmp_path, rc=rc)
     mixed = fasta_bytes(cut(300) + patchwork(300))
     got = classify_fasta_bytes(db, tree, mixed, rc=False)
-    assert tree.kernel_name().startswith("classify_lanes_k<8, 4")   # 17 x 32 = 544 bases: four lanes per read
+    assert tree.kernel_name().startswith("classify_lanes_k<8, 16")   # 60 x 32 = 1920 bases: sixteen lanes per read
     assert got == oracle_text(o, mixed, tmp_path)
-    big = fasta_bytes(patchwork(70_000))
-    for _ in range(6):                                                              # > 256 Ki reads, all of them left over
+    big = fasta_bytes(patchwork(30_000))
+    for _ in range(10):                                                              # > 256 Ki reads, all of them left over
         classify_fasta_bytes(db, tree, big, rc=False)
     assert "classify_short_k" in tree.kernel_name()                                 # the pass has given up on this handle
     assert classify_fasta_bytes(db, tree, mixed, rc=False) == got

@@ -549,7 +549,9 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
     }
     /* long reads in pieces through the lane-per-read pass: a tally table per read that can be long, the list of pieces */
     w->pieces = NULL; w->ltab_rank = w->ltab_cnt = w->lflag = w->long_left = NULL; w->n_long_cap = 0;
-    if (w->long_blocks && utk_lanes_image_ok(&d->kimg)) {
+    if (w->long_blocks && lanes_enabled() && !d->lanes_off && utk_lanes_image_ok(&d->kimg)) {
+        /* ... and with them the mid-length ones: route_k lists everything beyond the 150-bp-class kernel's size as long */
+        w->mid_limit = w->short_cap;
         const uint64_t staged = (do_rc ? 2 : 1) * total_bases + n_reads;
         uint64_t cap = staged / ((uint64_t)w->mid_limit + 1) + 1;
         if (cap > n_reads) cap = n_reads;
@@ -622,7 +624,7 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     } else
         KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
     if (e0 && dominant == 0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
-    if (w.mid_reads && !lanes) {
+    if (w.mid_reads && !lanes && !w.pieces) {
         if (e0 && dominant == 1) HIPCHK(hipEventRecord(e0, st));
         KCHK(utk_classify_mid(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
         if (e0 && dominant == 1) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
@@ -631,7 +633,7 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
         if (e0) HIPCHK(hipEventRecord(e0, st));
         utk_workspace wl = w;
         d->last_pieces = 0;
-        if (w.pieces && lanes_enabled() && !d->lanes_off) {
+        if (w.pieces) {
             /* the long reads in pieces of sixteen lanes through the lane-per-read pass; classify_long_k takes what that leaves */
             HIPCHK(hipMemsetAsync(w.ltab_rank, 0xFF, (size_t)w.n_long_cap * UTREE_LONG_SLOTS * 4, st));
             HIPCHK(hipMemsetAsync(w.ltab_cnt, 0, (size_t)w.n_long_cap * UTREE_LONG_SLOTS * 4, st));
