@@ -548,7 +548,7 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
         w->touch = (uint32_t *)(b + off); off = align_up(off + (uint64_t)w->long_blocks * ((d->hdr.n_labels + 31) / 32) * 4, 256);
     }
     /* long reads in pieces through the lane-per-read pass: a tally table per read that can be long, the list of pieces */
-    w->pieces = NULL; w->ltab_rank = w->ltab_cnt = w->lflag = w->long_left = NULL; w->n_long_cap = 0;
+    w->pieces = NULL; w->ltab_rank = w->ltab_cnt = w->lflag = w->long_left = NULL; w->n_long_cap = 0; w->ltally_base = 0;
     if (w->long_blocks && lanes_enabled() && !d->lanes_off && utk_lanes_image_ok(&d->kimg)) {
         /* ... and with them the mid-length ones: route_k lists everything beyond the 150-bp-class kernel's size as long */
         w->mid_limit = w->short_cap;
@@ -563,6 +563,8 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
         w->ltab_cnt = (uint32_t *)(b + off); off = align_up(off + cap * UTREE_LONG_SLOTS * 4, 256);
         w->lflag = (uint32_t *)(b + off); off = align_up(off + cap * 4, 256);
         w->long_left = (uint32_t *)(b + off); off = align_up(off + cap * 4, 256);
+        /* the long reads' tally lists at fixed places behind everything the other passes reserve (no reservation traffic) */
+        w->ltally_base = (uint64_t)((uint64_t *)(b + off) - w->tally); off = align_up(off + cap * UTREE_LONG_SLOTS * 8, 256);
     }
     *bytes = (size_t)off;
 }
@@ -640,6 +642,7 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
             HIPCHK(hipMemsetAsync(w.lflag, 0, (size_t)w.n_long_cap * 4, st));
             KCHK(utk_classify_long_pieces(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &w, d->n_cu, st));
             wl.long_list = w.long_left;
+            wl.long_blocks = w.long_blocks >= 8 ? w.long_blocks / 8 : 1;     /* few reads are left: a grid that finds that out quickly */
             d->last_pieces = 1;
         }
         KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &wl, d->n_cu, st));

@@ -743,31 +743,30 @@ __global__ __launch_bounds__(256) void pieces_k(const uint32_t *__restrict__ len
 // on ws.long_left for classify_long_k
 __global__ __launch_bounds__(256) void finish_long_k(utree_result *__restrict__ out, utk_workspace ws) {
     const uint32_t lane = lane_id();
-    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
-    if (i >= n_long) return;
+    // (a resident grid walking the entries: a workgroup per four reads is bound by the rate at which workgroups are dispatched)
+    for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_long; i += gridDim.x * 4u) {
     const uint32_t r = ws.long_list[i];
     if (ws.lflag[i]) {
         if (lane == 0) ws.long_left[atomicAdd(&ws.cursors[UTREE_CUR_LEFT], 1ull)] = r;
-        return;
+        continue;
     }
     const uint32_t rank = ws.ltab_rank[(size_t)i * UTREE_LONG_SLOTS + lane], cnt = ws.ltab_cnt[(size_t)i * UTREE_LONG_SLOTS + lane];
     const bool valid = rank != 0xFFFFFFFFu;
     const uint64_t vm = ballot64(valid);
     const uint32_t nu = (uint32_t)__popcll(vm);
     const uint32_t F = wave_sum_u32(valid ? cnt : 0u);
-    if (nu == 0) { if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); return; }
-    if (nu == 1) { if (valid) store_result(&out[r], rank, RANK_PENDING, F, 1, 0, 0); return; }
+    if (nu == 0) { if (lane == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0); continue; }
+    if (nu == 1) { if (valid) store_result(&out[r], rank, RANK_PENDING, F, 1, 0, 0); continue; }
     uint32_t place = 0;
     for (uint64_t m = vm; m; m &= m - 1) {
         const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)__builtin_ctzll(m));
         place += other < rank ? 1u : 0u;
     }
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&ws.cursors[0], (unsigned long long)nu);
-    base = uni64(base);
+    const unsigned long long base = ws.ltally_base + (unsigned long long)i * UTREE_LONG_SLOTS;   // the entry's own place: no reservation
     if (valid) ws.tally[base + place] = (uint64_t)rank | ((uint64_t)cnt << 32);
     if (lane == 0) store_result(&out[r], 0, CUT_PENDING, F, nu, (uint32_t)base, (uint32_t)(base >> 32));
+    }
 }
 
 // what classify_long_k is left with: its list is ws.long_left from here on, its count takes the place of the long-read count
@@ -793,7 +792,7 @@ int utk_classify_long_pieces(const utk_image *im, const uint8_t *d_bases, const 
     else rc = im->irr_n ? launch_lanes<8, 16, true, true>(im, d_bases, d_off, d_len, many, do_rc, d_out, ws, n_cu, stream)
                         : launch_lanes<8, 16, false, true>(im, d_bases, d_off, d_len, many, do_rc, d_out, ws, n_cu, stream);
     if (rc) return rc;
-    finish_long_k<<<dim3((ws->n_long_cap + 3) / 4), dim3(256), 0, st>>>(d_out, *ws);
+    { uint32_t fb = (ws->n_long_cap + 3) / 4, fcap = (uint32_t)n_cu * 8u; finish_long_k<<<dim3(fb < fcap ? fb : fcap), dim3(256), 0, st>>>(d_out, *ws); }
     left_count_k<<<dim3(1), dim3(1), 0, st>>>(*ws);
     return (int)hipGetLastError();
 }

@@ -111,6 +111,7 @@ typedef struct {
     uint32_t *lflag;                 /* per long_list entry: 1 = left to classify_long_k                        */
     uint32_t *long_left;             /* the reads so left                                                       */
     uint32_t n_long_cap;             /* long_list entries the tables above hold                                  */
+    uint64_t ltally_base;            /* ws.tally index of the long reads' (rank, count) lists: UTREE_LONG_SLOTS each */
 } utk_workspace;
 
 int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
