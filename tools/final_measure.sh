@@ -12,4 +12,6 @@ python3 tests/scale/e2e_scale.py --threads 16 > gpurun_out/e2e_scale_lanes_k32.j
 python3 tests/scale/e2e_scale.py --threads 16 --nodes 400000000 --reads 2000000 --rc 1 > gpurun_out/e2e_scale_lanes_k32_rc.json 2> gpurun_out/e2e_scale_lanes_k32_rc.err; echo "e2e scale k32 rc rc=$?"
 python3 tests/scale/e2e_scale.py --threads 16 --kmer 64 --nodes 568000000 --reads 2000000 > gpurun_out/e2e_scale_lanes_k64.json 2> gpurun_out/e2e_scale_lanes_k64.err; echo "e2e scale k64 rc=$?"
 python3 tests/scale/e2e_scale.py --threads 16 --nodes 400000000 --reads 1000000 --read-len 250 > gpurun_out/e2e_scale_lanes_250bp.json 2> gpurun_out/e2e_scale_lanes_250bp.err; echo "e2e scale 250bp rc=$?"
+python3 tests/scale/e2e_scale.py --threads 16 --nodes 72000000 --reads 50000 --read-len 10000 --rc 1 > gpurun_out/e2e_scale_lanes_long_rc.json 2> gpurun_out/e2e_scale_lanes_long_rc.err; echo "e2e scale long rc rc=$?"
+python3 tests/scale/e2e_scale.py --threads 16 --kmer 64 --nodes 72000000 --reads 30000 --read-len 5000 > gpurun_out/e2e_scale_lanes_long_k64.json 2> gpurun_out/e2e_scale_lanes_long_k64.err; echo "e2e scale long k64 rc=$?"
 python3 bench.py > gpurun_out/bench_${T}_n1.json 2> gpurun_out/bench_${T}_n1.err; echo "bench rc=$?"
