@@ -77,7 +77,11 @@ def main():
                     help="N>1: image broadcast issued from C (utree_dev_replicate_rank, RCCL) or through torch.distributed.broadcast")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse on one GPU")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo --replicate torch)")
+    ap.add_argument("--e2e-reads-per-rank", type=int, default=8_000_000, help="N>1: reads of each rank's shard in the file -> file leg")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("UTREE_BENCH_FORCE_DIST"):
+        raise SystemExit(self_launch(args))
 
     # stdout carries ONE JSON line: libraries that chat on fd 1 (RCCL prints a version banner there when its
     # communicator is created) are sent to stderr until that line is written
@@ -97,6 +101,8 @@ def main():
     dist_on = world > 1 or bool(os.environ.get("UTREE_BENCH_FORCE_DIST"))   # the env var rehearses the N>1 code path with one rank
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not os.environ.get("UTREE_BENCH_FORCE_DIST"):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if args.share_gpu0:
@@ -111,6 +117,7 @@ def main():
     W = args.kmer // 4
     want_cpu = (world == 1 and not args.no_cpu_baseline)
     want_e2e = (world == 1 and not args.no_e2e)
+    want_e2e_dist = (world > 1 and not args.no_e2e)
 
     # ---- database: rank 0 builds the image in HBM, the others receive it by ONE broadcast (RCCL / xGMI) ----
     t0 = time.time()
@@ -198,6 +205,7 @@ def main():
         elapsed = udist.max_over_ranks(elapsed, dev)
     k_ms, k_launches = tree.kernel_time(reset=True)
 
+    line = None
     if rank == 0:
         reads_total = world * args.batch_reads * args.steps
         value = reads_total / elapsed
@@ -219,6 +227,23 @@ def main():
             "roofline": roof,
             "db_build_seconds": db_s, "classified_fraction_last_batch": nfound / args.batch_reads,
         }
+        if dist_on:
+            line["ranks"] = dist.get_world_size()
+            line["gpus_arg"] = args.gpus
+            line["bcast_s"] = bcast_s
+            line["bcast"] = bcast_how
+            line["scaling_note"] = ("value is the HBM-resident rate: every rank classifies its own batches, so it scales with the GPUs by construction (weak scaling, "
+                                    "no data-path collective).  The file -> file rate (`e2e`) scales only while every rank writes its own output file; "
+                                    "ONE concatenated output file fills at the host's page-allocation rate (~6 GB/s on this class of box, DESIGN.md section 5b) "
+                                    "whatever the number of GPUs")
+    if want_e2e_dist:
+        # every rank takes part: its own shard of the reads, file -> file on its own GPU; rank 0 reports
+        del batches[1:], outs[1:], wss[:]
+        torch.cuda.empty_cache()
+        e2e = e2e_leg_dist(args, sdb, tree, rank, world, dev, udist)
+        if rank == 0:
+            line["e2e"] = e2e
+    if rank == 0:
         files = None
         try:
             if want_cpu or want_e2e:
@@ -239,6 +264,123 @@ def main():
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def e2e_leg_dist(args, sdb, tree, rank, world, dev, udist):
+    """The file -> file leg at N > 1, in the shape SURVEY 8(e) / north_star give the path: the reads shard into contiguous ranges,
+    rank g classifies range g from its own FASTA shard into its own output file on its own GPU (utree_search_file, C-ABI), and the
+    host concatenates the per-rank outputs in rank order (= input order).  `value` counts the reads of all ranks over the time until
+    the LAST rank has closed its output file (barrier before, max over ranks); the concatenation into one file is timed by itself
+    (`concat_seconds`, `value_with_concat`): it is a host-side copy bound by the page-allocation rate of one file.  Parity at N > 1:
+    rank 0 classifies the last rank's shard again on its own replica of the image -- the two files must be identical (the image a
+    rank received by the broadcast answers like the image that was built)."""
+    import ctypes as C
+    import hashlib
+    import shutil
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from utree_amd import lib as ulib
+    from utree_amd import synth
+    from utree_amd.search import search_gg
+    out = {"metric": "reads/s, per-rank FASTA shard in -> per-rank classifications file closed (all ranks), database image resident", "unit": "reads/s"}
+    n = int(min(args.e2e_reads_per_rank, args.steps * args.batch_reads))
+    box = [None]
+    if rank == 0:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 3 * world * 300 * n else None
+        box[0] = tempfile.mkdtemp(prefix="utree_bench_dist_", dir=base)
+    dist.broadcast_object_list(box, src=0)
+    d = box[0]
+    fa, outp = os.path.join(d, "reads_%d.fa" % rank), os.path.join(d, "out_%d.txt" % rank)
+    err = None
+    wall, st = 0.0, None
+    try:
+        with open(fa, "wb") as f:
+            done, b = 0, 0
+            while done < n:
+                m = min(args.batch_reads, n - done)
+                r = synth.make_reads(sdb, args.batch_reads, args.read_len, seed=synth.READ_SEED + 1000 * rank + b, device=dev)
+                if m < args.batch_reads:
+                    r = synth.SynthReads(bases=r.bases[: m * args.read_len], off=r.off[:m], length=r.length[:m], n=m, read_len=args.read_len)
+                synth.fasta_tensor(r, rank * n + done).cpu().numpy().tofile(f)
+                done += m
+                b += 1
+                del r
+        torch.cuda.empty_cache()
+        L = ulib.load()
+        arr = (C.c_void_p * 1)(tree._h)
+        ulib.check(L.utree_search_prepare(sdb.ctr._h, arr, 1, int(bool(args.rc))), "utree_search_prepare")
+    except Exception as e:            # every rank must still reach the collectives below
+        err = repr(e)
+    dist.barrier()
+    if err is None:
+        try:
+            t0 = time.time()
+            code, st = search_gg(sdb.ctr, [tree], fa, outp, rc=bool(args.rc), threads=16)
+            wall = time.time() - t0
+            ulib.check(code, "utree_search_file")
+        except Exception as e:
+            err = repr(e)
+    dist.barrier()
+    mine = {"rank": rank, "error": err, "wall_seconds": wall}
+    if st is not None and err is None:
+        mine.update(reads=int(st.n_reads), lines=int(st.good_finds), bytes_in=int(st.bytes_in), bytes_out=int(st.bytes_out),
+                    pipeline="device text" if st.pipeline else "host text",
+                    sha256=hashlib.sha256(open(outp, "rb").read()).hexdigest())
+    parts = [None] * world
+    dist.gather_object(mine, parts if rank == 0 else None, dst=0)
+    if rank == 0:
+        try:
+            bad = [p for p in parts if p["error"]]
+            if bad:
+                raise RuntimeError("rank %d: %s" % (bad[0]["rank"], bad[0]["error"]))
+            slowest = max(p["wall_seconds"] for p in parts)
+            reads = sum(p["reads"] for p in parts)
+            out["value"] = reads / slowest
+            out["reads"] = reads
+            out["reads_per_rank"] = n
+            out["wall_seconds_slowest_rank"] = slowest
+            out["per_rank"] = parts
+            t0 = time.time()
+            with open(os.path.join(d, "out_all.txt"), "wb") as fo:
+                for g in range(world):
+                    with open(os.path.join(d, "out_%d.txt" % g), "rb") as fi:
+                        shutil.copyfileobj(fi, fo, 64 << 20)
+            out["concat_seconds"] = time.time() - t0
+            out["value_with_concat"] = reads / (slowest + out["concat_seconds"])
+            out["bound"] = ("per-rank output files: each rank fills its own file; the host-side concatenation of %.2f GB into ONE file took %.2f s "
+                            "(page allocation of one file, DESIGN.md section 5b)" % (sum(p["bytes_out"] for p in parts) / 1e9, out["concat_seconds"]))
+            # the last rank's shard once more on rank 0's replica
+            code, st2 = search_gg(sdb.ctr, [tree], os.path.join(d, "reads_%d.fa" % (world - 1)), os.path.join(d, "again.txt"), rc=bool(args.rc), threads=16)
+            ulib.check(code, "utree_search_file (cross-replica check)")
+            again = hashlib.sha256(open(os.path.join(d, "again.txt"), "rb").read()).hexdigest()
+            out["cross_replica_identical"] = (again == parts[world - 1]["sha256"])
+            out["parity_ok"] = bool(out["cross_replica_identical"])
+            out["parity_sample"] = "rank %d's shard classified again on rank 0's replica of the image: identical bytes" % (world - 1)
+        except Exception as e:
+            out["error"] = repr(e)
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: this process has not imported torch or touched the GPU yet, so it starts
+    the N ranks -- one process per GPU, the same command line the driver uses -- as children, lets rank 0's JSON line through on
+    stdout and returns the launcher's exit code.  Nothing is exec'ed over a process that has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["UTREE_BENCH_SELF_LAUNCHED"] = "1"
+    print("[bench] --gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, ulib):
@@ -494,31 +636,35 @@ def e2e_leg(args, sdb, tree, files, cpu):
         L = ulib.load()
         arr = (C.c_void_p * 1)(tree._h)
         ulib.check(L.utree_search_prepare(sdb.ctr._h, arr, 1, int(bool(args.rc))), "utree_search_prepare")   # buffers: part of "resident"
-        runs = []
-        for rep, target in enumerate(("out.txt", "out2.txt", "/dev/null")):
+        runs, hashes = [], []
+        for rep, target in enumerate(("out.txt", "out2.txt", "out3.txt", "/dev/null")):
             outp = target if target.startswith("/dev/") else files.path(target)
             t0 = time.time()
             code, st = search_gg(sdb.ctr, [tree], fa, outp, rc=bool(args.rc), threads=16)
             wall = time.time() - t0
             ulib.check(code, "utree_search_file")
+            if not target.startswith("/dev/"):
+                hashes.append(hashlib.sha256(open(outp, "rb").read()).hexdigest())
+                if rep:
+                    os.unlink(outp)                         # (the first file stays for the comparison with the reference's lines)
             runs.append({"output": "discarded (/dev/null)" if target == "/dev/null" else "file in /dev/shm", "wall_seconds": wall,
                          "reads_per_second": st.n_reads / wall, "reads": int(st.n_reads), "lines": int(st.good_finds), "bytes_in": int(st.bytes_in),
                          "bytes_out": int(st.bytes_out), "pipeline": "device text" if st.pipeline else "host text", "lanes": int(st.n_lanes),
                          "lane_seconds": {"read": st.seconds_read, "h2d_frame": st.seconds_frame, "classify_format": st.seconds_classify_format,
                                           "order_and_write_turn_wait": st.seconds_order_wait, "d2h": st.seconds_d2h, "write": st.seconds_write}})
-        best = max(runs[:2], key=lambda r: r["reads_per_second"])
+        to_file = sorted(runs[:3], key=lambda r: r["reads_per_second"])
+        best = to_file[1]                                     # the median of the three runs that write the file
         out["value"] = best["reads_per_second"]
+        out["value_is"] = "median of 3 runs to a file (min %.4g, max %.4g reads/s)" % (to_file[0]["reads_per_second"], to_file[2]["reads_per_second"])
         out["runs"] = runs
-        out["value_output_discarded"] = runs[2]["reads_per_second"]
+        out["value_output_discarded"] = runs[3]["reads_per_second"]
         out["write_GBps"] = best["bytes_out"] / max(1e-9, best["lane_seconds"]["write"]) / 1e9
         out["bound"] = ("output file: %.2f GB of text into fresh page-cache pages of ONE file at %.1f GB/s (one writer; the kernel allocates "
                         "tmpfs pages at ~5-6 GB/s whatever the thread count: tools/hostio_probe*.c, profiles/r02/hostio_*.txt); with the output "
-                        "discarded the same pipeline runs at %.0f M reads/s" % (best["bytes_out"] / 1e9, out["write_GBps"], runs[2]["reads_per_second"] / 1e6))
+                        "discarded the same pipeline runs at %.0f M reads/s" % (best["bytes_out"] / 1e9, out["write_GBps"], runs[3]["reads_per_second"] / 1e6))
         # parity: (1) both runs wrote the same bytes; (2) the head of the file == the reference's lines for the cpu_baseline sample
-        h1 = hashlib.sha256(open(files.path("out.txt"), "rb").read()).hexdigest()
-        h2 = hashlib.sha256(open(files.path("out2.txt"), "rb").read()).hexdigest()
-        out["output_sha256"] = h1
-        out["runs_identical"] = (h1 == h2)
+        out["output_sha256"] = hashes[0]
+        out["runs_identical"] = (len(set(hashes)) == 1)
         nref = getattr(files, "sample_reads", 0)
         if nref and os.path.exists(files.path("ref.txt")):
             ref_lines = sorted(open(files.path("ref.txt"), "rb").read().split(b"\n"))

@@ -75,3 +75,44 @@ def test_two_rank_gloo_shard_and_concat(tmp_path):
     mp.spawn(_worker, args=(2, port, util.fixture_ctr("toy"), util.fixture_reads_path("toy"), str(tmp_path)), nprocs=2,
              join=True)
     assert (tmp_path / "out.txt").read_bytes() == util.fixture_bytes("toy_out_rc.txt.gz")
+
+
+def test_bench_gpus_flag_launches_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` outside a launcher starts N ranks itself (before anything touches the GPU) with the driver's
+    own command line; inside a launcher the flag must agree with WORLD_SIZE."""
+    import argparse
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert bench.self_launch(argparse.Namespace(gpus=4)) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_gpus_flag_cold_start_reaches_every_rank(tmp_path):
+    """The real thing from a cold start, on this GPU-less box: two ranks come up under torch.distributed.run and each one refuses
+    to run without an MI355X (there is no CPU fallback); the launcher's exit code comes back."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: the N-rank launch is exercised by bench.py itself")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "launching" in p.stderr and p.stderr.count("bench.py needs an MI355X") >= 2
+    assert p.stdout.strip() == ""
