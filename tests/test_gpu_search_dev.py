@@ -229,3 +229,43 @@ def test_replicate_rccl_over_all_visible_devices(torch_cuda, tmp_path):
                          torch.from_numpy(fr["seq_len"].astype(np.int32)).to(dev), rc=True).cpu()
         want = res if want is None else want
         assert torch.equal(res, want), "replica on device %d differs" % g
+
+
+def test_output_that_cannot_seek_is_written_in_order(torch_cuda, tmp_path, monkeypatch):
+    """`xtree-searchGG db reads.fa /dev/stdout | gzip`, a FIFO, process substitution: the reference writes with fprintf and works
+    there; the device pipeline places chunks with pwrite, so on such an output it writes them in chunk order instead."""
+    import threading
+    monkeypatch.setenv("UTREE_CHUNK_BYTES", "20000")
+    db, tree = tree_for("toy")
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    fa, fifo = tmp_path / "in.fa", tmp_path / "out.fifo"
+    fa.write_bytes(data)
+    os.mkfifo(fifo)
+    got = {}
+
+    def reader():
+        with open(fifo, "rb") as f:
+            got["bytes"] = f.read()
+    th = threading.Thread(target=reader)
+    th.start()
+    code, st = search_gg(db, [tree], str(fa), str(fifo), rc=True, threads=4)
+    th.join(60)
+    assert code == lib.OK and st.pipeline == 1 and st.n_lanes >= 2
+    assert got["bytes"] == util.fixture_bytes("toy_out_rc.txt.gz")
+
+
+def test_three_byte_records_fill_a_chunk(torch_cuda, tmp_path):
+    """A record can be ">\\n\\n" (the reference reads it as a sequence of length 0 and prints nothing): a chunk of them holds
+    more reads than bytes / 4.  Every read must be framed, and the real reads among them classified."""
+    db, tree = tree_for("toy")
+    o = orc.OracleDB.load(util.fixture_ctr("toy"))
+    real = util.fixture_bytes("toy_reads.fa.gz")[:60_000]
+    real = real[: real.rfind(b"\n>") + 1]
+    data = b">\n\n" * 150_000 + real + b">\n\n" * 70_001 + real + b">x\n\n" * 10
+    fa, want = tmp_path / "w.fa", tmp_path / "want.txt"
+    fa.write_bytes(data)
+    ocode, nr, good, err = o.search_file(str(fa), str(want), threads=4, rc=False)
+    code, st, got = run(db, [tree], data, tmp_path)
+    assert code == lib.OK and ocode == 0
+    assert got == want.read_bytes() and len(got) > 0
+    assert st.n_reads == nr == data.count(b"\n") // 2 and st.good_finds == good

@@ -594,13 +594,15 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
         HIPCHK(hipMemsetAsync(w.touch, 0, (size_t)w.long_blocks * ((d->hdr.n_labels + 31) / 32) * 4, st));
     }
     /* HIP events on the launch stream bracket the dominant kernel (bench.py's roofline leg) */
+    /* (callers on several threads share the handle -- the lanes of search_dev.c --: a call claims its pair of events with one
+     * atomic, the events exist since utree_classify_kernel_time switched the bracket on, and a pair counts only once both of its
+     * events are recorded) */
     hipEvent_t e0 = NULL, e1 = NULL;
-    if (d->timing_on && d->n_pending < UTREE_MAX_PENDING) {
-        if (d->n_events < 2 * (d->n_pending + 1)) {
-            HIPCHK(hipEventCreate((hipEvent_t *)&d->events[d->n_events])); d->n_events++;
-            HIPCHK(hipEventCreate((hipEvent_t *)&d->events[d->n_events])); d->n_events++;
-        }
-        e0 = d->events[2 * d->n_pending]; e1 = d->events[2 * d->n_pending + 1];
+    int tslot = -1;
+    if (__atomic_load_n(&d->timing_on, __ATOMIC_ACQUIRE)) {
+        tslot = __atomic_fetch_add(&d->n_claimed, 1, __ATOMIC_RELAXED);
+        if (tslot >= 0 && tslot < UTREE_MAX_PENDING && 2 * tslot + 1 < d->n_events) { e0 = d->events[2 * tslot]; e1 = d->events[2 * tslot + 1]; }
+        else tslot = -1;
     }
     /* The lane-per-read pass takes the whole batch when image and lengths allow (reads of up to 2095 bases, sixteen lanes each; what
      * it leaves over must fit the listed wave-per-read pass: 2112 staged bases); then nothing is routed. */
@@ -625,11 +627,11 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
         KCHK(utk_classify_listed(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
     } else
         KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
-    if (e0 && dominant == 0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
+    if (e0 && dominant == 0) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
     if (w.mid_reads && !lanes && !w.pieces) {
         if (e0 && dominant == 1) HIPCHK(hipEventRecord(e0, st));
         KCHK(utk_classify_mid(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
-        if (e0 && dominant == 1) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
+        if (e0 && dominant == 1) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
     }
     if (w.long_blocks) {
         if (e0) HIPCHK(hipEventRecord(e0, st));
@@ -646,7 +648,7 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
             d->last_pieces = 1;
         }
         KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &wl, d->n_cu, st));
-        if (e0) { HIPCHK(hipEventRecord(e1, st)); d->n_pending++; }
+        if (e0) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
     }
     KCHK(utk_vote(&d->kimg, d_out, &w, n_reads, st));
 #ifdef UTREE_LANES_TIMERS
@@ -707,17 +709,23 @@ int utree_classify_kernel_time(utree_dev *d, int reset, double *ms_total, uint64
     int rc = UTREE_OK;
     if (!d) return UTREE_E_ARG;
     HIPCHK(hipSetDevice(d->device));
-    for (int i = 0; i < d->n_pending; ++i) {
+    /* (called between batches: no utree_classify_batch is running on this handle) */
+    int claimed = __atomic_load_n(&d->n_claimed, __ATOMIC_RELAXED);
+    if (claimed > UTREE_MAX_PENDING) claimed = UTREE_MAX_PENDING;
+    for (int i = 0; i < claimed; ++i) {
         float ms = 0.f;
+        if (!d->recorded[i]) continue;                          /* a call that failed between its two events */
+        d->recorded[i] = 0;
         HIPCHK(hipEventSynchronize(d->events[2 * i + 1]));
         HIPCHK(hipEventElapsedTime(&ms, d->events[2 * i], d->events[2 * i + 1]));
         d->ms_total += ms; d->launches++;
     }
-    d->n_pending = 0;
+    while (d->n_events < 2 * UTREE_MAX_PENDING) { HIPCHK(hipEventCreate((hipEvent_t *)&d->events[d->n_events])); d->n_events++; }
+    __atomic_store_n(&d->n_claimed, 0, __ATOMIC_RELAXED);
     if (ms_total) *ms_total = d->ms_total;
     if (launches) *launches = d->launches;
     if (reset) { d->ms_total = 0; d->launches = 0; }
-    d->timing_on = 1;
+    __atomic_store_n(&d->timing_on, 1, __ATOMIC_RELEASE);
 fail:
     return rc;
 }

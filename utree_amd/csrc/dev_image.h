@@ -12,10 +12,11 @@ struct utree_dev {
     utree_image_header hdr;
     utk_image kimg;
     /* HIP-event timing of the dominant kernel (enabled by the first utree_classify_kernel_time call) */
-    int timing_on, n_pending, n_events, last_long;   /* last_long: the last batch's dominant kernel was classify_long_k */
+    int timing_on, n_claimed, n_events, last_long;   /* last_long: the last batch's dominant kernel was classify_long_k */
     int last_mid, last_rc, last_lanes, last_pieces; uint32_t last_short_cap;  /* ... and which wave-per-read instantiation it was otherwise        */
     char kernel_sig[160];
     void *events[2 * UTREE_MAX_PENDING];
+    unsigned char recorded[UTREE_MAX_PENDING];  /* pair i holds a complete bracket */
     double ms_total;
     uint64_t launches;
     /* rank-specific search: the reference's never-cleared hit array as later reads see it (rank.c) */

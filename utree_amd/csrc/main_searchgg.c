@@ -89,7 +89,8 @@ int main(int argc, char *argv[]) {
         if (rc) { fprintf(stderr, "ERROR: RCCL broadcast of the tree: %s\n", utree_strerror(rc)); exit(3); }
     }
 #ifndef UTREE_RANK_SPECIFIC
-    (void)utree_search_prepare(ctr, devs, n_dev, doRC);                                   /* the search's pinned / device buffers: part of "database resident" */
+    { int prc = utree_search_prepare(ctr, devs, n_dev, doRC);
+      if (prc) fprintf(stderr, "[utree_amd] warning: the search buffers could not be allocated ahead (%s); the search allocates them itself\n", utree_strerror(prc)); }                                   /* the search's pinned / device buffers: part of "database resident" */
 #endif
     puts("Tree read.");                                                                   /* itree.c:826 */
     utree_dev_info di;

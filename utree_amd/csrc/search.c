@@ -92,6 +92,7 @@ typedef struct {
     utree_search_stats st;
     double t_read, t_frame, t_gpu, t_format, t_write;
     uint32_t max_label;
+    uint64_t progress_printed;                  /* progress lines the device pipeline printed before it handed the file back */
 } pipe_t;
 
 static void set_error(pipe_t *P, int rc) {
@@ -283,7 +284,7 @@ static void *format_main(void *arg) {
 /* ---- stage 4: write -------------------------------------------------------------------------- */
 static void *writer_main(void *arg) {
     pipe_t *P = (pipe_t *)arg;
-    uint64_t next_progress = 1048576;
+    uint64_t next_progress = 1048576 * (P->progress_printed + 1);
     for (int i = 0;; ++i) {
         slot_t *s = &P->slot[i % NSLOTS];
         if (!wait_state(P, s, S_FORMATTED)) break;
@@ -336,11 +337,12 @@ static int search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const 
                        int do_rc, const utree_rank_params *rank, int host_threads, int input_format, utree_search_stats *stats) {
     if (!ctr || !devs || n_dev < 1 || !fasta_path || !out_path || input_format < 0 || input_format > UTREE_INPUT_AUTO) return UTREE_E_ARG;
     int rc = UTREE_OK;
+    uint64_t dev_printed = 0;
     /* The GG search on the reference's input format takes the device text pipeline (search_dev.c); it hands back input it
      * does not take -- malformed records, NUL bytes, lines fgets would split -- and the host framing below then reproduces
      * the reference on it case by case.  UTREE_HOST_TEXT=1 forces the host pipeline (tests, A/B). */
     if (!rank && input_format == UTREE_INPUT_REFERENCE && !getenv("UTREE_HOST_TEXT")) {
-        rc = utree_search_file_device(ctr, devs, n_dev, fasta_path, out_path, do_rc, host_threads, stats);
+        rc = utree_search_file_device(ctr, devs, n_dev, fasta_path, out_path, do_rc, host_threads, stats, &dev_printed);
         if (rc != UTREE_RETRY_HOST) return rc;
         rc = UTREE_OK;
     }
@@ -348,6 +350,7 @@ static int search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const 
     pipe_t *P = (pipe_t *)calloc(1, sizeof *P);
     if (!P) return UTREE_E_NOMEM;
     P->ctr = ctr; P->n_dev = n_dev; P->do_rc = do_rc; P->rank = rank; P->input_format = input_format;
+    P->progress_printed = dev_printed;
     P->fd = open(fasta_path, O_RDONLY);
     P->fo = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);                   /* fopen(outfile, "wb"), itree.c:834 */
     if (P->fd < 0 || P->fo < 0) {                                                 /* itree.c:835 */

@@ -99,10 +99,12 @@ void utree_search_ctx_free(void *p) {
     free(c);
 }
 
-#define HA(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); return UTREE_E_NOMEM; } } while (0)
+/* (a lane whose allocation fails half way is freed whole: the next search starts it from nothing) */
+#define HA(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); lane_free(b); return UTREE_E_NOMEM; } } while (0)
 static int lane_alloc(utree_dev *dev, lane_buf *b, int do_rc) {
     if (!b->stream) {
-        if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) return UTREE_E_HIP;
+        b->ws_rc = -1;
+        if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); b->stream = NULL; return UTREE_E_HIP; }
         HA(hipHostMalloc((void **)&b->h_in, DCHUNK_BYTES + 64, hipHostMallocDefault));
         HA(hipHostMalloc((void **)&b->h_out, DOUT_BYTES, hipHostMallocDefault));
         HA(hipHostMalloc((void **)&b->h_meta, sizeof(utk_text_meta), hipHostMallocDefault));
@@ -119,14 +121,13 @@ static int lane_alloc(utree_dev *dev, lane_buf *b, int do_rc) {
         HA(hipMalloc((void **)&b->d_res, (size_t)DMAX_READS * sizeof(utree_result)));
         HA(hipMalloc((void **)&b->d_meta, sizeof(utk_text_meta)));
         b->scan_bytes = utk_text_scan_temp_bytes(DMAX_READS);
-        if (!b->scan_bytes) return UTREE_E_HIP;
+        if (!b->scan_bytes) { lane_free(b); return UTREE_E_HIP; }
         HA(hipMalloc(&b->d_scan, b->scan_bytes));
-        b->ws_rc = -1;
     }
     if (b->ws_rc < do_rc) {                    /* the both-strands workspace also serves forward-only searches */
         if (b->d_ws) { hipFree(b->d_ws); b->d_ws = NULL; }
         b->ws_bytes = utree_classify_workspace_bytes(dev, DMAX_READS, DCHUNK_BYTES, LINELEN_MAX, do_rc);
-        if (!b->ws_bytes) return UTREE_E_ARG;
+        if (!b->ws_bytes) { lane_free(b); return UTREE_E_ARG; }
         HA(hipMalloc(&b->d_ws, b->ws_bytes));
         b->ws_rc = do_rc;
     }
@@ -142,9 +143,12 @@ static int ctx_get(const utree_ctr *ctr, utree_dev *dev, int n_lanes, struct utr
         c = (struct utree_search_ctx *)calloc(1, sizeof *c);
         if (!c) return UTREE_E_NOMEM;
         c->device = dev->device; c->n_labels = ctr->info.n_labels;
+        /* (published only when complete: a later search must not find a context without its table) */
+        if (hipMalloc((void **)&c->d_ix2rank, ((size_t)c->n_labels + 1) * 4) != hipSuccess) { (void)hipGetLastError(); free(c); return UTREE_E_NOMEM; }
+        if (hipMemcpy(c->d_ix2rank, ctr->ix2rank, (size_t)c->n_labels * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError(); hipFree(c->d_ix2rank); free(c); return UTREE_E_HIP;
+        }
         dev->search_ctx = c;
-        if (hipMalloc((void **)&c->d_ix2rank, ((size_t)c->n_labels + 1) * 4) != hipSuccess) return UTREE_E_NOMEM;
-        if (hipMemcpy(c->d_ix2rank, ctr->ix2rank, (size_t)c->n_labels * 4, hipMemcpyHostToDevice) != hipSuccess) return UTREE_E_HIP;
     }
     if (n_lanes > MAX_LANES) n_lanes = MAX_LANES;
     if (n_lanes > c->n_lanes) c->n_lanes = n_lanes;
@@ -174,6 +178,8 @@ struct dpipe {
                                                  * concurrent ones only fight over it (tmpfs, measured: 4 writers 3.0 GB/s, one 5.7 GB/s) */
     off_t next_off; uint64_t n_taken;           /* chunk dispenser                                                  */
     uint64_t published; off_t cum_out;          /* chunks whose output offset is fixed; text bytes before the next  */
+    int seq_out; uint64_t written;              /* the output cannot seek (pipe, FIFO, tty): chunks are written in order with write() */
+    uint64_t printed;                           /* progress lines already on stdout (a host re-run must not repeat them) */
     uint64_t n_reads, good, next_progress, bytes_in;
     int rc, stop;                               /* first error; UTREE_RETRY_HOST = input for the host path          */
     uint8_t tail[(64 << 10) + 8];
@@ -259,14 +265,16 @@ static void *lane_main(void *arg) {
         /* ---- newlines, framing ---- */
         LH(hipMemcpyAsync(b->d_in, b->h_in, n, hipMemcpyHostToDevice, b->stream));
         LK(utk_text_newlines(b->d_in, n, b->d_counts, b->d_nl, 2 * DMAX_READS, b->d_meta, b->stream));
-        LK(utk_text_frame(b->d_in, b->d_nl, DMAX_READS, (uint32_t)(n / 4 + 1), b->d_seq_off, b->d_seq_len, b->d_name_off, b->d_name_len,
+        /* (the smallest well-formed record is ">\n\n": three bytes -- the reference takes it as a read of length 0) */
+        const uint32_t grid_reads = n / 3 + 1 > DMAX_READS ? DMAX_READS : (uint32_t)(n / 3 + 1);
+        LK(utk_text_frame(b->d_in, b->d_nl, DMAX_READS, grid_reads, b->d_seq_off, b->d_seq_len, b->d_name_off, b->d_name_len,
                           b->d_meta, b->stream));
         LH(hipMemcpyAsync(b->h_meta, b->d_meta, sizeof(utk_text_meta), hipMemcpyDeviceToHost, b->stream));
         LH(hipStreamSynchronize(b->stream));
         double t2 = now_s();
         L->t_frame += t2 - t1;
         const utk_text_meta m1 = *b->h_meta;
-        if (m1.flags || (m1.n_lines & 1u) || m1.n_lines > 2 * DMAX_READS) { dfail(P, UTREE_RETRY_HOST); return NULL; }
+        if (m1.flags || (m1.n_lines & 1u) || m1.n_lines > 2 * DMAX_READS || m1.n_lines / 2 > grid_reads) { dfail(P, UTREE_RETRY_HOST); return NULL; }
         const uint32_t nr = m1.n_lines / 2;
         /* ---- classify (kernels.hip), then the output text ---- */
         if (nr) {
@@ -300,6 +308,7 @@ static void *lane_main(void *arg) {
         while (P->n_reads >= P->next_progress) {                                   /* itree.c:878 */
             printf("Searched %llu queries...\n", (unsigned long long)P->next_progress);
             P->next_progress += 1048576;
+            P->printed++;
         }
         P->published++;
         pthread_cond_broadcast(&P->cv);
@@ -310,14 +319,28 @@ static void *lane_main(void *arg) {
         double t5 = now_s();
         L->t_d2h += t5 - t4;
         size_t done = 0;
+        if (P->seq_out) {                                           /* wait for every earlier chunk's text to be out */
+            pthread_mutex_lock(&P->mu);
+            while (P->written != c && !P->stop) pthread_cond_wait(&P->cv, &P->mu);
+            const int stop = P->stop;
+            pthread_mutex_unlock(&P->mu);
+            if (stop) return NULL;
+        }
         pthread_mutex_lock(&P->wmu);
         double t6 = now_s();
         while (done < (size_t)m2.out_bytes) {
-            ssize_t w = pwrite(P->fo, b->h_out + done, (size_t)m2.out_bytes - done, base + (off_t)done);
+            ssize_t w = P->seq_out ? write(P->fo, b->h_out + done, (size_t)m2.out_bytes - done)
+                                   : pwrite(P->fo, b->h_out + done, (size_t)m2.out_bytes - done, base + (off_t)done);
             if (w <= 0) { pthread_mutex_unlock(&P->wmu); dfail(P, UTREE_E_IO); return NULL; }
             done += (size_t)w;
         }
         pthread_mutex_unlock(&P->wmu);
+        if (P->seq_out) {
+            pthread_mutex_lock(&P->mu);
+            P->written++;
+            pthread_cond_broadcast(&P->cv);
+            pthread_mutex_unlock(&P->mu);
+        }
         L->t_wlock += t6 - t5;
         L->t_write += now_s() - t6;
         L->chunks++;
@@ -343,8 +366,9 @@ int utree_search_prepare(const utree_ctr *ctr, utree_dev **devs, int n_dev, int 
 }
 
 int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
-                             int do_rc, int host_threads, utree_search_stats *stats) {
+                             int do_rc, int host_threads, utree_search_stats *stats, uint64_t *progress_printed) {
     const double t_start = now_s();
+    if (progress_printed) *progress_printed = 0;
     dpipe *P = (dpipe *)calloc(1, sizeof *P);
     if (!P) return UTREE_E_NOMEM;
     P->ctr = ctr; P->do_rc = do_rc; P->next_progress = 1048576;
@@ -360,6 +384,7 @@ int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, 
     if (!S_ISREG(sb.st_mode)) { close(P->fd); close(P->fo); free(P); return UTREE_RETRY_HOST; }   /* a pipe: no pread */
     P->file_size = sb.st_size;
     P->chunk_bytes = chunk_bytes();
+    P->seq_out = lseek(P->fo, 0, SEEK_CUR) == (off_t)-1;                          /* `out` is a pipe, a FIFO, a tty: no pwrite there */
     const int K = lanes_per_device(n_dev), n_lanes = K * n_dev;
     int rc = UTREE_OK;
     for (int g = 0; g < n_dev && !rc; ++g) { struct utree_search_ctx *c = NULL; rc = ctx_get(ctr, devs[g], K, &c); }
@@ -391,6 +416,7 @@ int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, 
     }
     close(P->fd);
     close(P->fo);
+    if (progress_printed) *progress_printed = P->printed;
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->n_reads = P->n_reads; stats->good_finds = P->good;
