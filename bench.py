@@ -12,8 +12,8 @@ scaling, no data-path collective); the only collective is the one-off RCCL broad
 from rank 0 before the timed region, issued from C (utree_dev_replicate_rank).  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      dominant kernel (classify_lanes_k for 150-bp-class forward batches, else classify_short_k / classify_long_k): bytes the kernel must move per launch by the byte model of the image AS
-                BUILT (distinct 64-byte buckets per read, counted on the device) / average launch duration measured with
+  roofline      dominant kernel (classify_lanes_k, or classify_short_k / classify_long_k for images it does not take): bytes the kernel must move per launch by the byte model of the image AS
+                BUILT (distinct 128-byte buckets per read, counted on the device) / average launch duration measured with
                 HIP events on the launch stream, against 8 TB/s; next to it the PMC-measured HBM fraction and the VALU / SALU
                 issue fractions from the kept profile (profiles/traffic.json) -- used only when that profile was taken from
                 exactly the kernel sources this library was built from; the SURVEY section 8(d) figure (per-window binary search,
@@ -398,9 +398,9 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
     # tally entries written for vote_k (reads with more than one distinct label), from the results of batch 0
     multi = out0[:, 3] > 1
     tally_entries = float(out0[multi, 3].sum().item()) / batch.n
-    # bytes a read must move: its bases, each distinct bucket once (+ one more 64-byte fetch where the bucket overflows into
-    # the sorted records), its 24-byte result and its (rank, count) list
-    model = L + 64.0 * (buckets + over) + 24.0 + 8.0 * tally_entries
+    # bytes a read must move: its bases, each distinct bucket -- a 128-byte line since image version 9 -- once (+ one more line
+    # where the bucket overflows into the sorted records), its 24-byte result and its (rank, count) list
+    model = L + 128.0 * (buckets + over) + 24.0 + 8.0 * tally_entries
     achieved = model * args.batch_reads / avg_launch_s / 1e9 if k_launches else None
     contract, b_win, windows = contract_bytes_per_read(args.nodes, W, 2, L)
     if args.rc:
@@ -408,7 +408,7 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
     roof = {"bound": "hbm", "kernel": kernel_sig, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
             "algorithmic_bytes_per_read": model,
-            "model": {"what": "bases + 64 B x distinct buckets (+64 B per overflowing bucket) + 24 B result + 8 B x tally entries",
+            "model": {"what": "bases + 128 B x distinct buckets (a bucket is one HBM line; +128 B per overflowing bucket) + 24 B result + 8 B x tally entries",
                       "sample_reads": mc["reads"], "windows_per_read": mc["windows"] / reads, "distinct_buckets_per_read": buckets,
                       "distinct_128B_lines_per_read": lines128, "overflow_buckets_per_read": over, "tally_entries_per_read": tally_entries,
                       "bytes_if_hbm_delivers_128B_lines": L + 128.0 * lines128 + 24.0 + 8.0 * tally_entries},
@@ -466,7 +466,7 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
                 roof["random_line_ceiling_GBs"] = RANDOM_LINE_GBS
                 roof["random_line_frac"] = e["hbm_bytes_per_launch"] / t_prof / 1e9 / RANDOM_LINE_GBS
                 if "classify_lanes_k" in kernel_sig:
-                    roof["limiter_note"] = ("lane-per-read pass: one 64-byte bucket fetch per minimizer run, each a random 128-byte HBM line; the measured "
+                    roof["limiter_note"] = ("lane-per-read pass: one bucket fetch per minimizer run, each a random 128-byte HBM line (the bucket IS the line); the measured "
                                             "traffic runs at random_line_frac of the rate at which this chip serves random lines -- DESIGN.md section 5c")
                 else:
                     roof["limiter_note"] = ("no unit is saturated: the kernel is bound by each wavefront's chain of dependent steps (LDS round trips, two bucket "

@@ -39,7 +39,8 @@ enum {
     UTREE_E_NOLABELS = 7,    /* no label text after the node dump ("No annotation found in tree file.", 776)    */
     UTREE_E_FASTA = 8,       /* malformed read: details in utree_fasta_error (872, 880, 886, 888 -> exit 2)     */
     UTREE_E_RCCL = 9,
-    UTREE_E_BUILD = 10       /* BUILD input rejected: details in utree_build_stats.error_kind                   */
+    UTREE_E_BUILD = 10,      /* BUILD input rejected: details in utree_build_stats.error_kind                   */
+    UTREE_E_DEVICE = 11      /* a batch's kernels found the workspace too small for it (utree_classify_poll)    */
 };
 
 const char *utree_strerror(int code);
@@ -149,6 +150,13 @@ size_t utree_classify_workspace_bytes(const utree_dev *dev, uint32_t n_reads, ui
 int utree_classify_batch(utree_dev *dev, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                          uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc, utree_result *d_out,
                          void *d_workspace, size_t workspace_bytes, void *stream);
+/* A batch's kernels check what the workspace's sizing rules out -- (rank, count) lists past their capacity, more long reads or
+ * pieces of long reads than the tables hold: total_bases / max_len did not describe the batch -- and report it in an error word
+ * that comes back with the batch (no kernel writes past a buffer, none drops a read silently).  Once `stream` has drained,
+ * utree_classify_poll returns UTREE_E_DEVICE if a batch finished since the last call reported something (its results are not to
+ * be used; utree_last_hip_error says what), else UTREE_OK.  utree_classify_batch also returns UTREE_E_DEVICE when an EARLIER
+ * batch's report has arrived by the time it is called.  utree_search_file polls after every chunk. */
+int utree_classify_poll(utree_dev *dev);
 /* The innermost operator alone (XT_getIX32, itree.c:720): words (hi:lo, hi = 0 for k = 32) -> stored label
  * index, 0xFFFFFFFF when absent or when the stored index is >= n_labels.  For tests and micro-benchmarks. */
 int utree_lookup_words(utree_dev *dev, const uint64_t *d_hi, const uint64_t *d_lo, uint64_t n, uint32_t *d_ix,

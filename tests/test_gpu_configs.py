@@ -93,7 +93,7 @@ def test_long_reads_with_both_strands_on_the_l4_size_database(torch_cuda):
     perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(3))      # lengths interleaved, as a file would have them
     off, ln = off[perm].contiguous(), ln[perm].contiguous()
     got = sdb.tree.classify(bases, off, ln, rc=True)
-    assert "classify_long_k" in sdb.tree.kernel_name() or sdb.tree.kernel_name().startswith("classify_lanes_k<8, 16, false, true")   # long reads: in pieces through the lane pass
+    assert "classify_long_k" in sdb.tree.kernel_name() or sdb.tree.kernel_name().startswith("classify_lanes_k<8, 2, 16, false, 2>")   # long reads: in pieces through the lane pass
     again = sdb.tree.classify(bases, off, ln, rc=True)
     assert torch.equal(got, again)
     o = oracle_of(sdb)

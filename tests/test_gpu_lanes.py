@@ -98,7 +98,7 @@ def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path
         assert got == oracle_text(o, data, tmp_path, rc=rc)
 
 
-@pytest.mark.parametrize("name,rc", [("vote", 0), ("kat", 0), ("toy", 0), ("toy", 1), ("k64", 0), ("k64", 1), ("katq", 0), ("katq2", 0)])
+@pytest.mark.parametrize("name,rc", [("vote", 0), ("kat", 0), ("toy", 0), ("toy", 1), ("k64", 0), ("k64", 1), ("katq", 0), ("katq2", 0), ("ix32", 0), ("ix32", 1)])
 def test_reference_golden_lines_through_the_lane_pass(torch_cuda, name, rc, monkeypatch):
     """The genuine reference's committed output (tests/golden) for the fixture reads this pass takes, k = 32 and 64, both strand
     modes.  toy / k64 / katq2 carry COMPRESS' first-bin quirk: one or two irregular bins, whose reads the pass leaves to the
@@ -114,7 +114,7 @@ def test_reference_golden_lines_through_the_lane_pass(torch_cuda, name, rc, monk
     want = b"".join(l + b"\n" for l in out.split(b"\n") if l and l.split(b"\t")[0] in names)
     monkeypatch.setenv("UTREE_LANE_PASS", "1")
     got = classify_fasta_bytes(db, tree, b"".join(h + b"\n" + q + b"\n" for h, q in keep), rc=bool(rc))
-    assert tree.kernel_name().startswith("classify_lanes_k<")
+    assert tree.kernel_name().startswith("classify_lanes_k<%d, %d," % (db.k // 4, db.I))     # (ix32: the u32-label instantiation)
     assert got == want and len(want) > 0
 
 
@@ -220,13 +220,21 @@ def test_hit_dense_reads_and_reads_with_more_labels_than_the_tally_table(torch_c
         assert got == oracle_text(o, data, tmp_path, rc=rc)
     mixed = fasta_bytes(cut(300) + patchwork(300))
     got = classify_fasta_bytes(db, tree, mixed, rc=False)
-    assert tree.kernel_name().startswith("classify_lanes_k<8, 16")   # 60 x 32 = 1920 bases: sixteen lanes per read
+    assert tree.kernel_name().startswith("classify_lanes_k<8, 2, 16")   # 60 x 32 = 1920 bases: sixteen lanes per read (the batch's other reads take one)
     assert got == oracle_text(o, mixed, tmp_path)
     big = fasta_bytes(patchwork(30_000))
     for _ in range(10):                                                              # > 256 Ki reads, all of them left over
         classify_fasta_bytes(db, tree, big, rc=False)
-    assert "classify_short_k" in tree.kernel_name()                                 # the pass has given up on this handle
+    assert "classify_short_k" in tree.kernel_name()                                 # the pass sits such batches out ...
     assert classify_fasta_bytes(db, tree, mixed, rc=False) == got
+    # ... but keeps probing (every eighth batch), and a batch it does well on brings it back: no latch for the handle's lifetime
+    easy = fasta_bytes(cut(4000))
+    want_easy = oracle_text(o, easy, tmp_path)
+    names = []
+    for _ in range(12):
+        assert classify_fasta_bytes(db, tree, easy, rc=False) == want_easy
+        names.append(tree.kernel_name())
+    assert any("classify_short_k" in x for x in names[:4]) and all(x.startswith("classify_lanes_k<") for x in names[-3:]), names
     tree.close()
 
 
@@ -245,3 +253,84 @@ def test_synthetic_config2_shape_lanes_equals_wave_per_read(torch_cuda, monkeypa
         assert torch.equal(a, b)
         assert int((a[:, 2] > 0).sum()) > 0.9 * 300_001
     sdb.tree.close()
+
+
+@pytest.mark.parametrize("k", [32, 64])
+def test_batch_of_mixed_lengths_is_split_by_lanes_per_read(torch_cuda, k, tmp_path, monkeypatch):
+    """One file holds any mix of lengths (itree.c:866-901).  A batch with 150 bp reads, a few hundred longer ones and some of 3-12 kb is
+    routed on the device: every read goes through the instantiation for the lanes it needs (1, 2, 4, 8, 16), the longest in pieces --
+    the 150 bp reads do not fall back to the wave-per-read kernel because a long read shares their batch."""
+    d = OwnDB(tmp_path, seed=21, k=k)
+    db = CtrDB.open(d.ctr)
+    tree = DeviceTree.upload(db, 0)
+    o = orc.OracleDB.load(d.ctr)
+    rng = np.random.default_rng(k)
+    reads = (random_reads(rng, d, 3000, 1, 160, hit_frac=0.6) + random_reads(rng, d, 300, 161, 600, hit_frac=0.7) +
+             random_reads(rng, d, 120, 601, 2095, hit_frac=0.7) + random_reads(rng, d, 24, 3000, 12000, hit_frac=0.8))
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    for sub in (reads, [r for r in reads if len(r[1]) <= 600], [r for r in reads if len(r[1]) <= 160 or len(r[1]) >= 3000]):
+        data = fasta_bytes(sub)
+        for rc in (False, True):
+            monkeypatch.setenv("UTREE_LANE_PASS", "1")
+            got = classify_fasta_bytes(db, tree, data, rc=rc)
+            assert tree.kernel_name().startswith("classify_lanes_k<")
+            monkeypatch.setenv("UTREE_LANE_PASS", "0")
+            assert got == classify_fasta_bytes(db, tree, data, rc=rc)
+            assert got == oracle_text(o, data, tmp_path, rc=rc)
+    tree.close()
+
+
+def test_long_reads_with_more_labels_than_their_tables_hold(torch_cuda, tmp_path, monkeypatch):
+    """A long read's pieces add their tallies to a 64-slot table of the read in HBM; a piece keeps 48 labels.  Reads pieced together from
+    72 contigs (72 labels) overflow one or the other: they are flagged and finished by classify_long_k, the others by finish_long_k."""
+    rng = np.random.default_rng(5)
+    ctr, contigs = genome_db(tmp_path, rng, n_contigs=72, contig=3000)
+    db = CtrDB.open(ctr)
+    tree = DeviceTree.upload(db, 0)
+    o = orc.OracleDB.load(ctr)
+
+    def patch(n_parts, part, pool):
+        s = []
+        for c in rng.permutation(pool)[:n_parts]:
+            p = int(rng.integers(0, len(contigs[c]) - part))
+            s.append(contigs[c][p:p + part])
+        return "".join(s)
+    reads = [("many%d" % i, patch(72, 140, 72)) for i in range(40)]                    # 10 080 bases, 72 labels: beyond the read's table
+    reads += [("piece%d" % i, patch(60, 40, 72) + patch(10, 500, 10)) for i in range(40)]   # 60 labels inside the first piece (2 064 windows)
+    reads += [("few%d" % i, patch(30, 300, 30)) for i in range(40)]                    # 9 000 bases, 30 labels: stays in the pass
+    reads += [("short%d" % i, patch(1, 150, 72)) for i in range(500)]
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    data = fasta_bytes(reads)
+    for rc in (False, True):
+        monkeypatch.setenv("UTREE_LANE_PASS", "1")
+        got = classify_fasta_bytes(db, tree, data, rc=rc)
+        assert tree.kernel_name().startswith("classify_lanes_k<8, 2, 16, false, 2>")
+        want = oracle_text(o, data, tmp_path, rc=rc)
+        assert got == want
+        uix = {l.split(b"\t")[0]: int(l.split(b"\t")[3]) for l in want.split(b"\n") if l}
+        assert max(v for n, v in uix.items() if n.startswith(b"many")) > 64 and min(v for n, v in uix.items() if n.startswith(b"few")) <= 48
+    tree.close()
+
+
+def test_a_workspace_too_small_is_reported_not_overrun(torch_cuda, tmp_path, monkeypatch):
+    """The kernels reserve (rank, count) list space from a cursor; the workspace's size makes an overrun impossible.  With the test
+    hook that shrinks the capacity the kernels raise the batch's error word: utree_classify_poll turns it into UTREE_E_DEVICE, nothing
+    is written past the buffer, and the next batch (hook off) is fine."""
+    import torch
+    from utree_amd import lib
+    d = OwnDB(tmp_path, seed=4)
+    db = CtrDB.open(d.ctr)
+    tree = DeviceTree.upload(db, 0)
+    o = orc.OracleDB.load(d.ctr)
+    rng = np.random.default_rng(6)
+    data = fasta_bytes(random_reads(rng, d, 100_000, 150, 150, hit_frac=0.9))
+    want = oracle_text(o, data, tmp_path)
+    for lane_pass in ("1", "0"):
+        monkeypatch.setenv("UTREE_LANE_PASS", lane_pass)
+        monkeypatch.setenv("UTREE_TEST_TALLY_CAP", "20000")
+        with pytest.raises(lib.UtreeError) as ei:
+            classify_fasta_bytes(db, tree, data)
+        assert ei.value.code == lib.E_DEVICE
+        monkeypatch.delenv("UTREE_TEST_TALLY_CAP")
+        assert classify_fasta_bytes(db, tree, data) == want
+    tree.close()

@@ -25,6 +25,7 @@ const char *utree_strerror(int code) {
         case UTREE_E_FASTA: return "malformed query file";
         case UTREE_E_RCCL: return "RCCL error";
         case UTREE_E_BUILD: return "BUILD input rejected";
+        case UTREE_E_DEVICE: return "a kernel found the batch's workspace too small";
         default: return "unknown error";
     }
 }

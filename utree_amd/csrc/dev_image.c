@@ -3,7 +3,7 @@
  * The image replaces UTree.Dump / UTree.BinIx (itree.c:140-141) as XT_getIX32 (itree.c:720) sees them.
  * Layout in HBM (one flat allocation, offsets only -- DESIGN.md §3):
  *
- *   [header 4 KiB][table over 24+F minimizer-hash bits][MIN records: nodes by (minimizer hash, position, rest)]
+ *   [header 4 KiB][table: 128-byte buckets over the minimizer hash][MIN records: nodes by (bucket, key): overflow runs]
  *   [bin table 2^24+1][irregular-bin bitmap 2 MiB][label offsets][labels in strcmp order][rank -> file index]
  *   [FILE records: nodes as the file orders them -- kept in the image only when some bin needs the exact probe path]
  */
@@ -37,24 +37,28 @@ static int timing_on(void) { return getenv("UTREE_TIMING") != NULL || getenv("UT
 
 static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
-/* Bucket widths per hash region (utree_image_header.regions) for a tree of N nodes: a node's minimizer hash is the smallest of
- * m = K-15 hashes, so with x = h / 2^32 there are about N/2^32 * m * (1-x)^(m-1) nodes per hash value.  A region takes the
- * width 2^s (s <= 8: the record key has 8 bits for the hash bits a bucket does not imply) that brings a bucket closest to
- * TARGET nodes, but not finer than 2^(8-F) (F = fine_bits: 8 = as fine as the density asks, 0 = 256 values per bucket). */
-#define UTREE_BUCKET_TARGET 2.0
-static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t F, uint64_t regions[256]) {
-    const double m = 4.0 * W - 15.0, lam0 = (double)n_nodes / 4294967296.0;
-    const uint32_t smin = F >= 8 ? 0 : 8 - F;
-    const char *te = getenv("UTREE_BUCKET_TARGET");                     /* experiments only */
-    const double target = te && atof(te) > 0 ? atof(te) : UTREE_BUCKET_TARGET;
+/* Buckets per hash region (utree_image_header.regions) for a tree of N nodes: a node's minimizer hash is the smallest of m = K-15
+ * hashes, so region r -- the hashes whose top 8 bits are r -- expects N ((1 - r/256)^m - (1 - (r+1)/256)^m) of the nodes.  The region
+ * gets as many 128-byte buckets as bring a bucket to TARGET nodes: any number (bucket = base + ((h24 * nb) >> 24)), between 2^16 -- a
+ * bucket spans at most 256 hash values: the record key has 8 bits for them -- and 2^(16+F), at most one bucket per hash value (F =
+ * fine_bits: 8 = as many as the density asks, 0 = 256 values per bucket everywhere).  The default TARGET fills a bucket to 53 %:
+ * config 2 (k = 32, 16 entries per bucket): 8.5 nodes, image 17 GiB, 0.1 overflowing buckets per 150 bp read. */
+#define UTREE_BUCKET_FILL 0.53
+static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32_t F, uint64_t regions[256]) {
+    const double m = 4.0 * W - 15.0;
+    const uint32_t cap_entries = 16u / utree_rec_words(W, I);
+    const char *te = getenv("UTREE_BUCKET_TARGET");                     /* nodes per bucket; experiments only */
+    const double target = te && atof(te) > 0 ? atof(te) : UTREE_BUCKET_FILL * cap_entries;
+    const uint64_t nb_max = 1ull << (16 + (F > 8 ? 8 : F)), nb_min = 1ull << 16;
     uint64_t base = 0;
     for (int r = 0; r < 256; ++r) {
-        const double x = (r + 0.5) / 256.0, dens = lam0 * m * pow(1.0 - x, m - 1.0);
-        uint32_t s = 0;
-        while (s < 8 && dens * (double)(2u << s) <= target * 1.5) ++s;     /* doubling the width still leaves <= 1.5 x TARGET */
-        if (s < smin) s = smin;
-        if (regions) regions[r] = (base << 8) | s;
-        base += 1ull << (24 - s);
+        const double expect = (double)n_nodes * (pow(1.0 - r / 256.0, m) - pow(1.0 - (r + 1) / 256.0, m));
+        double want = ceil(expect / target);
+        uint64_t nb = want >= (double)nb_max ? nb_max : (uint64_t)want;
+        if (nb < nb_min) nb = nb_min;
+        if (nb > nb_max) nb = nb_max;
+        if (regions) regions[r] = (base << UTREE_REGION_NB_BITS) | nb;
+        base += nb;
     }
     return base;
 }
@@ -67,7 +71,7 @@ int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
         const char *cap_env = getenv("UTREE_TABLE_MAX_GB");
         double cap = (cap_env && atof(cap_env) > 0 ? atof(cap_env) : 48.0) * 1073741824.0;
         int F = 8;
-        while (F > 0 && (double)compute_regions(ctr->info.n_nodes, ctr->info.W, (uint32_t)F, NULL) * 64.0 > cap) --F;
+        while (F > 0 && (double)compute_regions(ctr->info.n_nodes, ctr->info.W, ctr->info.I, (uint32_t)F, NULL) * 128.0 > cap) --F;
         return F;
     }
     if (fine_bits < 0) fine_bits = 0;
@@ -77,15 +81,15 @@ int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
 
 static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     memset(h, 0, sizeof *h);
-    h->magic = UTREE_IMG_MAGIC; h->version = 8;   /* 6: k = 32 / u16-label records keep the rest in their low word (scan_bucket82); 7: the MIN area keeps the overflow runs only; 8: four-instruction minimizer hash */
+    h->magic = UTREE_IMG_MAGIC; h->version = UTREE_IMG_VERSION;   /* 6: k = 32 / u16-label records keep the rest in their low word (scan_bucket82); 7: the MIN area keeps the overflow runs only; 8: four-instruction minimizer hash; 9: 128-byte buckets, any number per region */
     h->W = ctr->info.W; h->I = ctr->info.I; h->k = ctr->info.k;
     h->fine_bits = F; h->rec_words = utree_rec_words(h->W, h->I);
     h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
     /* UTREE_FORCE_OFF64: test hook that runs the 64-bit-offset instantiations (N >= 2^32-1 databases) on small files */
     h->flags = (ctr->info.binix_width == 8 || getenv("UTREE_FORCE_OFF64")) ? UTREE_F_OFF64 : 0;
-    h->n_slots = compute_regions(h->n_nodes, h->W, F, h->regions);
+    h->n_slots = compute_regions(h->n_nodes, h->W, h->I, F, h->regions);
     uint64_t off = UTREE_IMG_HEADER_BYTES;
-    h->off_table = off; off = align_up(off + h->n_slots * 64, 4096);
+    h->off_table = off; off = align_up(off + h->n_slots * 128, 4096);
     h->off_mrecs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 4096);
     h->off_coarse = off; off = align_up(off + (uint64_t)UTREE_NUMBINS * ((h->flags & UTREE_F_OFF64) ? 8 : 4), 256);
     h->off_irreg = off; off = align_up(off + (1u << 24) / 8, 256);
@@ -185,7 +189,7 @@ static int build_begin(builder *b, const utree_ctr *ctr, int device, int fine_bi
     lanes_ring_init(d);
     layout(ctr, (uint32_t)utree_pick_fine_bits(ctr, fine_bits), &d->hdr);
     if (d_image) {
-        if (image_bytes < d->hdr.total_bytes) { rc = UTREE_E_ARG; goto fail; }
+        if (image_bytes < d->hdr.total_bytes || ((uintptr_t)d_image & 127u)) { rc = UTREE_E_ARG; goto fail; }   /* buckets are 128-byte lines */
         d->image = d_image; d->owns = 0;
     } else {
         HIPCHK(hipMalloc(&d->image, d->hdr.total_bytes));
@@ -278,7 +282,7 @@ static int build_finish(builder *b, const void *d_binix_raw) {
         HIPCHK(hipMemsetAsync(b->d_counters, 0, 16, st));
         HIPCHK(hipMemcpyAsync(img, &d->hdr, sizeof d->hdr, hipMemcpyHostToDevice, st));   /* the kernels read the region table there */
         KCHK(utk_build_min(d->hdr.W, d->hdr.I, off64, coarse, recs, c0, d->hdr.n_min, (const uint64_t *)(img + offsetof(utree_image_header, regions)),
-                           d->hdr.n_slots, (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs),
+                           d->hdr.regions, d->hdr.n_slots, (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs),
                            (uint32_t *)(img + d->hdr.off_irreg), b->d_counters, st));
         KCHK(utk_fill_recs_pad((uint64_t *)(img + d->hdr.off_mrecs) + d->hdr.n_min * d->hdr.rec_words, 8 * d->hdr.rec_words, st));
         HIPCHK(hipMemcpyAsync(counters, b->d_counters, 16, hipMemcpyDeviceToHost, st));
@@ -433,7 +437,7 @@ int utree_dev_image(const utree_dev *dev, void **d_image, size_t *bytes) {
 
 int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t bytes, utree_dev **out) {
     int rc = UTREE_OK, n_cu = 0;
-    if (!d_image || !out || bytes < UTREE_IMG_HEADER_BYTES) return UTREE_E_ARG;
+    if (!d_image || !out || bytes < UTREE_IMG_HEADER_BYTES || ((uintptr_t)d_image & 127u)) return UTREE_E_ARG;   /* buckets are 128-byte lines */
     *out = NULL;
     if ((rc = device_ok(device, &n_cu))) return rc;
     utree_dev *d = (utree_dev *)calloc(1, sizeof *d);
@@ -441,7 +445,7 @@ int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t byt
     d->device = device; d->n_cu = n_cu; d->image = d_image; d->owns = 0;
     lanes_ring_init(d);
     HIPCHK(hipMemcpy(&d->hdr, d_image, sizeof d->hdr, hipMemcpyDeviceToHost));
-    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != 8 || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
+    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != UTREE_IMG_VERSION || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
     if (ctr && (ctr->info.W != d->hdr.W || ctr->info.I != d->hdr.I || ctr->info.n_nodes != d->hdr.n_nodes ||
                 ctr->info.n_labels != d->hdr.n_labels)) { rc = UTREE_E_ARG; goto fail; }
     d->image_bytes = d->hdr.total_bytes;
@@ -456,8 +460,8 @@ fail:
 
 static void lanes_ring_init(utree_dev *d) {
     void *p = NULL;
-    if (hipSetDevice(d->device) == hipSuccess && hipHostMalloc(&p, 64 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) {
-        memset(p, 0xFF, 64 * sizeof(unsigned long long));
+    if (hipSetDevice(d->device) == hipSuccess && hipHostMalloc(&p, 128 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess) {
+        memset(p, 0xFF, 128 * sizeof(unsigned long long));
         d->lanes_ring = (volatile unsigned long long *)p;
     }
 }
@@ -501,20 +505,85 @@ static uint32_t mid_limit(void) {
 /* UTREE_LANE_PASS=0 keeps every batch on the wave-per-read kernels (comparison runs) */
 static int lanes_enabled(void) { const char *e = getenv("UTREE_LANE_PASS"); return !(e && e[0] == '0'); }
 
-/* What the lane-per-read pass left to the wave-per-read kernel in earlier batches, as far as the counts have arrived: with more
- * than a quarter of at least 256 Ki reads left, the pass is a loss for this database (hit-dense reads: more hits per read than it
- * keeps) and stays off for the handle's lifetime.  Callers on several threads share the handle: atomics only. */
-static void lanes_ring_collect(utree_dev *d) {
-    if (!d->lanes_ring || d->lanes_off) return;
+static void ring_lock(utree_dev *d) { while (__atomic_test_and_set(&d->ring_busy, __ATOMIC_ACQUIRE)) ; }
+static void ring_unlock(utree_dev *d) { __atomic_clear(&d->ring_busy, __ATOMIC_RELEASE); }
+
+/* Two words come back from every batch without a wait (a ring of pinned slots; ~0 = not arrived or consumed): the reads the lane-per-read
+ * pass left to the wave-per-read kernel, and the batch's error word.
+ *  - The left-over counts of the last UTREE_LANES_WINDOW lane-pass batches decide whether the pass is worth running: with more than a
+ *    quarter of at least 256 Ki reads left over (reads with more distinct labels than a lane's tally table holds, say) the next batches
+ *    go to the wave-per-read kernels alone -- except every eighth, which keeps the window current, so the pass comes back when the
+ *    input changes.  (Round 2 latched this for the handle's lifetime.)
+ *  - A non-zero error word is kept until utree_classify_poll hands it out.
+ * Callers on several threads share the handle (the lanes of search_dev.c): everything here happens under the ring's lock. */
+static void ring_collect(utree_dev *d) {
+    if (!d->lanes_ring) return;
+    ring_lock(d);
     for (unsigned i = 0; i < 64; ++i) {
-        unsigned long long v = d->lanes_ring[i];
-        if (v == ~0ull) continue;
-        if (!__atomic_compare_exchange_n((unsigned long long *)&d->lanes_ring[i], &v, ~0ull, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) continue;
-        __atomic_add_fetch(&d->lanes_left, v, __ATOMIC_RELAXED);
-        __atomic_add_fetch(&d->lanes_reads, (unsigned long long)d->lanes_ring_reads[i], __ATOMIC_RELAXED);
+        const unsigned long long left = d->lanes_ring[2 * i], err = d->lanes_ring[2 * i + 1];
+        if (left == ~0ull || err == ~0ull) continue;
+        d->lanes_ring[2 * i] = ~0ull; d->lanes_ring[2 * i + 1] = ~0ull;
+        d->ring_inflight[i] = 0;
+        if (err && !d->dev_error) d->dev_error = err;
+        if (d->lanes_ring_reads[i]) {
+            /* (a batch the pass did well on ends a bad spell at once: the window starts again with it) */
+            if (left * 4 <= d->lanes_ring_reads[i]) { unsigned long long n = 0, l = 0; for (unsigned w = 0; w < UTREE_LANES_WINDOW; ++w) { n += d->win_reads[w]; l += d->win_left[w]; }
+                if (n >= (1u << 18) && l * 4 > n) { memset(d->win_left, 0, sizeof d->win_left); memset(d->win_reads, 0, sizeof d->win_reads); } }
+            const unsigned w = d->win_next++ % UTREE_LANES_WINDOW;
+            d->win_left[w] = left; d->win_reads[w] = d->lanes_ring_reads[i];
+        }
+        d->lanes_ring_reads[i] = 0;
     }
-    const unsigned long long n = __atomic_load_n(&d->lanes_reads, __ATOMIC_RELAXED), l = __atomic_load_n(&d->lanes_left, __ATOMIC_RELAXED);
-    if (n >= (1u << 18) && l * 4 > n) d->lanes_off = 1;
+    ring_unlock(d);
+}
+/* run the lane-per-read pass on this batch? */
+static int lanes_worth(utree_dev *d) {
+    unsigned long long n = 0, l = 0;
+    ring_lock(d);
+    for (unsigned w = 0; w < UTREE_LANES_WINDOW; ++w) { n += d->win_reads[w]; l += d->win_left[w]; }
+    int go = !(n >= (1u << 18) && l * 4 > n);
+    if (!go && (++d->lanes_skipped & 7u) == 0) go = 1;                      /* a probe */
+    ring_unlock(d);
+    return go;
+}
+/* the batch's two words into the next free ring slot (on the batch's stream, behind its kernels) */
+static int ring_post(utree_dev *d, const utk_workspace *w, uint32_t lane_reads, hipStream_t st) {
+    if (!d->lanes_ring) return 0;
+    ring_lock(d);
+    unsigned slot = 64;
+    for (unsigned k = 0; k < 64; ++k) {
+        const unsigned c = (d->lanes_ring_next + k) & 63u;
+        if (!d->ring_inflight[c]) { slot = c; break; }
+    }
+    /* (all 64 slots wait for their copies: more than 64 batches in flight on one handle -- this batch goes unreported) */
+    if (slot < 64) { d->lanes_ring_next = slot + 1; d->ring_inflight[slot] = 1; d->lanes_ring_reads[slot] = lane_reads; }
+    ring_unlock(d);
+    if (slot == 64) return 0;
+    return hipMemcpyAsync((void *)&d->lanes_ring[2 * slot], w->cursors + UTREE_CUR_MID, 16, hipMemcpyDeviceToHost, st) != hipSuccess;
+}
+
+int utree_classify_poll(utree_dev *d) {
+    if (!d) return UTREE_E_ARG;
+    ring_collect(d);
+    ring_lock(d);
+    const unsigned long long e = d->dev_error;
+    d->dev_error = 0;
+    ring_unlock(d);
+    if (e) {
+        snprintf(g_hip_msg, sizeof g_hip_msg, "a batch's kernels reported error %llu (%s)", e,
+                 e == UTREE_DEVERR_TALLY_CAP ? "tally lists beyond the workspace: total_bases / max_len did not describe the batch" :
+                 e == UTREE_DEVERR_LONG_CAP ? "more long reads than the workspace holds" :
+                 e == UTREE_DEVERR_PIECES_CAP ? "more pieces of long reads than the workspace holds" : "unknown");
+        return UTREE_E_DEVICE;
+    }
+    return UTREE_OK;
+}
+
+/* reads of at least this many bases are "long" for the lane-per-read pass: beyond sixteen lanes, or -- with both strands -- beyond
+ * what the wave-per-read pass that finishes its left-overs stages */
+static uint32_t lanes_long_min(const utree_dev *d, int do_rc) {
+    const uint32_t a = utk_lanes_max_len(&d->kimg), b = do_rc ? (UTREE_MID_CAP - 1u) / 2u : UTREE_MID_CAP;
+    return (a < b ? a : b) + 1u;
 }
 
 static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total_bases, uint32_t max_len, int do_rc,
@@ -526,13 +595,16 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
      * refill abandons fewer than UTREE_TALLY_CHUNK / 16 entries of the old chunk (longer lists reserve exactly their length), i.e.
      * less than 1/15 of what it used, and every wave may leave ONE chunk part-used -- the resident waves of the 150-bp-class pass
      * (8 per SIMD: 32 per CU) and, in a batch that has mid-length reads, those of the mid pass (5 workgroups of 4 per CU) on top:
-     * both passes draw from the same cursor.  The kernels do not check the cursor; this bound is what makes that safe. */
-    const uint64_t max_total_ = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
-    /* (a batch of the lane-per-read pass runs fewer waves of its own, but leaves reads to a listed pass: both terms, always) */
-    const uint64_t waves_per_cu = 32 + 20;
-    (void)max_total_;
+     * both passes draw from the same cursor.  A kernel that would pass the bound raises the batch's error word (UTREE_DEVERR_TALLY_CAP)
+     * instead of writing there.  UTREE_TEST_TALLY_CAP: test hook, a capacity too small on purpose. */
+    /* (a batch of the lane-per-read pass runs fewer waves of its own, but leaves reads to a listed pass: both terms, always; a mixed
+     * batch runs up to five class launches one after the other, each leaving its waves' chunks part-used) */
+    const uint64_t waves_per_cu = 32 + 20 + 5 * 12;
     w->tally_cap = ((do_rc ? 2 : 1) * total_bases + (uint64_t)n_reads) * 9 / 8 + (uint64_t)d->n_cu * waves_per_cu * UTREE_TALLY_CHUNK + 4096;
-    w->tally = (uint64_t *)(b + off); off = align_up(off + w->tally_cap * 8, 256);
+    { const char *e = getenv("UTREE_TEST_TALLY_CAP"); if (e && atoll(e) > 0 && (uint64_t)atoll(e) < w->tally_cap) w->tally_cap = (uint64_t)atoll(e); }
+    /* (a kernel that finds the capacity exceeded writes its list at the start of the area instead: room for the longest single list) */
+    { uint64_t room = w->tally_cap; if (room < UTREE_TALLY_CHUNK) room = UTREE_TALLY_CHUNK; if (room < d->hdr.n_labels) room = d->hdr.n_labels;
+      w->tally = (uint64_t *)(b + off); off = align_up(off + room * 8, 256); }
     w->long_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
     w->mid_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)n_reads * 4, 256);
     uint64_t max_total = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
@@ -541,23 +613,29 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
     w->short_cap = max_total > UTREE_SHORT_CAP ? UTREE_SHORT2_CAP : UTREE_SHORT_CAP;
     w->mid_reads = max_total > w->short_cap;
     w->mid_limit = mid_limit();
-    if (max_total > w->mid_limit) {
+    const int lanes_img = lanes_enabled() && utk_lanes_image_ok(&d->kimg);
+    if (max_total > w->mid_limit || (lanes_img && max_len > utk_lanes_max_len(&d->kimg))) {
         w->long_blocks = (uint32_t)d->n_cu * LONG_BLOCKS_PER_CU;
         if (w->long_blocks > n_reads) w->long_blocks = n_reads;
         w->hist = (uint32_t *)(b + off); off = align_up(off + (uint64_t)w->long_blocks * d->hdr.n_labels * 4, 256);
         w->touch = (uint32_t *)(b + off); off = align_up(off + (uint64_t)w->long_blocks * ((d->hdr.n_labels + 31) / 32) * 4, 256);
     }
-    /* long reads in pieces through the lane-per-read pass: a tally table per read that can be long, the list of pieces */
+    /* the lane-per-read pass on a batch of mixed lengths: the reads listed by the lanes they need; long reads in pieces: a tally table
+     * per read that can be long, the list of pieces.  (Carved whenever the image takes that pass: whether a batch uses it is decided
+     * per batch, the workspace's size must not depend on that.) */
     w->pieces = NULL; w->ltab_rank = w->ltab_cnt = w->lflag = w->long_left = NULL; w->n_long_cap = 0; w->ltally_base = 0;
-    if (w->long_blocks && lanes_enabled() && !d->lanes_off && utk_lanes_image_ok(&d->kimg)) {
-        /* ... and with them the mid-length ones: route_k lists everything beyond the 150-bp-class kernel's size as long */
-        w->mid_limit = w->short_cap;
-        const uint64_t staged = (do_rc ? 2 : 1) * total_bases + n_reads;
-        uint64_t cap = staged / ((uint64_t)w->mid_limit + 1) + 1;
+    w->cls_list = NULL; w->cls_stride = 0; w->n_pieces_cap = 0;
+    if (lanes_img && max_len > UTREE_LANES_CAP) {
+        w->cls_stride = (n_reads + 63u) & ~63u;
+        w->cls_list = (uint32_t *)(b + off); off = align_up(off + (uint64_t)5 * w->cls_stride * 4, 256);
+    }
+    if (lanes_img && w->long_blocks) {
+        uint64_t cap = total_bases / lanes_long_min(d, do_rc) + 1;
         if (cap > n_reads) cap = n_reads;
         const uint64_t piece_windows = 16ull * (UTREE_LANES_CAP - 4 * d->hdr.W + 1);
         const uint64_t n_pieces = total_bases / piece_windows + cap + 1;
         w->n_long_cap = (uint32_t)cap;
+        w->n_pieces_cap = n_pieces;
         w->pieces = (uint64_t *)(b + off); off = align_up(off + n_pieces * 8, 256);
         w->ltab_rank = (uint32_t *)(b + off); off = align_up(off + cap * UTREE_LONG_SLOTS * 4, 256);
         w->ltab_cnt = (uint32_t *)(b + off); off = align_up(off + cap * UTREE_LONG_SLOTS * 4, 256);
@@ -604,53 +682,62 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
         if (tslot >= 0 && tslot < UTREE_MAX_PENDING && 2 * tslot + 1 < d->n_events) { e0 = d->events[2 * tslot]; e1 = d->events[2 * tslot + 1]; }
         else tslot = -1;
     }
-    /* The lane-per-read pass takes the whole batch when image and lengths allow (reads of up to 2095 bases, sixteen lanes each; what
-     * it leaves over must fit the listed wave-per-read pass: 2112 staged bases); then nothing is routed. */
-    lanes_ring_collect(d);
-    const uint64_t staged_max = do_rc ? 2 * (uint64_t)max_len + 1 : max_len;
-    const int lanes = lanes_enabled() && !d->lanes_off && !w.long_blocks && staged_max <= UTREE_MID_CAP && utk_lanes_ok(&d->kimg, max_len, do_rc);
-    /* the bracket goes around the batch's dominant kernel: the long-read kernel when the batch has long reads,
-     * else the mid-length pass when it has mid-length reads, else the 150-bp-class kernel */
-    const int dominant = lanes ? 0 : (w.long_blocks ? 2 : (w.mid_reads ? 1 : 0));
-    d->last_long = dominant == 2; d->last_mid = dominant == 1; d->last_rc = do_rc; d->last_short_cap = w.short_cap;
-    if (w.mid_reads && !lanes) KCHK(utk_route(d_len, n_reads, do_rc, &w, st));
-    if (e0 && dominant == 0) HIPCHK(hipEventRecord(e0, st));
-    d->last_lanes = lanes ? utk_lanes_segs(&d->kimg, max_len) : 0;          /* 0, or the lanes per read */
+    ring_collect(d);
+    const int lanes = lanes_enabled() && utk_lanes_image_ok(&d->kimg) && lanes_worth(d);
     if (lanes) {
-        /* one lane per read; the reads it leaves (several bad bases, more hits than it keeps) are listed for the wave-per-read kernel */
-        KCHK(utk_classify_lanes(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
-        if (d->lanes_ring) {
-            const unsigned slot = __atomic_fetch_add(&d->lanes_ring_next, 1u, __ATOMIC_RELAXED) & 63u;
-            d->lanes_ring[slot] = ~0ull; d->lanes_ring_reads[slot] = n_reads;
-            HIPCHK(hipMemcpyAsync((void *)&d->lanes_ring[slot], w.cursors + UTREE_CUR_MID, 8, hipMemcpyDeviceToHost, st));
-        }
-        KCHK(utk_classify_listed(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
-    } else
-        KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
-    if (e0 && dominant == 0) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
-    if (w.mid_reads && !lanes && !w.pieces) {
-        if (e0 && dominant == 1) HIPCHK(hipEventRecord(e0, st));
-        KCHK(utk_classify_mid(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
-        if (e0 && dominant == 1) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
-    }
-    if (w.long_blocks) {
-        if (e0) HIPCHK(hipEventRecord(e0, st));
-        utk_workspace wl = w;
-        d->last_pieces = 0;
-        if (w.pieces) {
-            /* the long reads in pieces of sixteen lanes through the lane-per-read pass; classify_long_k takes what that leaves */
+        /* ---- the lane-per-read pass: a batch of reads of up to 160 bases goes through whole with one lane per read; any other batch is
+         * split by the lanes a read needs (one launch per size), its long reads -- beyond sixteen lanes -- go through in pieces, and
+         * classify_long_k finishes the few the pieces pass gives up on.  What the pass leaves (several bad bases, more labels than a
+         * read's table holds) is on mid_list for the wave-per-read kernel. ---- */
+        const int mixed = max_len > UTREE_LANES_CAP;
+        d->last_long = w.long_blocks != 0; d->last_mid = 0; d->last_rc = do_rc; d->last_short_cap = w.short_cap;
+        d->last_lanes = utk_lanes_segs(&d->kimg, max_len); d->last_mixed = mixed; d->last_pieces = w.long_blocks != 0;
+        if (e0 && !w.long_blocks) HIPCHK(hipEventRecord(e0, st));
+        if (!mixed) KCHK(utk_classify_lanes(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
+        else KCHK(utk_classify_lanes_mixed(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
+        if (e0 && !w.long_blocks) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
+        if (w.long_blocks) {
+            if (e0) HIPCHK(hipEventRecord(e0, st));
             HIPCHK(hipMemsetAsync(w.ltab_rank, 0xFF, (size_t)w.n_long_cap * UTREE_LONG_SLOTS * 4, st));
             HIPCHK(hipMemsetAsync(w.ltab_cnt, 0, (size_t)w.n_long_cap * UTREE_LONG_SLOTS * 4, st));
             HIPCHK(hipMemsetAsync(w.lflag, 0, (size_t)w.n_long_cap * 4, st));
             KCHK(utk_classify_long_pieces(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &w, d->n_cu, st));
+            utk_workspace wl = w;
             wl.long_list = w.long_left;
             wl.long_blocks = w.long_blocks >= 8 ? w.long_blocks / 8 : 1;     /* few reads are left: a grid that finds that out quickly */
-            d->last_pieces = 1;
+            KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &wl, d->n_cu, st));
+            if (e0) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
         }
-        KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &wl, d->n_cu, st));
-        if (e0) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
+        KCHK(utk_classify_listed(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
+    } else {
+        /* ---- the wave-per-read kernels: images the lane-per-read pass does not take (k = 64 with u32 labels, many irregular bins, a
+         * non-monotone bin table), and batches it is not worth running on ---- */
+        /* the bracket goes around the batch's dominant kernel: the long-read kernel when the batch has long reads,
+         * else the mid-length pass when it has mid-length reads, else the 150-bp-class kernel */
+        const int dominant = w.long_blocks ? 2 : (w.mid_reads ? 1 : 0);
+        d->last_long = dominant == 2; d->last_mid = dominant == 1; d->last_rc = do_rc; d->last_short_cap = w.short_cap;
+        d->last_lanes = 0; d->last_mixed = 0; d->last_pieces = 0;
+        if (w.mid_reads) KCHK(utk_route(d_len, n_reads, do_rc, &w, st));
+        if (e0 && dominant == 0) HIPCHK(hipEventRecord(e0, st));
+        KCHK(utk_classify_short(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
+        if (e0 && dominant == 0) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
+        if (w.mid_reads) {
+            if (e0 && dominant == 1) HIPCHK(hipEventRecord(e0, st));
+            KCHK(utk_classify_mid(&d->kimg, d_bases, d_off, d_len, n_reads, do_rc, d_out, &w, d->n_cu, st));
+            if (e0 && dominant == 1) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
+        }
+        if (w.long_blocks) {
+            if (e0) HIPCHK(hipEventRecord(e0, st));
+            KCHK(utk_classify_long(&d->kimg, d_bases, d_off, d_len, do_rc, d_out, &w, d->n_cu, st));
+            if (e0) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
+        }
     }
     KCHK(utk_vote(&d->kimg, d_out, &w, n_reads, st));
+    /* the reads the lane pass left, and the batch's error word, come back behind the kernels without a wait */
+    if (ring_post(d, &w, lanes ? n_reads : 0, st)) { (void)hipGetLastError(); }
+    /* an earlier batch's error that has arrived meanwhile is this call's to report too (utree_classify_poll after the stream has
+     * drained reports this batch's own) */
+    { ring_lock(d); const unsigned long long pe = d->dev_error; ring_unlock(d); if (pe) rc = UTREE_E_DEVICE; }
 #ifdef UTREE_LANES_TIMERS
     { extern void utk_lanes_phase_dump(void); static int lcalls; if (++lcalls == 6) utk_lanes_phase_dump(); }
 #endif
@@ -674,12 +761,13 @@ fail:
 const char *utree_classify_kernel_name(const utree_dev *dc) {
     if (!dc) return "";
     utree_dev *d = (utree_dev *)dc;                       /* the signature string lives in the handle */
-    if (d->last_long && d->last_pieces) {
-        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, 16, %s, true>", d->hdr.W, d->kimg.irr_n ? "true" : "false");
+    if (d->last_lanes && d->last_pieces) {
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, 16, %s, 2>", d->hdr.W, d->hdr.I, d->kimg.irr_n ? "true" : "false");
         return d->kernel_sig;
     }
-    if (d->last_lanes && !d->last_long && !d->last_mid) {
-        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %d, %s, false>", d->hdr.W, d->last_lanes, d->kimg.irr_n ? "true" : "false");
+    if (d->last_lanes) {      /* (a mixed batch: the instantiation its longest read takes) */
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, %d, %s, %d>", d->hdr.W, d->hdr.I, d->last_lanes, d->kimg.irr_n ? "true" : "false",
+                 d->last_mixed ? 1 : 0);
         return d->kernel_sig;
     }
     return d->last_long ? utk_classify_long_name(&d->kimg, d->kernel_sig, sizeof d->kernel_sig)

@@ -4,6 +4,7 @@
 #include "utree_internal.h"
 
 #define UTREE_MAX_PENDING 256
+#define UTREE_LANES_WINDOW 16
 
 struct utree_dev {
     int device, n_cu, owns;
@@ -13,7 +14,7 @@ struct utree_dev {
     utk_image kimg;
     /* HIP-event timing of the dominant kernel (enabled by the first utree_classify_kernel_time call) */
     int timing_on, n_claimed, n_events, last_long;   /* last_long: the last batch's dominant kernel was classify_long_k */
-    int last_mid, last_rc, last_lanes, last_pieces; uint32_t last_short_cap;  /* ... and which wave-per-read instantiation it was otherwise        */
+    int last_mid, last_rc, last_lanes, last_pieces, last_mixed; uint32_t last_short_cap;  /* ... and which wave-per-read instantiation it was otherwise        */
     char kernel_sig[160];
     void *events[2 * UTREE_MAX_PENDING];
     unsigned char recorded[UTREE_MAX_PENDING];  /* pair i holds a complete bracket */
@@ -24,11 +25,14 @@ struct utree_dev {
     uint64_t rank_state_cap;
     /* lane-per-read pass: reads it left to the wave-per-read kernel, read back without a wait (a ring of pinned words; ~0 =
      * not arrived or consumed), summed here; a database whose reads mostly exceed what that pass keeps (hit-dense) turns it off */
-    volatile unsigned long long *lanes_ring;
-    uint32_t lanes_ring_reads[64];
+    volatile unsigned long long *lanes_ring;     /* [64][2]: {reads left over, error word} of a batch */
+    uint32_t lanes_ring_reads[64];               /* reads of the batch whose words slot i awaits (0: not a lane-pass batch) */
+    unsigned char ring_inflight[64];             /* 0 free, 1 a copy was posted into the slot */
     unsigned lanes_ring_next;
-    unsigned long long lanes_reads, lanes_left;
-    int lanes_off;
+    unsigned long long win_left[UTREE_LANES_WINDOW], win_reads[UTREE_LANES_WINDOW];   /* the last lane-pass batches */
+    unsigned win_next, lanes_skipped;
+    unsigned long long dev_error;                /* first error word that came back and was not polled yet */
+    char ring_busy;                              /* spin lock of everything above */
     /* whole-file search: per-lane pinned / device buffers, kept between searches (search_dev.c) */
     void *search_ctx;
 };

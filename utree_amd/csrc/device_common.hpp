@@ -20,9 +20,13 @@ namespace utk {
 constexpr uint64_t M40 = (1ull << 40) - 1;
 constexpr uint32_t INVALID = 0xFFFFFFFFu;
 
+// A bucket of the table is one 128-byte HBM line (image version 9: a lookup moves a whole line whatever it reads of it).
+constexpr uint32_t BUCKET_WORDS = 16, BUCKET_BYTES = 8 * BUCKET_WORDS;
 template <int W, int I> struct RecTraits {
     static constexpr int EW = (W == 16 ? 2 : 1) * (I == 4 ? 2 : 1);   // 8-byte words per record / table slot
     static constexpr int KW = (W == 16 ? 1 : 0);                       // word holding the top key bits, flag, rank16
+    static constexpr int CAP = (int)BUCKET_WORDS / EW;                 // entries of a bucket: 16 (k = 32, u16 labels), 8, 8, 4
+    static constexpr int HCAP = CAP / 2;                               // ... of one 64-byte half (what the wave-per-read kernels load at a time)
 };
 template <int W, int I> struct Entry { uint64_t w[RecTraits<W, I>::EW]; };
 
@@ -184,12 +188,16 @@ template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_
     min_rest<W>(khi, klo, pos, rest_hi32, rest_lo);
 }
 
-// Bucket of a minimizer hash and the hash bits the bucket does not imply (utree_image_header.regions).
-__device__ __forceinline__ void bucket_of(const uint64_t *__restrict__ regions, uint32_t h, uint64_t &bucket, uint32_t &hlow) {
+// Bucket of a minimizer hash and the hash bits the bucket does not imply (utree_image_header.regions): region r = the hash's top 8
+// bits has nb_r buckets (any number from 2^16 to 2^24) over its 2^24 hash values, bucket = base_r + ((h24 * nb_r) >> 24) -- one
+// multiply-high of (h << 8) --, so that a bucket spans at most 256 consecutive hash values and the hash's low 8 bits tell them apart.
+__host__ __device__ __forceinline__ uint32_t bucket_in_region(uint32_t h, uint32_t nb) {
+    return (uint32_t)(((uint64_t)(h << 8) * nb) >> 32);
+}
+__host__ __device__ __forceinline__ void bucket_of(const uint64_t *__restrict__ regions, uint32_t h, uint64_t &bucket, uint32_t &hlow) {
     const uint64_t e = regions[h >> 24];
-    const uint32_t s = (uint32_t)e & 0xFFu;
-    bucket = (e >> 8) + ((h & 0xFFFFFFu) >> s);
-    hlow = h & ((1u << s) - 1u);
+    bucket = (e >> UTREE_REGION_NB_BITS) + bucket_in_region(h, (uint32_t)e & ((1u << UTREE_REGION_NB_BITS) - 1u));
+    hlow = h & 0xFFu;
 }
 
 // bucket and MIN key from (h, pos)
@@ -211,7 +219,7 @@ template <int W> __device__ __forceinline__ void min_split(uint64_t khi, uint64_
 
 // MIN records / bucket entries.  flag (top 2 bits of word KW): 0 record, 1 empty entry, 2 (a bucket's LAST entry only)
 // overflow: run {count22 | start40} of the bucket's remaining records in the sorted array
-//   W=8, I=2: {flag2 | 0 | hlow8 pos5 | rank16 | rest32}    W=8, I=4: {flag2 | 0 | key45 | 0}{rank32}
+//   W=8, I=2: {flag2 | 0 | hlow8 pos5 | rank16 | rest32}    W=8, I=4: {flag2 | 0 | hlow8 pos5 | 0 | rest32}{rank32}
 //   W=16,I=2: {rest lo64}{flag2 | key_hi46 | rank16}        W=16,I=4: {rest lo64}{flag2 | key_hi46 | 0}{rank32}{0}
 // (W=8, I=2 -- the common format -- keeps the 32 "rest" bits in its low word and everything else in its high word: the bucket
 // scan of the search kernels is then one 32-bit compare and one select per entry, wave_common.hpp::scan_bucket82.)
@@ -222,8 +230,7 @@ template <int W, int I> __device__ __forceinline__ uint32_t mrec_flag(const Entr
 template <int W, int I> __device__ __forceinline__ MinKey<W> mrec_key(const Entry<W, I> &e) {
     MinKey<W> k;
     if constexpr (W == 16) { k.lo = e.w[0]; k.hi = (e.w[1] >> 16) & M46; }
-    else if constexpr (I == 2) { k.hi = 0; k.lo = (((e.w[0] >> 48) & 0x1FFFull) << 32) | (e.w[0] & 0xFFFFFFFFull); }
-    else { k.hi = 0; k.lo = (e.w[0] >> 16) & M46; }
+    else { k.hi = 0; k.lo = (((e.w[0] >> 48) & 0x1FFFull) << 32) | (e.w[0] & 0xFFFFFFFFull); }
     return k;
 }
 template <int W, int I> __device__ __forceinline__ uint32_t mrec_rank(const Entry<W, I> &e) {
@@ -239,8 +246,7 @@ template <int W, int I> __device__ __forceinline__ Entry<W, I> make_mrec(const M
     for (int j = 0; j < RecTraits<W, I>::EW; ++j) e.w[j] = 0;
     const uint64_t r16 = (I == 2) ? (rank == INVALID ? 0xFFFFull : (uint64_t)(rank & 0xFFFFu)) : 0ull;
     if constexpr (W == 16) { e.w[0] = k.lo; e.w[1] = (k.hi << 16) | r16; }
-    else if constexpr (I == 2) { e.w[0] = ((k.lo >> 32) << 48) | (r16 << 32) | (k.lo & 0xFFFFFFFFull); }
-    else { e.w[0] = (k.lo << 16) | r16; }
+    else { e.w[0] = ((k.lo >> 32) << 48) | (r16 << 32) | (k.lo & 0xFFFFFFFFull); }
     if constexpr (I == 4) e.w[RecTraits<W, I>::KW + 1] = rank;
     return e;
 }

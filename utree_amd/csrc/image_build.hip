@@ -6,7 +6,7 @@
 //   assign_k     per node: minimizer hash, position, rest, 24-bit prefix
 //   (rocprim radix sorts: nodes ordered by (hash, position, rest))
 //   emit_k       MIN records in that order
-//   bucket_k     64-byte buckets addressed by the minimizer hash through the region table: records inline, overflow descriptor
+//   bucket_k     128-byte buckets addressed by the minimizer hash through the region table: records inline, overflow descriptor
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <algorithm>
@@ -155,7 +155,7 @@ template <int W, int I>
 __global__ void bucket_k(const uint32_t *__restrict__ Hs, const uint64_t *__restrict__ mrecs, uint64_t base, uint64_t m,
                          const uint64_t *__restrict__ regions, uint64_t *__restrict__ table, uint64_t run_max, unsigned long long *overflow) {
     // Hs / mrecs: this part's sorted hashes and records (a part = a range of whole buckets); base = MIN records in earlier parts
-    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = 8 / EW;
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = RecTraits<W, I>::CAP;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t b, bp; uint32_t hl;
         bucket_of(regions, Hs[j], b, hl);
@@ -167,7 +167,7 @@ __global__ void bucket_k(const uint32_t *__restrict__ Hs, const uint64_t *__rest
             if (bp != b) break;
             ++n;
         }
-        uint64_t *o = table + b * 8;                                                  // 64 bytes per bucket
+        uint64_t *o = table + b * BUCKET_WORDS;                                       // 128 bytes per bucket
         const uint64_t inl = n <= (uint64_t)CAP ? n : (uint64_t)CAP - 1;
         for (uint64_t q = 0; q < inl; ++q)
 #pragma unroll
@@ -192,11 +192,11 @@ template <int W, int I, typename OFF, typename IDX>
 __global__ void flag_saturated_k(const uint32_t *__restrict__ Hs, const IDX *__restrict__ idx, uint64_t m, uint64_t c0,
                                  const OFF *__restrict__ coarse, const uint64_t *__restrict__ regions, const uint64_t *__restrict__ table,
                                  uint32_t *irreg, unsigned long long *counters) {
-    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = 8 / EW;
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = RecTraits<W, I>::CAP;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t b; uint32_t hl;
         bucket_of(regions, Hs[j], b, hl);
-        const uint64_t d = table[b * 8 + (uint64_t)(CAP - 1) * EW + KW];
+        const uint64_t d = table[b * BUCKET_WORDS + (uint64_t)(CAP - 1) * EW + KW];
         if ((d >> 62) != 2 || ((d >> 40) & 0x3FFFFFull) != 0x3FFFFFull) continue;
         const uint32_t p = bin_of<OFF>(coarse, c0 + (uint64_t)idx[j]);
         const uint32_t bit = 1u << (p & 31);
@@ -209,9 +209,9 @@ __global__ void flag_saturated_k(const uint32_t *__restrict__ Hs, const IDX *__r
 // their new places: the sorted array of ALL nodes (8-32 bytes per node) leaves the image.
 template <int W, int I>
 __global__ void ovf_count_k(const uint64_t *__restrict__ table, uint64_t n_buckets, uint32_t *__restrict__ cnt) {
-    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = 8 / EW;
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = RecTraits<W, I>::CAP;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t d = table[b * 8 + (uint64_t)(CAP - 1) * EW + KW];
+        const uint64_t d = table[b * BUCKET_WORDS + (uint64_t)(CAP - 1) * EW + KW];
         uint32_t c = (d >> 62) == 2 ? (uint32_t)((d >> 40) & 0x3FFFFFull) : 0u;
         if (c == 0x3FFFFFu) c = 0;           // a saturated run is never followed (its nodes' bins take the exact-probe path): nothing to keep
         cnt[b] = c;
@@ -220,10 +220,10 @@ __global__ void ovf_count_k(const uint64_t *__restrict__ table, uint64_t n_bucke
 template <int W, int I>
 __global__ void ovf_move_k(uint64_t *__restrict__ table, uint64_t n_buckets, const uint32_t *__restrict__ cnt,
                            const uint64_t *__restrict__ prefix, const uint64_t *__restrict__ mrecs, uint64_t *__restrict__ packed) {
-    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = 8 / EW;
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = RecTraits<W, I>::CAP;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t c = cnt[b];
-        uint64_t *dp = table + b * 8 + (uint64_t)(CAP - 1) * EW + KW;
+        uint64_t *dp = table + b * BUCKET_WORDS + (uint64_t)(CAP - 1) * EW + KW;
         if (!c) {
             // a saturated descriptor becomes an empty run: a word that is no node finds nothing there (words of nodes never come here)
             if ((*dp >> 62) == 2) *dp = MFLAG_RUN;
@@ -268,11 +268,22 @@ int sort_pass(const uint64_t *key_by_node, uint32_t nbits, IDX *&idx, IDX *&idx_
     IDX *t = idx; idx = idx_alt; idx_alt = t;
     return (int)hipGetLastError();
 }
+// the last pass: by { bucket | the hash's low 8 bits } -- the bucket is monotone in the hash, but a bucket's up to 256 consecutive
+// hash values need not ascend in their low 8 bits, and inside a bucket (and its overflow run) records ascend by their KEY, whose top
+// field those 8 bits are
+template <typename IDX> __global__ void gather_bkey_k(const uint32_t *__restrict__ H, const IDX *__restrict__ idx, const uint64_t *__restrict__ regions,
+                                                      uint64_t *__restrict__ dst, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t b; uint32_t hl;
+        bucket_of(regions, H[idx[i]], b, hl);
+        dst[i] = (b << 8) | hl;
+    }
+}
 template <typename IDX>
-int sort_pass32(const uint32_t *key_by_node, IDX *&idx, IDX *&idx_alt, uint32_t *kg, uint32_t *kg_alt, uint64_t m, void *tmp,
-                size_t tmp_bytes, hipStream_t st) {
-    gather_k<IDX, uint32_t><<<grid_for(m), 256, 0, st>>>(key_by_node, idx, kg, m);
-    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kg, kg_alt, idx, idx_alt, m, 0, 32, st);
+int sort_pass_bucket(const uint32_t *H, const uint64_t *regions, uint32_t nbits, IDX *&idx, IDX *&idx_alt, uint64_t *kg, uint64_t *kg_alt, uint64_t m,
+                     void *tmp, size_t tmp_bytes, hipStream_t st) {
+    gather_bkey_k<IDX><<<grid_for(m), 256, 0, st>>>(H, idx, regions, kg, m);
+    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kg, kg_alt, idx, idx_alt, m, 0, nbits, st);
     if (e != hipSuccess) return (int)e;
     IDX *t = idx; idx = idx_alt; idx_alt = t;
     return (int)hipGetLastError();
@@ -309,13 +320,13 @@ struct in_part {
 // node on top of the 12-20 bytes of keys; when that does not fit beside the image (trees of billions of nodes) the
 // nodes are handled in 2^pb parts by the top bits of the hash -- parts are contiguous in the final order.
 template <int W, int I, typename OFF, typename IDX>
-int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, const uint64_t *regions, uint64_t n_buckets,
+int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, const uint64_t *regions, const uint64_t *h_regions, uint64_t n_buckets,
               uint64_t *table, uint64_t *mrecs, uint32_t *irreg, unsigned long long *d_overflow, hipStream_t st) {
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
-    const uint64_t nslots = n_buckets * (8 / EW);                                      // entries, all flagged empty to begin with
+    const uint64_t nslots = n_buckets * (BUCKET_WORDS / EW);                           // entries, all flagged empty to begin with
     for (int x = 0; x < EW; ++x) fill_u64_k<<<grid_for(nslots), 256, 0, st>>>(table, nslots, x == KW ? MFLAG_EMPTY : 0ull, EW, x);
     if (!m) return (int)hipGetLastError();
-    uint32_t *H = nullptr, *Hg = nullptr, *Hg2 = nullptr;
+    uint32_t *H = nullptr, *Hg = nullptr, *Hg2 = nullptr; (void)Hg2;
     uint64_t *K1 = nullptr, *K2 = nullptr, *kg = nullptr, *kg2 = nullptr;
     IDX *idx = nullptr, *idx2 = nullptr;
     unsigned long long *d_counts = nullptr;
@@ -360,10 +371,12 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
             (void)hipFree(d_s);
             if (e1 != hipSuccess || e2 != hipSuccess) { free(h_s); rc = (int)(e1 != hipSuccess ? e1 : e2); goto done; }
             std::sort(h_s, h_s + ns);
-            const uint64_t slot = 256;                                                 // cuts fall on bucket boundaries (a bucket spans <= 256 hash values, aligned)
             for (uint32_t q = 1; q < nparts; ++q) {
-                uint64_t c = h_s[(uint64_t)ns * q / nparts];
-                c -= c % slot;
+                // cuts fall on bucket boundaries: the smallest hash of the bucket that holds the sampled quantile
+                const uint32_t hq = h_s[(uint64_t)ns * q / nparts];
+                const uint64_t nb = h_regions[hq >> 24] & ((1ull << UTREE_REGION_NB_BITS) - 1);
+                const uint64_t bl = bucket_in_region(hq, (uint32_t)nb);
+                uint64_t c = ((uint64_t)(hq >> 24) << 24) | (((bl << 24) + nb - 1) / nb);
                 pbnd.cut[q] = c < pbnd.cut[q - 1] ? pbnd.cut[q - 1] : c;
             }
             free(h_s);
@@ -422,9 +435,13 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
         } else {
             if ((rc = sort_pass<IDX>(K1, 37, idx, idx2, kg, kg2, mq, tmp, t64, st))) goto done;      // position | rest
         }
+        {
+            uint32_t bbits = 1;
+            while (bbits < 56 && (n_buckets >> bbits)) ++bbits;
+            if ((rc = sort_pass_bucket<IDX>(H, regions, 8 + bbits, idx, idx2, kg, kg2, mq, tmp, t64, st))) goto done;   // bucket, low hash bits
+        }
         Hg = (uint32_t *)kg; Hg2 = (uint32_t *)kg2;
-        if ((rc = sort_pass32<IDX>(H, idx, idx2, Hg, Hg2, mq, tmp, t64, st))) goto done;             // minimizer hash
-        // Hg2 now holds the sorted hashes but emit_k recomputes them from H[idx]: reuse Hg as the sorted-hash array
+        // emit_k recomputes the hashes from H[idx]: Hg becomes the array of hashes in the final order
         emit_k<W, I, IDX><<<grid_for(mq), 256, 0, st>>>(recs, c0, idx, H, K1, K2, regions, mq, mrecs + base * EW, Hg);
         bucket_k<W, I><<<grid_for(mq), 256, 0, st>>>(Hg, mrecs + base * EW, base, mq, regions, table, run_max, d_overflow);
         CK(hipGetLastError());
@@ -546,16 +563,16 @@ done:
 /* nodes [c0, c0+m) = what the (monotone) bin table reaches.  d_overflow[0] += buckets whose run saturates the descriptor,
  * d_overflow[1] += bins newly flagged in d_irreg because of them. */
 int utk_build_min(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
-                  const uint64_t *d_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
+                  const uint64_t *d_regions, const uint64_t *h_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
                   unsigned long long *d_overflow, void *stream) {
     int rc = 0;
     int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
         constexpr int W = decltype(w)::value, I = decltype(i)::value;
         hipStream_t st = (hipStream_t)stream;
         const bool idx64 = m >= 0xFFFFFFFFull;
-        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
-        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
-        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, d_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
+        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
+        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
+        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
     });
     return rc ? rc : drc;
 }

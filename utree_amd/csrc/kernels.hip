@@ -120,9 +120,8 @@ __device__ __forceinline__ void build_minkeys(const uint32_t *s, uint32_t sh, ui
 }
 
 // The block's copy of the image's region table in the form the window loop wants it (stage_regions):
-//   s_raddr[r] = address of bucket (base_r - ((r << 24) >> s_r)): with it, bucket address = s_raddr[r] + ((h >> s_r) << 6)
-//   s_rshift[r] = s_r
-struct RegionLds { const uint64_t *addr; const uint8_t *shift; };
+//   s_reg[r] = the header's entry, first bucket << 25 | buckets of the region: bucket address = table + ((first + mulhi(h << 8, nb)) << 7)
+struct RegionLds { const uint64_t *reg; uint64_t table; };
 
 // One wave looks up the windows [w0, w0+n) of a staged buffer (lb / sw = packed bases, sbad = bad-base bit words, both
 // indexed from the buffer's first base; w0 a multiple of 64) and hands every lane's result to on_rank(rank) -- called by all
@@ -154,22 +153,23 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const Lan
             const uint32_t p = (kb < ka ? kb : ka) & MIN_POS_MASK;
             const uint32_t h = Hh[p];
             const uint32_t pos = p + nlane - it * 64;                       // minimizer position inside the window
-            const uint32_t sft = rg.shift[h >> 24];
+            const uint64_t re = rg.reg[h >> 24];
+            const uint32_t bl = __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u));
 #ifdef UTREE_ABLATE_L2
-            baddr = (uint64_t)(uintptr_t)im.table + ((uint64_t)((h >> sft) & 0x3FFFu) << 6);   // timing experiment: every bucket inside 1 MB (L2 hits), answers wrong
+            baddr = rg.table + ((uint64_t)(bl & 0x1FFFu) << 7);             // timing experiment: every bucket inside 1 MB (L2 hits), answers wrong
 #else
-            baddr = rg.addr[h >> 24] + ((uint64_t)(h >> sft) << 6);
+            baddr = rg.table + (((re >> UTREE_REGION_NB_BITS) + bl) << 7);
 #endif
-            tag = ((h & ((1u << sft) - 1u)) << 6) | pos;                    // hash bits the bucket does not imply | position (< 64)
+            tag = ((h & 0xFFu) << 6) | pos;                                 // hash bits the bucket does not imply | position (< 64)
         };
-        auto resolve = [&](uint32_t it, const Bucket<W, I> &bk, uint32_t tag) -> uint32_t {
+        auto resolve = [&](uint32_t it, const Bucket<W, I> &bk, uint64_t baddr, uint32_t tag) -> uint32_t {
             const uint32_t *sr = st + it * 4;
             const uint32_t pos = tag & 63u, hlow = tag >> 6;
             if constexpr (W == 8) {
                 const uint32_t x0 = mmer_l(sr, 0, lb.sh), x1 = mmer_l(sr, 1, lb.sh);
                 const uint32_t M = (uint32_t)(0xFFFFFFFFull >> (2 * pos));           // ones over the bases after the minimizer
                 const uint32_t rest = x0 ^ ((x0 ^ x1) & M);                          // bit-select: x1 where M, x0 elsewhere
-                return resolve_bucket8<I, EXC, OFF>(im, bk, hlow, pos, rest, x0, x1);
+                return resolve_bucket8<I, EXC, OFF>(im, bk, baddr, hlow, pos, rest, x0, x1);
             } else {
                 const uint32_t x0 = mmer_l(sr, 0, lb.sh), x1 = mmer_l(sr, 1, lb.sh), x2 = mmer_l(sr, 2, lb.sh), x3 = mmer_l(sr, 3, lb.sh);
                 const uint64_t wh = ((uint64_t)x0 << 32) | x1, wl = ((uint64_t)x2 << 32) | x3;
@@ -177,7 +177,7 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const Lan
                 min_rest<W>(wh, wl, pos, rh, rl);
                 MinKey<W> mk;
                 mk.lo = rl; mk.hi = ((uint64_t)hlow << 38) | ((uint64_t)pos << 32) | rh;
-                return resolve_bucket<W, I, EXC, OFF>(im, bk, mk, wh, wl);
+                return resolve_bucket<W, I, EXC, OFF>(im, bk, baddr, mk, wh, wl);
             }
         };
         auto window_ok = [&](uint32_t it, uint32_t left) -> bool {
@@ -208,8 +208,8 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const Lan
                 PH_WAITVM;
                 TICK(4);
                 uint32_t rank0 = INVALID, rank1 = INVALID;
-                if (ok0) rank0 = resolve(it, bk0, t0);
-                if (ok1) rank1 = resolve(it + 1, bk1, t1);
+                if (ok0) rank0 = resolve(it, bk0, a0, t0);
+                if (ok1) rank1 = resolve(it + 1, bk1, a1, t1);
                 TICK(5);
                 on_rank(rank0);                                              // itree.c:929-931
                 if (left1) on_rank(rank1);
@@ -218,7 +218,7 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const Lan
                 PH_WAITVM;
                 TICK(4);
                 uint32_t rank0 = INVALID;
-                if (ok0) rank0 = resolve(it, bk0, t0);
+                if (ok0) rank0 = resolve(it, bk0, a0, t0);
                 TICK(5);
                 on_rank(rank0);                                              // itree.c:929-931
                 TICK(6);
@@ -229,14 +229,19 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const Lan
 }
 
 // the image's region table -> LDS in the window loop's form (all threads of the workgroup; followed by a barrier)
-__device__ __forceinline__ void stage_regions(const utk_image &im, uint64_t *s_raddr, uint8_t *s_rshift) {
-    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) {
-        const uint64_t e = im.regions[x];
-        const uint32_t sft = (uint32_t)e & 0xFFu;
-        s_raddr[x] = (uint64_t)(uintptr_t)im.table + (((e >> 8) - (((uint64_t)x << 24) >> sft)) << 6);
-        s_rshift[x] = (uint8_t)sft;
-    }
+__device__ __forceinline__ void stage_regions(const utk_image &im, uint64_t *s_reg) {
+    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) s_reg[x] = im.regions[x];
     __syncthreads();
+}
+
+// `n` entries of (rank, count) list space from the batch's cursor (one lane calls this).  The workspace is sized so that the space
+// cannot run out (dev_image.c: carve); should it -- a caller's total_bases that does not describe the batch, or the test hook --, the
+// batch's error word is raised (utree_classify_poll reports it) and the caller writes at the start of the list area instead of past its
+// end.
+__device__ __forceinline__ unsigned long long reserve_tally(const utk_workspace &ws, unsigned long long n) {
+    unsigned long long nb = atomicAdd(&ws.cursors[0], n);
+    if (nb + n > ws.tally_cap) { ws.cursors[UTREE_CUR_ERROR] = UTREE_DEVERR_TALLY_CAP; nb = 0; }
+    return nb;
 }
 
 __device__ __forceinline__ void store_result(utree_result *out, uint32_t label, int32_t cut, uint32_t found,
@@ -410,15 +415,14 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     constexpr bool PAIRS = false;
 #endif
     __shared__ uint64_t s_keys[WAVES_PER_BLOCK][TILE + 128];
-    __shared__ uint64_t s_raddr[256];
-    __shared__ uint8_t s_rshift[256];
+    __shared__ uint64_t s_reg[256];
     // the mid-length pass has no room for a raw buffer of its own and less to gain: its raw bytes pass through the hit
     // list's space (consumed by stage_read before the first hit is written) and are not requested ahead
     constexpr bool PREFETCH = CAP <= SHORT2_CAP;
     static_assert(PREFETCH || sizeof(HIT) * CAP >= 4 * (RawBuf<CAP>::DW + 4), "raw bytes must fit the hit list");
     __shared__ uint32_t s_raw[PREFETCH ? WAVES_PER_BLOCK : 1][PREFETCH ? RawBuf<CAP>::DW + 4 : 1];
-    stage_regions(im, s_raddr, s_rshift);
-    const RegionLds rg = {s_raddr, s_rshift};
+    stage_regions(im, s_reg);
+    const RegionLds rg = {s_reg, (uint64_t)(uintptr_t)im.table};
     const uint32_t lane = lane_id();
     const uint32_t wv = uni32(threadIdx.x >> 6);
     uint32_t *raw = PREFETCH ? s_raw[wv] : (uint32_t *)s_hits[wv];
@@ -476,7 +480,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 if (nu == 1) { if (lane == 0) store_result(&out[r], h0, RANK_PENDING, F, 1, 0, 0); return; }
                 if (nu > chunk_left) {
                     unsigned long long nb = 0;
-                    if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)TALLY_CHUNK);
+                    if (lane == 0) nb = reserve_tally(ws, (unsigned long long)TALLY_CHUNK);
                     chunk_base = uni64(nb);
                     chunk_left = TALLY_CHUNK;
                 }
@@ -502,12 +506,12 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             const bool direct = (uint32_t)CAP >= TALLY_DIRECT && F >= TALLY_DIRECT;   // (a 320-base slice never holds that many hits)
             if (direct) {
                 unsigned long long nb = 0;
-                if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)F);
+                if (lane == 0) nb = reserve_tally(ws, (unsigned long long)F);
                 base = uni64(nb);
             } else {
                 if (F > chunk_left) {
                     unsigned long long nb = 0;
-                    if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)TALLY_CHUNK);
+                    if (lane == 0) nb = reserve_tally(ws, (unsigned long long)TALLY_CHUNK);
                     chunk_base = uni64(nb);
                     chunk_left = TALLY_CHUNK;
                 }
@@ -659,8 +663,7 @@ __global__ __launch_bounds__(LONG_THREADS, EXC ? 5 : 8) void classify_long_k(utk
     __shared__ uint32_t s_touch[LONG_LDS_BITWORDS];
     __shared__ uint64_t s_keys[LONG_THREADS / 64][KEY_TILE + 128];
     __shared__ unsigned long long s_base;
-    __shared__ uint64_t s_raddr[256];
-    __shared__ uint8_t s_rshift[256];
+    __shared__ uint64_t s_reg[256];
     __shared__ uint32_t s_work, s_single;               // the read this workgroup took; the label of a one-label read
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = uni32(tid >> 6);
     uint32_t *s_words = s_words_pad + 2;
@@ -671,8 +674,8 @@ __global__ __launch_bounds__(LONG_THREADS, EXC ? 5 : 8) void classify_long_k(utk
     uint32_t *touch = nbw <= LONG_LDS_BITWORDS ? s_touch : ws.touch + (size_t)blockIdx.x * nbw;   // all zero between reads
     const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
     if (nbw <= LONG_LDS_BITWORDS) for (uint32_t x = tid; x < nbw; x += LONG_THREADS) s_touch[x] = 0;
-    stage_regions(im, s_raddr, s_rshift);
-    const RegionLds rg = {s_raddr, s_rshift};
+    stage_regions(im, s_reg);
+    const RegionLds rg = {s_reg, (uint64_t)(uintptr_t)im.table};
 
     for (;;) {
         // long reads differ in length by orders of magnitude: hand them out one at a time
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(LONG_THREADS, EXC ? 5 : 8) void classify_long_k(utk
         uint32_t wbase = 0, uix = 0;
         for (uint32_t w = 0; w < LONG_THREADS / 64; ++w) { if (w < wv) wbase += s_scan[w]; uix += s_scan[w]; }
         uint32_t pos = wbase + inc - cnt;
-        if (tid == 0) s_base = uix > 1 ? atomicAdd(&ws.cursors[0], (unsigned long long)uix) : 0ull;
+        if (tid == 0) s_base = uix > 1 ? reserve_tally(ws, (unsigned long long)uix) : 0ull;
         __syncthreads();
         const unsigned long long base = s_base;
         for (uint32_t x = lo; x < hi; ++x) {
@@ -990,11 +993,12 @@ __global__ __launch_bounds__(256) void model_k(utk_image im, const uint8_t *__re
                 if (b == ~0ull) continue;
                 ++c_win;
                 bool first_b = true, first_l = true;
-                for (uint32_t j = 0; j < i; ++j) { const uint64_t x = s_b[wv][j]; first_b = first_b && x != b; first_l = first_l && (x == ~0ull || (x >> 1) != (b >> 1)); }
+                for (uint32_t j = 0; j < i; ++j) { const uint64_t x = s_b[wv][j]; first_b = first_b && x != b; }
+                first_l = first_b;                                                       // (a bucket is a 128-byte line)
                 c_buck += first_b; c_line += first_l;
                 if (first_b) {
-                    const Bucket<W, I> bk = load_bucket<W, I>(im.table, b);
-                    c_over += mrec_flag<W, I>(bk.e[BucketOf<W, I>::CAP - 1]) == 2;
+                    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAPF = RecTraits<W, I>::CAP;
+                    c_over += (im.table[b * BUCKET_WORDS + (uint64_t)(CAPF - 1) * EW + KW] >> 62) == 2;
                 }
             }
             wave_lds_fence();

@@ -108,18 +108,29 @@ __device__ __forceinline__ void rest96(const uint32_t (&A)[3], const uint32_t (&
 // hold) and the LCAP bases from s SW on that they lie in -- reads of up to (SEGS - 1) SW + LCAP bases, 64 / SEGS of them per wavefront
 // IRR: the table has a few irregular bins (COMPRESS' first-bin quirk): their words need the reference's own probe sequence
 // (wave_common.hpp: resolve_bucket), so a read with a window in one of them is left to the wave-per-read kernel
-// PIECE: the items are not reads but pieces of long reads (ws.pieces: SEGS SW windows of a read on ws.long_list each); a piece's
-// tally goes into its read's table in HBM (ws.ltab_*), which finish_long_k turns into the read's result
-template <int W, int SEGS, bool IRR, bool PIECE>
+// MODE 0: the items are the batch's reads 0 .. n_reads - 1.  MODE 1 (LISTED): the reads of one length class of a mixed batch, listed by
+// lanes_route_k (ws.cls_list, class `cls`; their number is on the device).  MODE 2 (PIECE): the items are not reads but pieces of
+// long reads (ws.pieces: SEGS SW windows of a read on ws.long_list each); a piece's tally goes into its read's table in HBM
+// (ws.ltab_*), which finish_long_k turns into the read's result
+// I: bytes of a label index (2, or 4 with k = 32: tally slots then keep 19 bits of rank and 13 of count, which bounds the labels of such
+// an image -- utk_lanes_image_ok)
+template <int W, int I, int SEGS, bool IRR, int MODE>
 __global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
 void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
-                      uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws) {
+                      uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws, uint32_t cls) {
+    constexpr bool PIECE = MODE == 2, LISTED = MODE == 1;
     using G = Geo<W>;
     constexpr uint32_t K = G::K, NB = G::NB, NA = G::NA, STRIDE = G::STRIDE, FRONT = G::FRONT, RUNS_CAP = G::RUNS;
     constexpr uint32_t SW = LCAP - K + 1, RPW = 64 / SEGS;            // windows per lane; reads per wavefront
     constexpr uint32_t SEGSH = SEGS == 16 ? 4 : SEGS == 8 ? 3 : SEGS == 4 ? 2 : SEGS == 2 ? 1 : 0;
     constexpr uint32_t TSR = TSLOTS * SEGS < 48u ? TSLOTS * SEGS : 48u;   // tally slots per read: the table space of its lanes, up to 48 labels
     static_assert(SEGS == 1 || SEGS == 2 || SEGS == 4 || SEGS == 8 || SEGS == 16, "lanes per read");
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+    static_assert(EW <= 2, "entries of 8 or 16 bytes");
+    // a tally slot is {rank << CB | count}: a read of this kernel has at most 2 * 2064 hits (sixteen lanes, both strands)
+    constexpr uint32_t CB = I == 2 ? 16u : 13u, CMASK = (1u << CB) - 1u;
+    // a hit waiting for its push is {lane of its read << QS | rank}
+    constexpr uint32_t QS = I == 2 ? 16u : 20u, QMASK = (1u << QS) - 1u;
     __shared__ uint32_t s_stream[LANES_WAVES][64 * STRIDE];
     __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
     // a read's hits are tallied as they are found: TSR slots {rank << 16 | count} per read, filled from slot 0 (itree.c:1031-1040
@@ -128,14 +139,14 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     __shared__ uint32_t s_full[LANES_WAVES][2];               // reads with more distinct labels than slots
     __shared__ uint32_t s_pref[LANES_WAVES][64];
     __shared__ uint64_t s_ost[LANES_WAVES][64];               // overflow descriptors of up to 64 runs
-    __shared__ uint64_t s_raddr[256];
-    __shared__ uint8_t s_rshift[256];
-    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) {            // region table in the window loop's form (kernels.hip: stage_regions)
-        const uint64_t e = im.regions[x];
-        const uint32_t sft = (uint32_t)e & 0xFFu;
-        s_raddr[x] = (uint64_t)(uintptr_t)im.table + (((e >> 8) - (((uint64_t)x << 24) >> sft)) << 6);
-        s_rshift[x] = (uint8_t)sft;
-    }
+    __shared__ uint64_t s_reg[256];
+    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) s_reg[x] = im.regions[x];   // {first bucket << 25 | buckets} of every hash region
+    const uint64_t tbl = (uint64_t)(uintptr_t)im.table;
+    // the 128-byte bucket of a minimizer hash (device_common.hpp: bucket_of)
+    auto bucket_addr = [&](uint32_t h) -> uint64_t {
+        const uint64_t re = s_reg[h >> 24];
+        return tbl + (((re >> UTREE_REGION_NB_BITS) + __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u))) << 7);
+    };
     const uint32_t lane = lane_id();
     const uint32_t wv = uni32(threadIdx.x >> 6);
     uint32_t *stream = s_stream[wv];
@@ -154,7 +165,9 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     uint32_t chunk_left = 0;
     const uint32_t wave_gid = blockIdx.x * LANES_WAVES + wv;
     if constexpr (PIECE) n_reads = (uint32_t)ws.cursors[UTREE_CUR_PIECES];    // (the items: pieces)
-    unsigned long long *parts = ws.cursors + 64 + (PIECE ? 2 * UTREE_WORK_PARTS * UTREE_WORK_STRIDE : 0);
+    if constexpr (LISTED) n_reads = (uint32_t)ws.cursors[UTREE_CUR_CLASS + cls];
+    const uint32_t *const lst = LISTED ? ws.cls_list + (size_t)cls * ws.cls_stride : nullptr;
+    unsigned long long *parts = ws.cursors + 64 + (PIECE ? 2 : LISTED ? 3 + cls : 0) * (UTREE_WORK_PARTS * UTREE_WORK_STRIDE);
     const uint32_t part_len = ((n_reads + UTREE_WORK_PARTS - 1) / UTREE_WORK_PARTS + 63u) / 64u * 64u;
     uint32_t part = wave_gid % UTREE_WORK_PARTS, parts_left = UTREE_WORK_PARTS;
 
@@ -197,9 +210,10 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                     const uint64_t Lr = len[rd];
                     if (Lr > at) { L = (uint32_t)(Lr - at < LCAP ? Lr - at : LCAP); o = off[rd] + at; }
                 } else {
-                    const uint32_t Lr = len[r0];
+                    const uint32_t rd = LISTED ? lst[r0] : r0;
+                    const uint32_t Lr = len[rd];
                     if (Lr > (SEGS - 1u) * SW + LCAP) exc = true;                 // longer than this instantiation holds
-                    else if (Lr > piece * SW) { L = umin(LCAP, Lr - piece * SW); o = off[r0] + piece * SW; }
+                    else if (Lr > piece * SW) { L = umin(LCAP, Lr - piece * SW); o = off[rd] + piece * SW; }
                 }
             }
         }
@@ -365,8 +379,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // quad broadcast (DPP), nothing goes through LDS.  Two more batches of 64 buckets are in flight meanwhile.
         // (a lane beyond the list repeats the list's last run -- its load stays inside the table -- as a run no entry can belong to)
         uint32_t n_ovf = 0;
-        // what a scan needs of a run: {minimizer hash, first window | minimizer position - first << 8 | windows - 1 << 14 | read << 20 |
-        // the hash region's shift << 26, the 16 (k = 64: 48) bases before the minimizer, the 16 (48) bases behind it}
+        // what a scan needs of a run: {minimizer hash, first window | minimizer position - first << 8 | windows - 1 << 14 | read << 20,
+        // the 16 (k = 64: 48) bases before the minimizer, the 16 (48) bases behind it}
         struct RunRegs { uint32_t h, pk, A[NA], B[NA]; };
         // a run's context from its record: the words around the minimizer come from the slot of the run's read
         auto context = [&](uint32_t q, uint32_t ustar, uint32_t &m, uint32_t (&A)[NA], uint32_t (&B)[NA]) {
@@ -394,18 +408,20 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             c.h = mix32(m);
             // (beyond the list: an offset no run has -- no entry's position field names a window of that run)
             const uint32_t dl = act ? ((ustar - first) << 8) | ((end - 1u - first) << 14) : (G::DNONE << 8);
-            c.pk = first | dl | (q << 20) | ((uint32_t)s_rshift[c.h >> 24] << 26);
+            c.pk = first | dl | (q << 20);
         };
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) u32x4 *gptr128;
 #define QUAD_BCAST(v, k) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (k) * 0x55, 0xF, 0xF, true))
-        auto issue = [&](const RunRegs &c, u32x4 (&P)[4]) {
-            const uint64_t a = s_raddr[c.h >> 24] + ((uint64_t)(c.h >> ((c.pk >> 26) & 15u)) << 6);      // 64-byte aligned
+        // (lane j of a quad fetches bytes 16 j .. 16 j + 15 of both 64-byte halves of each of the quad's four buckets: P[2 k] and
+        // P[2 k + 1] of run k; the two requests of a quad for one bucket are the two halves of one 128-byte line)
+        auto issue = [&](const RunRegs &c, u32x4 (&P)[8]) {
+            const uint64_t a = bucket_addr(c.h);                                                       // 128-byte aligned
             const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32), mine = 16u * (lane & 3u);
-            P[0] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 0) << 32) | (QUAD_BCAST(alo, 0) | mine));
-            P[1] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 1) << 32) | (QUAD_BCAST(alo, 1) | mine));
-            P[2] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 2) << 32) | (QUAD_BCAST(alo, 2) | mine));
-            P[3] = *(gptr128)(((uint64_t)QUAD_BCAST(ahi, 3) << 32) | (QUAD_BCAST(alo, 3) | mine));
+#define ISSUE_K(k) { const uint64_t b_ = ((uint64_t)QUAD_BCAST(ahi, k) << 32) | (QUAD_BCAST(alo, k) | mine); \
+                     P[2 * k] = *(gptr128)b_; P[2 * k + 1] = *(gptr128)(b_ | 64u); }
+            ISSUE_K(0) ISSUE_K(1) ISSUE_K(2) ISSUE_K(3)
+#undef ISSUE_K
         };
         auto push = [&](uint32_t q, uint32_t rank) {                  // q: the lane whose slot the hit was found in
             const uint32_t rd = q >> SEGSH;
@@ -414,22 +430,24 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             for (; i < TSR; ++i) {                                    // (a slot's rank never changes once it is set)
                 uint32_t cur = t[i * RPW];
                 if (cur == T_EMPTY) {
-                    cur = atomicCAS(&t[i * RPW], T_EMPTY, (rank << 16) | 1u);
+                    cur = atomicCAS(&t[i * RPW], T_EMPTY, (rank << CB) | 1u);
                     if (cur == T_EMPTY) break;
                 }
-                if ((cur >> 16) == rank) { atomicAdd(&t[i * RPW], 1u); break; }
+                if ((cur >> CB) == rank) { atomicAdd(&t[i * RPW], 1u); break; }
             }
             if (i == TSR) atomicOr(&full[rd >> 5], 1u << (rd & 31u));
         };
-        // hits of a batch wait in two registers per lane (read << 16 | rank, the later one in `p0`) and go to the reads' lists once per
-        // batch
-        auto scan1 = [&](uint32_t ch, uint32_t cpk, const uint32_t (&cA)[NA], const uint32_t (&cB)[NA], const u32x4 &Pk, uint32_t &p0, uint32_t &p1, uint32_t &np) {
-            const uint32_t d = (cpk >> 8) & 63u, lenm1 = (cpk >> 14) & 63u, sft = (cpk >> 26) & 15u;
-            const uint32_t hlow = ch & ((1u << sft) - 1u);                              // hash bits the bucket does not imply
-            const uint32_t q16 = (cpk >> 4) & 0x3F0000u;                                // read << 16
+        // hits of a batch wait in two registers per lane (lane of the read << QS | rank, the later one in `p0`) and go to the reads' lists
+        // once per batch.  `last`: these 16 bytes are the bucket's last in this lane's share (the second load); the quad's fourth lane
+        // then holds the bucket's last entry, which says whether the bucket continues in an overflow run
+        auto scan1 = [&](uint32_t ch, uint32_t cpk, const uint32_t (&cA)[NA], const uint32_t (&cB)[NA], const u32x4 &Pk, const bool last,
+                         uint32_t &p0, uint32_t &p1, uint32_t &np) {
+            const uint32_t d = (cpk >> 8) & 63u, lenm1 = (cpk >> 14) & 63u;
+            const uint32_t hlow = ch & 0xFFu;                                           // hash bits the bucket does not imply
+            const uint32_t qs = I == 2 ? ((cpk >> 4) & 0x3F0000u) : (cpk & 0x3F00000u);  // read << QS
             bool hit0, hit1, more;
             uint32_t rank0, rank1;
-            if constexpr (W == 8) {
+            if constexpr (W == 8 && I == 2) {
                 // two entries, each rest | {flag2 0 hlow8 pos5 rank16}; the window that starts pos bases before the minimizer has the outer bases AB >> 2 pos
                 const uint64_t AB = ((uint64_t)cA[0] << 32) | cB[0];
                 const uint32_t lo0 = Pk.x, hi0 = Pk.y, lo1 = Pk.z, hi1 = Pk.w;
@@ -438,6 +456,15 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 hit1 = (hi1 >> 21) == hlow && (d - pos1) <= lenm1 && (uint32_t)(AB >> (2u * pos1)) == lo1 && (hi1 & 0xFFFFu) != 0xFFFFu;
                 rank0 = hi0 & 0xFFFFu; rank1 = hi1 & 0xFFFFu;
                 more = (hi1 >> 30) == 2u;
+            } else if constexpr (W == 8) {
+                // one entry: rest | {flag2 0 hlow8 pos5 0} | rank32 | 0
+                const uint64_t AB = ((uint64_t)cA[0] << 32) | cB[0];
+                const uint32_t lo0 = Pk.x, hi0 = Pk.y;
+                const uint32_t pos0 = (hi0 >> 16) & 31u;
+                hit0 = (hi0 >> 21) == hlow && (d - pos0) <= lenm1 && (uint32_t)(AB >> (2u * pos0)) == lo0 && Pk.z != INVALID;
+                hit1 = false;
+                rank0 = Pk.z; rank1 = 0;
+                more = (hi0 >> 30) == 2u;
             } else {
                 // one entry: {rest low 64}{flag2 | hlow8 pos6 rest-high 32 | rank16}
                 const uint32_t pos = (Pk.w >> 16) & 63u;
@@ -451,46 +478,47 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             }
             // (a third hit of a lane in one batch sends the oldest waiting one to its list first: a fraction of a percent of the lanes)
             if (ballot64((hit0 || hit1) && np >= 1u)) {
-                if (hit0 && np >= 2u) push(p1 >> 16, p1 & 0xFFFFu);
-                if (hit1 && np + (hit0 ? 1u : 0u) >= 2u) { const uint32_t w = hit0 ? p0 : p1; push(w >> 16, w & 0xFFFFu); }
+                if (hit0 && np >= 2u) push(p1 >> QS, p1 & QMASK);
+                if (hit1 && np + (hit0 ? 1u : 0u) >= 2u) { const uint32_t w = hit0 ? p0 : p1; push(w >> QS, w & QMASK); }
             }
-            p1 = hit0 ? p0 : p1; p0 = hit0 ? (q16 | rank0) : p0; np += hit0 ? 1u : 0u;
-            if constexpr (W == 8) { p1 = hit1 ? p0 : p1; p0 = hit1 ? (q16 | rank1) : p0; np += hit1 ? 1u : 0u; }
+            p1 = hit0 ? p0 : p1; p0 = hit0 ? (qs | rank0) : p0; np += hit0 ? 1u : 0u;
+            if constexpr (W == 8 && I == 2) { p1 = hit1 ? p0 : p1; p0 = hit1 ? (qs | rank1) : p0; np += hit1 ? 1u : 0u; }
             // The bucket continues in an overflow run (its last entry says so: the quad's fourth lane sees it): its windows are
             // looked up there after the loop, one lane per WINDOW.  The run's record goes to the front of the run list --
             // phase B has read further than that: the slots of at least 64 more runs than it has scanned.
-            const uint64_t om = ballot64((lane & 3u) == 3u && d != G::DNONE && more);
-            if (om) {
-                const uint32_t first = cpk & 0xFFu, q = (cpk >> 20) & 63u;
-                if ((om >> lane) & 1ull) runs[n_ovf + lanes_below(om)] = (first + d) | (first << 8) | ((first + lenm1 + 1u) << 16) | (q << 24);
-                n_ovf += (uint32_t)__popcll(om);
+            if (last) {
+                const uint64_t om = ballot64((lane & 3u) == 3u && d != G::DNONE && more);
+                if (om) {
+                    const uint32_t first = cpk & 0xFFu, q = (cpk >> 20) & 63u;
+                    if ((om >> lane) & 1ull) runs[n_ovf + lanes_below(om)] = (first + d) | (first << 8) | ((first + lenm1 + 1u) << 16) | (q << 24);
+                    n_ovf += (uint32_t)__popcll(om);
+                }
             }
         };
-        auto scan = [&](const RunRegs &c, const u32x4 (&P)[4]) {
+        auto scan = [&](const RunRegs &c, const u32x4 (&P)[8]) {
             uint32_t p0 = 0, p1 = 0, np = 0;
 #define SCAN_K(k) { uint32_t bA[NA], bB[NA]; \
                     _Pragma("unroll") for (uint32_t i = 0; i < NA; ++i) { bA[i] = QUAD_BCAST(c.A[i], k); bB[i] = QUAD_BCAST(c.B[i], k); } \
-                    scan1(QUAD_BCAST(c.h, k), QUAD_BCAST(c.pk, k), bA, bB, P[k], p0, p1, np); }
+                    const uint32_t bh = QUAD_BCAST(c.h, k), bpk = QUAD_BCAST(c.pk, k); \
+                    scan1(bh, bpk, bA, bB, P[2 * k], false, p0, p1, np); scan1(bh, bpk, bA, bB, P[2 * k + 1], true, p0, p1, np); }
             SCAN_K(0) SCAN_K(1) SCAN_K(2) SCAN_K(3)
 #undef SCAN_K
             if (ballot64(np != 0u)) {
-                if (np >= 1u) push(p0 >> 16, p0 & 0xFFFFu);
-                if (ballot64(np >= 2u)) { if (np >= 2u) push(p1 >> 16, p1 & 0xFFFFu); }
+                if (np >= 1u) push(p0 >> QS, p0 & QMASK);
+                if (ballot64(np >= 2u)) { if (np >= 2u) push(p1 >> QS, p1 & QMASK); }
             }
         };
         if (nruns) {
+            // two batches of 64 buckets (16 KB) in flight: one is scanned while the next arrives
             const uint32_t nit = (nruns + 63u) >> 6;
-            RunRegs R0, R1, R2;
-            u32x4 P0[4], P1[4], P2[4];
+            RunRegs R0, R1;
+            u32x4 P0[8], P1[8];
             prepare(0u, R0); issue(R0, P0);
-            prepare(1u, R1); issue(R1, P1);
-            for (uint32_t it = 0; it < nit; it += 3) {                        // no branch around a load: the waits then count them
-                prepare(it + 2, R2); issue(R2, P2);
+            for (uint32_t it = 0; it < nit; it += 2) {                        // no branch around a load: the waits then count them
+                prepare(it + 1, R1); issue(R1, P1);
                 scan(R0, P0);
-                prepare(it + 3, R0); issue(R0, P0);
+                prepare(it + 2, R0); issue(R0, P0);
                 if (it + 1 < nit) scan(R1, P1);
-                prepare(it + 4, R1); issue(R1, P1);
-                if (it + 2 < nit) scan(R2, P2);
             }
         }
 #undef QUAD_BCAST
@@ -516,8 +544,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 uint32_t m, A[NA], B[NA];
                 context(rec >> 24, rec & 0xFFu, m, A, B);
                 const uint32_t h = mix32(m);
-                const uint64_t baddr = s_raddr[h >> 24] + ((uint64_t)(h >> s_rshift[h >> 24]) << 6);
-                const uint64_t dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + 56);   // the key word of the bucket's last entry
+                const uint64_t baddr = bucket_addr(h);
+                const uint64_t dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + (BUCKET_BYTES - 8u * EW + 8u * KW));   // the key word of the bucket's last entry
                 const uint64_t n = (dsc >> 40) & 0x3FFFFFull;
                 ost[lane] = dsc;
                 if (n <= OVF_SCAN) nrec = (uint32_t)n; else wn = ((rec >> 16) & 0xFFu) - ((rec >> 8) & 0xFFu);
@@ -547,17 +575,17 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                     const uint32_t it_ = item_of(t, j);
                     const uint32_t rec = runs[ib + it_];
                     const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu, lenm1 = ((rec >> 16) & 0xFFu) - 1u - first;
-                    const Entry<W, 2> e = load_entry<W, 2>(im.mrecs, (ost[it_] & M40) + j);
+                    const Entry<W, I> e = load_entry<W, I>(im.mrecs, (ost[it_] & M40) + j);
                     uint32_t m, A[NA], B[NA];
                     context(q, ustar, m, A, B);
                     const uint32_t h = mix32(m);
-                    const uint32_t hlow = h & ((1u << s_rshift[h >> 24]) - 1u);
+                    const uint32_t hlow = h & 0xFFu;
                     bool hit;
                     uint32_t rank;
                     if constexpr (W == 8) {
                         const uint32_t lo = (uint32_t)e.w[0], hi = (uint32_t)(e.w[0] >> 32), pos = (hi >> 16) & 31u;
                         hit = (hi >> 21) == hlow && (ustar - first - pos) <= lenm1 && (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos)) == lo;
-                        rank = hi & 0xFFFFu;
+                        if constexpr (I == 2) rank = hi & 0xFFFFu; else { rank = (uint32_t)e.w[1]; hit = hit && rank != INVALID; }
                     } else {
                         const uint32_t z = (uint32_t)e.w[1], wq = (uint32_t)(e.w[1] >> 32), pos = (wq >> 16) & 63u;
                         uint32_t r0, r1, r2;
@@ -566,7 +594,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                               r1 == (uint32_t)(e.w[0] >> 32) && r2 == (uint32_t)e.w[0];
                         rank = z & 0xFFFFu;
                     }
-                    if (hit && rank != 0xFFFFu) push(q, rank);
+                    if (hit && (I == 4 || rank != 0xFFFFu)) push(q, rank);
                 }
             }
             const uint32_t total_win = spread(wn);
@@ -587,7 +615,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                         uint32_t m, A[NA], B[NA];
                         context(q, ustar, m, A, B);
                         const uint32_t h = mix32(m);
-                        const uint32_t hlow = h & ((1u << s_rshift[h >> 24]) - 1u);
+                        const uint32_t hlow = h & 0xFFu;
                         const uint64_t dsc = ost[it_];
                         lo[u] = dsc & M40; hi[u] = lo[u] + ((dsc >> 40) & 0x3FFFFFull); qs[u] = q;
                         if constexpr (W == 8) {
@@ -606,16 +634,16 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 #pragma unroll
                     for (uint32_t u = 0; u < OVF_WAYS; ++u) any = any || lo[u] < hi[u];
                     if (!ballot64(any)) break;
-                    Entry<W, 2> e[OVF_WAYS];
+                    Entry<W, I> e[OVF_WAYS];
                     uint64_t mid[OVF_WAYS];
 #pragma unroll
-                    for (uint32_t u = 0; u < OVF_WAYS; ++u) { mid[u] = lo[u] + ((hi[u] - lo[u]) >> 1); e[u] = load_entry<W, 2>(im.mrecs, mid[u]); }
+                    for (uint32_t u = 0; u < OVF_WAYS; ++u) { mid[u] = lo[u] + ((hi[u] - lo[u]) >> 1); e[u] = load_entry<W, I>(im.mrecs, mid[u]); }
 #pragma unroll
                     for (uint32_t u = 0; u < OVF_WAYS; ++u) {
                         if (lo[u] < hi[u]) {
-                            const MinKey<W> k = mrec_key<W, 2>(e[u]);
+                            const MinKey<W> k = mrec_key<W, I>(e[u]);
                             if (mkey_lt<W>(k, mk[u])) lo[u] = mid[u] + 1;
-                            else if (mkey_eq<W>(k, mk[u])) { const uint32_t rank = mrec_rank<W, 2>(e[u]); if (rank != INVALID) push(qs[u], rank); hi[u] = lo[u]; }
+                            else if (mkey_eq<W>(k, mk[u])) { const uint32_t rank = mrec_rank<W, I>(e[u]); if (rank != INVALID) push(qs[u], rank); hi[u] = lo[u]; }
                             else hi[u] = mid[u];
                         }
                     }
@@ -629,8 +657,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // ---- phase C: tally (itree.c:1028-1040), result records, the list of reads left to the wave-per-read kernel ----
         // (lane i < 64 / SEGS finishes read i of the grab; what its lanes could not take is in their `exc`)
         const uint64_t excm = ballot64(exc);
-        const uint32_t r = item + lane;
-        const bool have = lane < RPW && r < item_end;
+        const bool have = lane < RPW && item + lane < item_end;
+        const uint32_t r = LISTED ? (have ? lst[item + lane] : 0u) : item + lane;    // the read (PIECE: the piece)
         exc = ((excm >> ((lane * SEGS) & 63u)) & ((1ull << SEGS) - 1ull)) != 0ull || ((full[lane >> 5] >> (lane & 31u)) & 1u) != 0u || wave_full;
         if constexpr (PIECE) {
             // a piece's table is added to its read's: one lane per (piece, slot), claim-or-find the rank, add the count
@@ -643,13 +671,13 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 if (x < RPW * TSR && ((okm >> pc) & 1ull)) {
                     const uint32_t e = tab[slot * RPW + pc];
                     if (e != T_EMPTY) {
-                        const uint32_t li = pref[pc], rank = e >> 16;
+                        const uint32_t li = pref[pc], rank = e >> CB;
                         uint32_t *tr = ws.ltab_rank + (size_t)li * UTREE_LONG_SLOTS, *tc = ws.ltab_cnt + (size_t)li * UTREE_LONG_SLOTS;
                         uint32_t sidx = (rank * 0x9E3779B1u) >> 26, tries = 0;     // 64 slots, linear probing
                         for (; tries < UTREE_LONG_SLOTS; ++tries, sidx = (sidx + 1u) & (UTREE_LONG_SLOTS - 1u)) {
                             uint32_t cur = __hip_atomic_load(&tr[sidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (cur == 0xFFFFFFFFu) cur = atomicCAS(&tr[sidx], 0xFFFFFFFFu, rank);
-                            if (cur == 0xFFFFFFFFu || cur == rank) { atomicAdd(&tc[sidx], e & 0xFFFFu); break; }
+                            if (cur == 0xFFFFFFFFu || cur == rank) { atomicAdd(&tc[sidx], e & CMASK); break; }
                         }
                         if (tries == UTREE_LONG_SLOTS) ws.lflag[li] = 1u;          // more labels than the read's table holds
                     }
@@ -672,9 +700,9 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         uint32_t nu = 0, F = 0;
         if (live) {
 #pragma unroll
-            for (uint32_t i = 0; i < TSR; ++i) { const uint32_t e = tq[i * RPW]; if (e != T_EMPTY) { ++nu; F += e & 0xFFFFu; } }
+            for (uint32_t i = 0; i < TSR; ++i) { const uint32_t e = tq[i * RPW]; if (e != T_EMPTY) { ++nu; F += e & CMASK; } }
         }
-        const uint32_t first_rank = tq[0] >> 16;
+        const uint32_t first_rank = tq[0] >> CB;
         const uint32_t maxnu = uni32(wave_max_u32(nu));
         // space for the (rank, count) lists of the reads with two or more labels: one reservation per wave and TALLY_CHUNK
         const uint32_t need = nu >= 2u ? nu : 0u;
@@ -684,7 +712,12 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         const uint32_t total = uni32((uint32_t)__shfl(incl, 63));
         if (total > chunk_left) {
             unsigned long long nb = 0;
-            if (lane == 0) nb = atomicAdd(&ws.cursors[0], (unsigned long long)UTREE_TALLY_CHUNK);
+            if (lane == 0) {
+                nb = atomicAdd(&ws.cursors[0], (unsigned long long)UTREE_TALLY_CHUNK);
+                // (the workspace is sized so that this cannot happen, dev_image.c: carve; if it does, the batch is reported as failed
+                // and the wave writes into the first chunk instead of past the end)
+                if (nb + UTREE_TALLY_CHUNK > ws.tally_cap) { ws.cursors[UTREE_CUR_ERROR] = UTREE_DEVERR_TALLY_CAP; nb = 0; }
+            }
             chunk_base = uni64(nb);
             chunk_left = UTREE_TALLY_CHUNK;
         }
@@ -695,8 +728,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             for (uint32_t i = 0; i < maxnu; ++i) {
                 const uint32_t e = tq[i * RPW];
                 uint32_t place = 0;
-                for (uint32_t j = 0; j < maxnu; ++j) { const uint32_t x = tq[j * RPW]; place += (j < nu && (x >> 16) < (e >> 16)) ? 1u : 0u; }
-                if (need && i < nu) ws.tally[my_base + place] = (uint64_t)(e >> 16) | ((uint64_t)(e & 0xFFFFu) << 32);
+                for (uint32_t j = 0; j < maxnu; ++j) { const uint32_t x = tq[j * RPW]; place += (j < nu && (x >> CB) < (e >> CB)) ? 1u : 0u; }
+                if (need && i < nu) ws.tally[my_base + place] = (uint64_t)(e >> CB) | ((uint64_t)(e & CMASK) << 32);
             }
         }
         if (live) {
@@ -712,14 +745,14 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 #endif
 }
 
-template <int W, int SEGS, bool IRR, bool PIECE = false>
+template <int W, int I, int SEGS, bool IRR, int MODE = 0>
 static int launch_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
-                        int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+                        int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream, uint32_t cls = 0) {
     uint32_t blocks = (n_reads + (64u / SEGS) * LANES_WAVES - 1) / ((64u / SEGS) * LANES_WAVES);
     const uint32_t wps = W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS;
     const uint32_t cap = (uint32_t)n_cu * (4u * wps / LANES_WAVES > 0 ? 4u * wps / LANES_WAVES : 1u);
     if (blocks > cap) blocks = cap;
-    classify_lanes_k<W, SEGS, IRR, PIECE><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
+    classify_lanes_k<W, I, SEGS, IRR, MODE><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws, cls);
     return (int)hipGetLastError();
 }
 
@@ -729,12 +762,13 @@ __global__ __launch_bounds__(256) void pieces_k(const uint32_t *__restrict__ len
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
     if (i >= n_long) return;
-    if (i >= ws.n_long_cap) return;                                         // (cannot happen: the capacity is the bound on such reads)
+    if (i >= ws.n_long_cap) { ws.cursors[UTREE_CUR_ERROR] = UTREE_DEVERR_LONG_CAP; return; }   // (the capacity is the bound on such reads: a caller's total_bases was too small)
     const uint64_t L = len[ws.long_list[i]];
     const uint64_t nwin = L >= K ? L - K + 1 : 0;
     const uint32_t np = (uint32_t)((nwin + PW - 1) / PW);
     if (!np) return;
     const unsigned long long at = atomicAdd(&ws.cursors[UTREE_CUR_PIECES], (unsigned long long)np);
+    if (at + np > ws.n_pieces_cap) { ws.cursors[UTREE_CUR_ERROR] = UTREE_DEVERR_PIECES_CAP; return; }
     for (uint32_t p = 0; p < np; ++p) ws.pieces[at + p] = ((uint64_t)i << 32) | p;
 }
 
@@ -772,11 +806,61 @@ __global__ __launch_bounds__(256) void finish_long_k(utree_result *__restrict__ 
 // what classify_long_k is left with: its list is ws.long_left from here on, its count takes the place of the long-read count
 __global__ void left_count_k(utk_workspace ws) { ws.cursors[UTREE_CUR_LONG] = ws.cursors[UTREE_CUR_LEFT]; }
 
+// lanes_route_k: a batch whose reads differ in length is split by the number of lanes a read needs -- class c: 2^c lanes, reads of
+// up to cap[c] bases -- and every class goes through the instantiation for its size (MODE 1); reads beyond sixteen lanes, or whose
+// two strands would not fit the wave-per-read pass that finishes what this pass leaves (mid_cap staged bases), are listed as long and
+// go through in pieces.  One atomic per class and 64 reads.
+struct lane_caps { uint32_t cap[5]; uint32_t mid_cap; };
+__global__ __launch_bounds__(256) void lanes_route_k(const uint32_t *__restrict__ len, uint32_t n_reads, int do_rc, utk_workspace ws, lane_caps lc) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = lane_id();
+    uint32_t c = 6;                                                         // no read
+    if (r < n_reads) {
+        const uint32_t L = len[r];
+        const uint64_t staged = do_rc ? 2ull * L + 1 : L;
+        c = L <= lc.cap[0] ? 0u : L <= lc.cap[1] ? 1u : L <= lc.cap[2] ? 2u : L <= lc.cap[3] ? 3u : L <= lc.cap[4] ? 4u : 5u;
+        if (c && staged > lc.mid_cap) c = 5;
+    }
+#pragma unroll
+    for (uint32_t v = 0; v < 6; ++v) {
+        const uint64_t m = ballot64(c == v);
+        if (!m) continue;
+        unsigned long long base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&ws.cursors[v < 5 ? UTREE_CUR_CLASS + v : UTREE_CUR_LONG], (unsigned long long)__popcll(m));
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), (int)__builtin_ctzll(m)) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+        if (c == v) {
+            const unsigned long long at = base + lanes_below(m);
+            if (v < 5) ws.cls_list[(size_t)v * ws.cls_stride + at] = r; else ws.long_list[at] = r;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
-int utk_lanes_image_ok(const utk_image *im) { return (im->W == 8 || im->W == 16) && im->I == 2 && im->irr_n <= 4u; }
+// images this pass takes: k = 32 with u16 or u32 labels (u32: fewer than 2^19 - 1 of them, a tally slot keeps 19 bits of rank), k = 64 with
+// u16 labels; a table with at most four irregular bins; buckets on 128-byte boundaries
+int utk_lanes_image_ok(const utk_image *im) {
+    const bool fmt = (im->W == 8 && (im->I == 2 || (im->I == 4 && im->n_labels < (1u << 19) - 1u))) || (im->W == 16 && im->I == 2);
+    return fmt && im->irr_n <= 4u && ((uintptr_t)im->table & 127u) == 0;
+}
+
+// reads of up to this many bases take 2^c lanes (c = 0 .. 4)
+static uint32_t lanes_cap(const utk_image *im, int c) { return ((1u << c) - 1u) * (LCAP - 4u * im->W + 1u) + LCAP; }
+uint32_t utk_lanes_max_len(const utk_image *im) { return lanes_cap(im, 4); }
+
+#define LANES_DISPATCH(SEGS_, MODE_, ...) do { \
+    if (im->W == 16) return im->irr_n ? launch_lanes<16, 2, SEGS_, true, MODE_>(__VA_ARGS__) : launch_lanes<16, 2, SEGS_, false, MODE_>(__VA_ARGS__); \
+    if (im->I == 4) return im->irr_n ? launch_lanes<8, 4, SEGS_, true, MODE_>(__VA_ARGS__) : launch_lanes<8, 4, SEGS_, false, MODE_>(__VA_ARGS__); \
+    return im->irr_n ? launch_lanes<8, 2, SEGS_, true, MODE_>(__VA_ARGS__) : launch_lanes<8, 2, SEGS_, false, MODE_>(__VA_ARGS__); } while (0)
+
+static int lanes_pieces_launch(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, int do_rc,
+                               utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+    // (the grid of the pieces pass is the resident one: the number of pieces is on the device)
+    LANES_DISPATCH(16, 2, im, d_bases, d_off, d_len, 0x40000000u, do_rc, d_out, ws, n_cu, stream);
+}
 
 int utk_classify_long_pieces(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, int do_rc,
                              utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
@@ -784,46 +868,60 @@ int utk_classify_long_pieces(const utk_image *im, const uint8_t *d_bases, const 
     const uint32_t K = 4u * im->W, PW = 16u * (LCAP - K + 1u);
     hipStream_t st = (hipStream_t)stream;
     pieces_k<<<dim3((ws->n_long_cap + 255) / 256), dim3(256), 0, st>>>(d_len, K, PW, *ws);
-    // (the grid of the pieces pass is the resident one: the number of pieces is on the device)
-    const uint32_t many = 0x40000000u;
-    int rc;
-    if (im->W == 16) rc = im->irr_n ? launch_lanes<16, 16, true, true>(im, d_bases, d_off, d_len, many, do_rc, d_out, ws, n_cu, stream)
-                                    : launch_lanes<16, 16, false, true>(im, d_bases, d_off, d_len, many, do_rc, d_out, ws, n_cu, stream);
-    else rc = im->irr_n ? launch_lanes<8, 16, true, true>(im, d_bases, d_off, d_len, many, do_rc, d_out, ws, n_cu, stream)
-                        : launch_lanes<8, 16, false, true>(im, d_bases, d_off, d_len, many, do_rc, d_out, ws, n_cu, stream);
+    int rc = lanes_pieces_launch(im, d_bases, d_off, d_len, do_rc, d_out, ws, n_cu, stream);
     if (rc) return rc;
     { uint32_t fb = (ws->n_long_cap + 3) / 4, fcap = (uint32_t)n_cu * 8u; finish_long_k<<<dim3(fb < fcap ? fb : fcap), dim3(256), 0, st>>>(d_out, *ws); }
     left_count_k<<<dim3(1), dim3(1), 0, st>>>(*ws);
     return (int)hipGetLastError();
 }
 
-// The image and batch this kernel takes: k = 32 or 64, u16 labels, a table with at most four irregular bins, and no read longer than
-// sixteen lanes hold (2095 bases for k = 32, 1615 for k = 64), either strand mode.
+// A batch this pass takes whole with ONE instantiation, no routing: every read within one lane (LCAP bases).
 int utk_lanes_ok(const utk_image *im, uint32_t max_len, int do_rc) {
     (void)do_rc;
-    if (!((im->W == 8 || im->W == 16) && im->I == 2) || im->irr_n > 4u) return 0;       // (more irregular bins than the kernel tests for, or every bin)
-    return max_len <= 15u * (LCAP - 4u * im->W + 1u) + LCAP;
+    return utk_lanes_image_ok(im) && max_len <= LCAP;
 }
 
-// lanes per read for a batch whose longest read has max_len bases (1, 2, 4, 8, 16)
+// lanes per read for a read of max_len bases (1, 2, 4, 8, 16)
 int utk_lanes_segs(const utk_image *im, uint32_t max_len) {
-    const uint32_t sw = LCAP - 4u * im->W + 1u;
-    return max_len <= LCAP ? 1 : max_len <= sw + LCAP ? 2 : max_len <= 3u * sw + LCAP ? 4 : max_len <= 7u * sw + LCAP ? 8 : 16;
+    for (int c = 0; c < 4; ++c) if (max_len <= lanes_cap(im, c)) return 1 << c;
+    return 16;
 }
 
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                        uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     if (!n_reads) return 0;
-    const int segs = utk_lanes_segs(im, max_len);
-#define GO(W_, S_) return im->irr_n ? launch_lanes<W_, S_, true>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream) \
-                                   : launch_lanes<W_, S_, false>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream)
-    if (im->W == 16) { if (segs == 1) GO(16, 1); if (segs == 2) GO(16, 2); if (segs == 4) GO(16, 4); if (segs == 8) GO(16, 8); GO(16, 16); }
-    if (segs == 1) GO(8, 1);
-    if (segs == 2) GO(8, 2);
-    if (segs == 4) GO(8, 4);
-    if (segs == 8) GO(8, 8);
-    GO(8, 16);
-#undef GO
+    if (max_len > LCAP) return (int)hipErrorInvalidValue;
+    LANES_DISPATCH(1, 0, im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream);
+}
+
+static int lanes_class_launch(const utk_image *im, int c, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
+                              int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+    // (the number of reads of a class is on the device: the grid is what n_reads could fill, at most the resident one)
+    switch (c) {
+    case 0: LANES_DISPATCH(1, 1, im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, 0u);
+    case 1: LANES_DISPATCH(2, 1, im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, 1u);
+    case 2: LANES_DISPATCH(4, 1, im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, 2u);
+    case 3: LANES_DISPATCH(8, 1, im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, 3u);
+    default: LANES_DISPATCH(16, 1, im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, 4u);
+    }
+}
+
+// A batch of mixed lengths: reads are listed by the lanes they need (lanes_route_k; longer ones on ws->long_list for the pieces pass) and
+// every class that can hold a read of the batch runs as its own launch.
+int utk_classify_lanes_mixed(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
+                             uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
+    if (!n_reads) return 0;
+    if (!ws->cls_list) return (int)hipErrorInvalidValue;
+    lane_caps lc;
+    for (int c = 0; c < 5; ++c) lc.cap[c] = lanes_cap(im, c);
+    lc.mid_cap = UTREE_MID_CAP;
+    lanes_route_k<<<dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(d_len, n_reads, do_rc, *ws, lc);
+    int rc = (int)hipGetLastError();
+    for (int c = 0; c < 5 && !rc; ++c) {
+        if (c && max_len <= lc.cap[c - 1]) break;                          // no read of the batch needs this many lanes
+        rc = lanes_class_launch(im, c, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream);
+    }
+    return rc;
 }
 
 #ifdef UTREE_LANES_TIMERS

@@ -232,6 +232,7 @@ static void *gpu_main(void *arg) {
         for (size_t g = 0; g < n_dev && nr; ++g) {
             HIPOK(hipSetDevice(P->G[g].dev->device));
             HIPOK(hipStreamSynchronize(P->G[g].stream));
+            if (!P->rank) { int pe = utree_classify_poll(P->G[g].dev); if (pe) { set_error(P, pe); return NULL; } }   /* the batches' error words */
         }
         P->t_gpu += now_s() - t0;
         int last = s->last;

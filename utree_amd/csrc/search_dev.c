@@ -290,6 +290,7 @@ static void *lane_main(void *arg) {
         double t3 = now_s();
         L->t_classify += t3 - t2;
         const utk_text_meta m2 = *b->h_meta;
+        if (nr) { int pe = utree_classify_poll(L->dev); if (pe) { dfail(P, pe); return NULL; } }   /* the batch's error word came back with it */
         if (m2.flags || m2.out_bytes > DOUT_BYTES) { dfail(P, UTREE_RETRY_HOST); return NULL; }
         if (nr && m2.out_bytes) {
             LK(utk_text_format(&L->dev->kimg, ((struct utree_search_ctx *)L->dev->search_ctx)->d_ix2rank, b->d_in, b->d_res, b->d_name_off,

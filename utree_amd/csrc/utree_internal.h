@@ -13,6 +13,8 @@ extern "C" {
 #define UTREE_INVALID 0xFFFFFFFFu
 #define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
 #define UTREE_IMG_HEADER_BYTES 4096u
+#define UTREE_IMG_VERSION 9u                     /* 9: a bucket is a 128-byte line; any number of buckets per hash region */
+#define UTREE_REGION_NB_BITS 25                  /* regions[r] = base_r << 25 | nb_r (nb_r <= 2^24)                    */
 #define UTREE_TALLY_CHUNK 8192u                  /* tally entries a wave reserves with one atomic              */
 #define UTREE_CUR_LONG 32                        /* cursors[] index of the long-read counter (own 256-B line)   */
 #define UTREE_CUR_MID 16                         /* ... of the mid-length-read counter                           */
@@ -26,7 +28,14 @@ extern "C" {
 #define UTREE_WORK_STRIDE 16                     /* 8-byte words between two counters                            */
 #define UTREE_CUR_PIECES 8                       /* ... of the pieces of long reads listed for the lane-per-read pass */
 #define UTREE_CUR_LEFT 24                        /* ... of the long reads that pass left to classify_long_k            */
-#define UTREE_CURSOR_BYTES (512 + 3 * UTREE_WORK_PARTS * UTREE_WORK_STRIDE * 8)   /* cursors[] + part counters (main, mid, pieces) */
+#define UTREE_CUR_CLASS 9                        /* ... [9 .. 13]: reads of a mixed batch that take 1, 2, 4, 8, 16 lanes (lanes_route_k) */
+#define UTREE_CUR_ERROR 17                       /* ... the batch's error word (UTREE_DEVERR_*; next to UTREE_CUR_MID: both come back in one copy) */
+#define UTREE_CURSOR_BYTES (512 + 8 * UTREE_WORK_PARTS * UTREE_WORK_STRIDE * 8)   /* cursors[] + part counters (main, mid, pieces, five lane classes) */
+/* what a kernel found that the workspace's sizing rules out (utree_classify_batch's caller gave a wrong total_bases / max_len, or a
+ * test hook shrank the workspace): the batch's results are not to be used -- utree_classify_poll reports UTREE_E_DEVICE */
+#define UTREE_DEVERR_TALLY_CAP 1ull              /* (rank, count) lists beyond tally_cap                               */
+#define UTREE_DEVERR_LONG_CAP 2ull               /* more long reads than n_long_cap                                    */
+#define UTREE_DEVERR_PIECES_CAP 3ull             /* more pieces of long reads than n_pieces_cap                        */
 #define UTREE_LONG_SLOTS 64u                     /* {rank, count} slots of a long read's tally table in HBM (pieces mode) */
 #define UTREE_SHORT_CAP 320u                     /* staged bases (incl. RC) the wave-per-read kernel holds      */
 #define UTREE_SHORT2_CAP 640u                    /* ... its second size: 250-300 bp reads with the reverse strand */
@@ -45,21 +54,22 @@ typedef struct {
     uint32_t version, W, I, k;
     uint32_t fine_bits, rec_words, n_labels, flags;
     uint64_t n_nodes;
-    uint64_t n_slots;                /* 64-byte buckets in the table (sum over the 256 hash regions)        */
+    uint64_t n_slots;                /* 128-byte buckets in the table (sum over the 256 hash regions)       */
     uint64_t n_min;                  /* MIN records = nodes the bin table reaches                          */
     uint64_t off_table, off_mrecs, off_recs, off_coarse, off_irreg, off_label_off, off_label_blob, off_rank2ix;
     uint64_t label_blob_bytes;
     uint64_t n_irregular;
     uint64_t total_bytes;
-    /* Bucket addressing: region r = top 8 bits of the minimizer hash h; bucket = (regions[r] >> 8) + ((h & 0xFFFFFF) >> s)
-     * with s = regions[r] & 0xFF <= 8, and the low s bits of h go into the record key.  The hash is a MINIMUM of K-15
-     * hashes, so nodes crowd towards h = 0: low regions get one bucket per hash value, high regions up to 256. */
+    /* Bucket addressing: region r = top 8 bits of the minimizer hash h; regions[r] = base_r << 25 | nb_r and
+     * bucket = base_r + (((h & 0xFFFFFF) * nb_r) >> 24) with 2^16 <= nb_r <= 2^24 buckets in the region, so a bucket spans at most
+     * 256 consecutive hash values and the low 8 bits of h go into the record key.  The hash is a MINIMUM of K-15 hashes, so
+     * nodes crowd towards h = 0: every region gets the number of buckets its expected share of the nodes asks for. */
     uint64_t regions[256];
 } utree_image_header;
 
 /* What kernels take by value. */
 typedef struct {
-    const uint64_t *table;           /* 64-byte buckets: 8 / rec_words entries each, ascending by key; see regions[] */
+    const uint64_t *table;           /* 128-byte buckets: 16 / rec_words entries each, ascending by key; see regions[] */
     const uint64_t *regions;         /* [256] in the image header                                              */
     const uint64_t *mrecs;           /* MIN records: nodes ordered by (minimizer hash, position, rest)        */
     const uint64_t *recs;            /* FILE records: nodes as the file orders them (exact-probe path only)   */
@@ -85,7 +95,7 @@ int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_
 int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
                  uint32_t *d_irreg, unsigned long long *d_counters, void *stream);
 int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
-                  const uint64_t *d_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
+                  const uint64_t *d_regions, const uint64_t *h_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
                   unsigned long long *d_overflow, void *stream);
 int utk_compact_overflow(uint32_t W, uint32_t I, uint64_t *d_table, uint64_t n_buckets, uint64_t *d_mrecs, uint64_t *n_kept, void *stream);
 int utk_compress_chunk(uint32_t W, uint32_t I, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
@@ -111,6 +121,10 @@ typedef struct {
     uint32_t *lflag;                 /* per long_list entry: 1 = left to classify_long_k                        */
     uint32_t *long_left;             /* the reads so left                                                       */
     uint32_t n_long_cap;             /* long_list entries the tables above hold                                  */
+    uint64_t n_pieces_cap;           /* entries of `pieces`                                                      */
+    /* a batch of mixed read lengths through the lane-per-read pass: reads listed by the lanes they need (class c: 2^c lanes) */
+    uint32_t *cls_list;              /* [5][cls_stride]; NULL: the batch is not routed                           */
+    uint32_t cls_stride;
     uint64_t ltally_base;            /* ws.tally index of the long reads' (rank, count) lists: UTREE_LONG_SLOTS each */
 } utk_workspace;
 
@@ -127,6 +141,10 @@ int utk_classify_long_pieces(const utk_image *im, const uint8_t *d_bases, const 
                              utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                        uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
+/* a batch of mixed lengths: routed by lanes per read, one launch per class; reads beyond sixteen lanes end up on ws->long_list */
+int utk_classify_lanes_mixed(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
+                             uint32_t max_len, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
+uint32_t utk_lanes_max_len(const utk_image *im);                 /* longest read sixteen lanes hold */
 int utk_route(const uint32_t *d_len, uint32_t n_reads, int do_rc, const utk_workspace *ws, void *stream);
 int utk_classify_mid(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len,
                      uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);

@@ -28,20 +28,24 @@ template <int W, int I> static __device__ uint32_t min_find(const uint64_t *mrec
     return INVALID;
 }
 
-// A bucket = 64 bytes = BUCKET_CAP entries, ascending by key, unused ones flagged empty; when more nodes fall into a
-// bucket its last entry is an overflow descriptor instead (rare: ~1 % of buckets at the design load).
-template <int W, int I> struct BucketOf { static constexpr int CAP = 8 / RecTraits<W, I>::EW; };
+// A bucket = one 128-byte line = RecTraits::CAP entries, ascending by key and filled from entry 0, unused ones flagged empty; when more
+// nodes fall into a bucket its LAST entry is an overflow descriptor instead.  The wave-per-read kernels take a bucket one 64-byte HALF
+// at a time (16 registers, what they have room for): the lower half first, the upper half -- the same line: an L1 / L2 hit -- only when
+// the lower half is full and did not hold the key.  (The lane-per-read pass, lanes_kernel.hip, fetches the whole line with a quad of
+// lanes.)
+template <int W, int I> struct BucketOf { static constexpr int CAP = RecTraits<W, I>::HCAP; };   // entries of a half
 template <int W, int I> struct Bucket { Entry<W, I> e[BucketOf<W, I>::CAP]; };
 
+// lower half of bucket `bucket` of the table
 template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket(const uint64_t *__restrict__ table, uint64_t bucket) {
     Bucket<W, I> b;
-    constexpr int CAP = BucketOf<W, I>::CAP;
+    constexpr int HCAP = BucketOf<W, I>::CAP;
 #pragma unroll
-    for (int i = 0; i < CAP; ++i) b.e[i] = load_slot<W, I>(table, bucket * CAP + i);      // contiguous: 16-byte non-temporal loads
+    for (int i = 0; i < HCAP; ++i) b.e[i] = load_slot<W, I>(table, bucket * (2 * HCAP) + i);   // contiguous: 16-byte non-temporal loads
     return b;
 }
 
-// The bucket at a byte address computed from the LDS region table: the address space is stated (global), or the loads would be
+// The 64 bytes at a byte address computed from the LDS region table: the address space is stated (global), or the loads would be
 // flat ones.  Default cache policy on purpose: the four 16-byte loads of a lane -- and those of the ~9 lanes whose windows share
 // the bucket -- then merge in the L1's miss queue into one request to the L2; with the non-temporal policy (which serves single
 // 8-byte random reads best, load_slot) every one of the four instructions went to the L2 on its own (TCC_HIT 3x TCC_MISS) and the
@@ -51,18 +55,18 @@ template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket_at(u
     typedef const __attribute__((address_space(1))) u64x2 *gptr;
     const gptr p = (gptr)addr;
     Bucket<W, I> b;
-    constexpr int EW = RecTraits<W, I>::EW, CAP = 8 / EW;
+    constexpr int EW = RecTraits<W, I>::EW, HCAP = BucketOf<W, I>::CAP;
     u64x2 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = p[q];
 #pragma unroll
-    for (int i = 0; i < CAP; ++i)
+    for (int i = 0; i < HCAP; ++i)
 #pragma unroll
         for (int x = 0; x < EW; ++x) { const int w = i * EW + x; b.e[i].w[x] = (w & 1) ? v[w >> 1].y : v[w >> 1].x; }
     return b;
 }
 
-// The 8 entries of a k = 32 / u16-label bucket against (tag = hash bits the bucket does not imply << 5 | minimizer position, rest):
+// The 8 entries of half a k = 32 / u16-label bucket against (tag = hash low bits << 5 | minimizer position, rest):
 // an entry's low word is its rest, its high word {flag2 | 0 | tag13 | rank16}.  One compare and one select per entry pick the
 // high word of the entry whose rest matches; the tag (and with it the flag: 0 = a record) is checked once.  Two entries with
 // the same rest and different tags are possible (the same 16 outer bases around a minimizer at two positions): then, and when
@@ -81,11 +85,35 @@ __device__ __forceinline__ uint32_t scan_bucket82(const Bucket<8, 2> &b, uint32_
     return rank == 0xFFFFu ? INVALID : rank;
 }
 
-// Second half of a lookup, given the bucket of the word's minimizer.  Words whose 24-bit bin is not strictly ascending
-// (COMPRESS' first-bin quirk) or any word of a non-monotone table take the reference's own probe sequence over the FILE
-// records instead: only that reproduces its answers there.
+// the rank a half holds for the key, or INVALID
+template <int W, int I> __device__ __forceinline__ uint32_t scan_half(const Bucket<W, I> &b, const MinKey<W> &mk) {
+    constexpr int HCAP = BucketOf<W, I>::CAP;
+    if constexpr (W == 8 && I == 2) return scan_bucket82(b, (uint32_t)(mk.lo >> 32), (uint32_t)mk.lo);
+    else {
+        // straight-line scan.  An entry is the record of `mk` exactly when its key word without the 16 label bits equals
+        // {flag 0 | mk} (an empty entry or the overflow descriptor has a non-zero flag, so neither can): one AND and one
+        // 64-bit compare per entry; the label bits of the matching entry are picked up raw and decoded once at the end.
+        constexpr int KW = RecTraits<W, I>::KW;
+        const uint64_t want = W == 16 ? mk.hi << 16 : (((mk.lo >> 32) << 48) | (mk.lo & 0xFFFFFFFFull));
+        uint32_t raw = INVALID;
+#pragma unroll
+        for (int i = 0; i < HCAP; ++i) {
+            bool hit;
+            if constexpr (W == 16) hit = (b.e[i].w[KW] & ~0xFFFFull) == want && b.e[i].w[0] == mk.lo;
+            else hit = b.e[i].w[0] == want;                                              // (k = 32, u32 labels: the rank16 field is 0)
+            raw = hit ? (uint32_t)b.e[i].w[I == 4 ? KW + 1 : KW] : raw;
+        }
+        uint32_t rank = raw;
+        if constexpr (I == 2) { rank = raw & 0xFFFFu; rank = rank == 0xFFFFu ? INVALID : rank; }
+        return rank;
+    }
+}
+
+// Second half of a lookup, given the LOWER HALF of the bucket of the word's minimizer and the bucket's address.  Words whose 24-bit
+// bin is not strictly ascending (COMPRESS' first-bin quirk) or any word of a non-monotone table take the reference's own probe
+// sequence over the FILE records instead: only that reproduces its answers there.
 template <int W, int I, bool EXC, typename OFF>
-__device__ __forceinline__ uint32_t resolve_bucket(const utk_image &im, const Bucket<W, I> &b, const MinKey<W> &mk, uint64_t khi,
+__device__ __forceinline__ uint32_t resolve_bucket(const utk_image &im, const Bucket<W, I> &b, uint64_t baddr, const MinKey<W> &mk, uint64_t khi,
                                                    uint64_t klo) {
     if constexpr (EXC) {
         const uint32_t p = word_prefix<W>(khi, klo);
@@ -96,50 +124,26 @@ __device__ __forceinline__ uint32_t resolve_bucket(const utk_image &im, const Bu
             return exact_probe<W, I>(im.recs, s, e, word_suffix<W>(khi, klo));
         }
     }
-    constexpr int CAP = BucketOf<W, I>::CAP;
-    uint32_t rank;
-    if constexpr (W == 8 && I == 2) rank = scan_bucket82(b, (uint32_t)(mk.lo >> 32), (uint32_t)mk.lo);
-    else {
-        // straight-line scan.  An entry is the record of `mk` exactly when its key word without the 16 label bits equals
-        // {flag 0 | mk} (an empty entry or the overflow descriptor has a non-zero flag, so neither can): one AND and one
-        // 64-bit compare per entry; the label bits of the matching entry are picked up raw and decoded once at the end.
-        constexpr int KW = RecTraits<W, I>::KW;
-        const uint64_t want = (W == 16 ? mk.hi : mk.lo) << 16;
-        uint32_t raw = INVALID;
-#pragma unroll
-        for (int i = 0; i < CAP; ++i) {
-            bool hit = (b.e[i].w[KW] & ~0xFFFFull) == want;
-            if constexpr (W == 16) hit = hit && b.e[i].w[0] == mk.lo;
-            raw = hit ? (uint32_t)b.e[i].w[I == 4 ? KW + 1 : KW] : raw;
+    constexpr int HCAP = BucketOf<W, I>::CAP;
+    uint32_t rank = scan_half<W, I>(b, mk);
+    if (rank == INVALID && mrec_flag<W, I>(b.e[HCAP - 1]) != 1) {                         // the lower half is full: the upper one
+        const Bucket<W, I> u = load_bucket_at<W, I>(baddr + 64);
+        rank = scan_half<W, I>(u, mk);
+        if (mrec_flag<W, I>(u.e[HCAP - 1]) == 2 && rank == INVALID) {                      // the rest of the bucket's nodes
+            const uint64_t d = u.e[HCAP - 1].w[RecTraits<W, I>::KW];
+            const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull;
+            rank = min_find<W, I>(im.mrecs, start, start + n, mk);
         }
-        rank = raw;
-        if constexpr (I == 2) { rank = raw & 0xFFFFu; rank = rank == 0xFFFFu ? INVALID : rank; }
-    }
-    if (mrec_flag<W, I>(b.e[CAP - 1]) == 2 && rank == INVALID) {                          // the rest of the bucket's nodes
-        const uint64_t d = b.e[CAP - 1].w[RecTraits<W, I>::KW];
-        const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull;
-        rank = min_find<W, I>(im.mrecs, start, start + n, mk);
     }
     return rank;
 }
 
-// The same for k = 32 from the window loop's pieces (no 64-bit key is assembled on the common path).
+// The same for k = 32 from the window loop's pieces.
 template <int I, bool EXC, typename OFF>
-__device__ __forceinline__ uint32_t resolve_bucket8(const utk_image &im, const Bucket<8, I> &b, uint32_t hlow, uint32_t pos, uint32_t rest,
+__device__ __forceinline__ uint32_t resolve_bucket8(const utk_image &im, const Bucket<8, I> &b, uint64_t baddr, uint32_t hlow, uint32_t pos, uint32_t rest,
                                                     uint32_t x0, uint32_t x1) {
-    if constexpr (I == 2 && !EXC) {
-        uint32_t rank = scan_bucket82(b, (hlow << 5) | pos, rest);
-        if (mrec_flag<8, 2>(b.e[7]) == 2 && rank == INVALID) {                              // the rest of the bucket's nodes
-            const uint64_t d = b.e[7].w[0];
-            const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull;
-            MinKey<8> mk; mk.hi = 0; mk.lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
-            rank = min_find<8, 2>(im.mrecs, start, start + n, mk);
-        }
-        return rank;
-    } else {
-        MinKey<8> mk; mk.hi = 0; mk.lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
-        return resolve_bucket<8, I, EXC, OFF>(im, b, mk, 0ull, ((uint64_t)x0 << 32) | x1);
-    }
+    MinKey<8> mk; mk.hi = 0; mk.lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
+    return resolve_bucket<8, I, EXC, OFF>(im, b, baddr, mk, 0ull, ((uint64_t)x0 << 32) | x1);
 }
 
 template <int W, int I, bool EXC, typename OFF>
@@ -147,7 +151,7 @@ __device__ __forceinline__ uint32_t lookup_word(const utk_image &im, uint64_t kh
     uint64_t bucket; MinKey<W> mk;
     min_split<W>(khi, klo, im.regions, bucket, mk);
     const Bucket<W, I> b = load_bucket<W, I>(im.table, bucket);
-    return resolve_bucket<W, I, EXC, OFF>(im, b, mk, khi, klo);
+    return resolve_bucket<W, I, EXC, OFF>(im, b, (uint64_t)(uintptr_t)im.table + bucket * BUCKET_BYTES, mk, khi, klo);
 }
 
 // ------------------------------------------------------------------------------------------------

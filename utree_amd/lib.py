@@ -17,7 +17,7 @@ BUILD_GG_CLI_PATH = os.path.join(_HERE, "utree-buildGG")
 BUILD_CLI_PATH = os.path.join(_HERE, "utree-build")
 _LIB = None
 
-OK, E_IO, E_FORMAT, E_UNSUPPORTED, E_NOMEM, E_HIP, E_ARG, E_NOLABELS, E_FASTA, E_RCCL, E_BUILD = range(11)
+OK, E_IO, E_FORMAT, E_UNSUPPORTED, E_NOMEM, E_HIP, E_ARG, E_NOLABELS, E_FASTA, E_RCCL, E_BUILD, E_DEVICE = range(12)
 BUILD_E_MAP_EMPTY, BUILD_E_MAP, BUILD_E_FASTA, BUILD_E_NO_KMERS, BUILD_E_NAME = range(1, 6)
 FINE_AUTO = -1
 INPUT_REFERENCE, INPUT_FASTQ, INPUT_FASTA_MULTILINE, INPUT_AUTO = range(4)
@@ -93,6 +93,7 @@ SYMBOLS = {
     "utree_classify_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int]),
     "utree_classify_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                        C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "utree_classify_poll": (C.c_int, [C.c_void_p]),
     "utree_lookup_words": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "utree_classify_kernel_name": (C.c_char_p, [C.c_void_p]),
     "utree_model_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),

@@ -251,6 +251,11 @@ class DeviceTree:
                                                     workspace.numel(), stream), "utree_classify_batch")
         return out
 
+    def poll(self):
+        """utree_classify_poll: raises UtreeError(E_DEVICE) if a batch that has finished since the last call found its workspace
+        too small (call after the stream has drained; its results are not to be used)."""
+        _lib.check(_lib.load().utree_classify_poll(self._h), "utree_classify_poll")
+
     def rank_search(self, bases, off, length, rc: bool = False, slack: int = 2, sparsity: int = 4, tolerance: int = 2,
                     total_bases: Optional[int] = None, max_len: Optional[int] = None, out=None):
         """One batch of the rank-specific search (`xtree-search`, itree.c:969-1007).  Batches must come in file
@@ -365,5 +370,6 @@ def classify_fasta_bytes(db: CtrDB, tree: DeviceTree, data: bytes, rc: bool = Fa
     res = tree.classify(d_buf, d_off, d_len, rc=rc, total_bases=int(fr["seq_len"].sum()),
                         max_len=int(fr["seq_len"].max()))
     torch.cuda.synchronize()
+    tree.poll()
     h = res.cpu().numpy()
     return db.format(buf, fr["name_off"], fr["name_len"], h)
