@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UTREE_ABI_VERSION 2
+#define UTREE_ABI_VERSION 3
 
 enum {
     UTREE_OK = 0,
@@ -111,6 +111,10 @@ typedef struct {
                                    with the reference's exact probe sequence                             */
     uint32_t generic_mode;      /* 1: bin table not monotone -> every lookup uses the exact probe path   */
     int32_t  device;
+    uint32_t vote_table;        /* 1: the image carries the label table the vote decides from (every label
+                                   has at most 8 ';'-separated tokens and 255 bytes, 16-bit label indices)   */
+    uint32_t lane_pass;         /* 1: the lane-per-read classify kernels take this image (else the
+                                   wave-per-read kernels: k = 64 with 32-bit labels, many irregular bins)   */
 } utree_dev_info;
 int utree_dev_get_info(const utree_dev *dev, utree_dev_info *info);
 

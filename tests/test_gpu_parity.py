@@ -409,13 +409,17 @@ def test_overflowing_buckets(torch_cuda, tmp_path, run_max, monkeypatch):
         tree.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_vote_on_adversarial_label_sets(torch_cuda, seed, tmp_path):
+@pytest.mark.parametrize("seed,max_depth,table", [(1, 8, None), (2, 8, None), (3, 8, None), (4, 7, True), (5, 7, True), (6, 5, True), (4, 7, False), (6, 5, False)])
+def test_vote_on_adversarial_label_sets(torch_cuda, seed, max_depth, table, tmp_path, monkeypatch):
     """vote_k skips the levels a whole group of labels shares with ONE scan of the group's first and last label; this
     checks it (and the level loop behind it) on label sets built to sit on the vote's edges (util.adversarial_vote_case).
     Oracle = the CPU restatement, itself held against the genuine reference on the same cases
-    (test_oracle_golden.py::test_vote_adversarial_cases_oracle_vs_reference)."""
-    ctr_path, data, n_reads = util.adversarial_vote_case(seed, str(tmp_path))
+    (test_oracle_golden.py::test_vote_adversarial_cases_oracle_vs_reference).
+    Label sets of at most 8 tokens per label get the image's label table and vote_k's decisions from token ids (table=True); the same
+    sets with the table switched off (UTREE_VOTE_BYTES) and the deeper sets go through the byte scans."""
+    if table is False:
+        monkeypatch.setenv("UTREE_VOTE_BYTES", "1")
+    ctr_path, data, n_reads = util.adversarial_vote_case(seed, str(tmp_path), max_depth)
     fa = tmp_path / "r.fa"
     fa.write_bytes(data)
     o = orc.OracleDB.load(ctr_path)
@@ -424,7 +428,10 @@ def test_vote_on_adversarial_label_sets(torch_cuda, seed, tmp_path):
     assert code == 0 and nr == n_reads and good > 0
     db = CtrDB.open(ctr_path)
     tree = DeviceTree.upload(db, 0)
+    if table is not None:
+        assert tree.info.vote_table == int(table)
     assert classify_fasta_bytes(db, tree, data, rc=False) == out.read_bytes()
+    tree.close()
 
 
 @pytest.mark.parametrize("name,with_gt", [("toy", False), ("toy", True), ("k64", False), ("ix32", False), ("vote", False)])

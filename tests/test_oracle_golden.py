@@ -179,12 +179,12 @@ def test_build_matches_reference(tag, tmpdir_mod):
 
 
 @pytest.mark.skipif(not util.have_ref(), reason="needs oracle/_ref (the genuine reference, built from /root/reference by `make -C oracle ref`)")
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_vote_adversarial_cases_oracle_vs_reference(seed, tmp_path):
+@pytest.mark.parametrize("seed,max_depth", [(1, 8), (2, 8), (3, 8), (4, 7), (5, 7), (6, 5)])
+def test_vote_adversarial_cases_oracle_vs_reference(seed, max_depth, tmp_path):
     """The label sets the GPU vote is stressed with (util.adversarial_vote_case) go beyond the committed vote fixture, so
     the oracle is first held against the genuine reference binary on them, where that binary exists."""
     import subprocess
-    ctr_path, data, n_reads = util.adversarial_vote_case(seed, str(tmp_path))
+    ctr_path, data, n_reads = util.adversarial_vote_case(seed, str(tmp_path), max_depth)
     fa = tmp_path / "r.fa"
     fa.write_bytes(data)
     want = tmp_path / "ref.txt"

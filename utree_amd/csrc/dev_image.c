@@ -41,9 +41,11 @@ static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
  * hashes, so region r -- the hashes whose top 8 bits are r -- expects N ((1 - r/256)^m - (1 - (r+1)/256)^m) of the nodes.  The region
  * gets as many 128-byte buckets as bring a bucket to TARGET nodes: any number (bucket = base + ((h24 * nb) >> 24)), between 2^16 -- a
  * bucket spans at most 256 hash values: the record key has 8 bits for them -- and 2^(16+F), at most one bucket per hash value (F =
- * fine_bits: 8 = as many as the density asks, 0 = 256 values per bucket everywhere).  The default TARGET fills a bucket to 53 %:
- * config 2 (k = 32, 16 entries per bucket): 8.5 nodes, image 17 GiB, 0.1 overflowing buckets per 150 bp read. */
-#define UTREE_BUCKET_FILL 0.53
+ * fine_bits: 8 = as many as the density asks, 0 = 256 values per bucket everywhere).  The default TARGET fills a bucket to 56 %:
+ * config 2 (k = 32, 16 entries per bucket): 9 nodes, image 17.7 GiB, 0.3 overflowing buckets per 150 bp read (the dense end of the
+ * hash range has several nodes per hash VALUE, so buckets there hold the nodes of one, two or three values: a mixture, not one Poisson
+ * mean -- DESIGN.md section 3 has the sweep). */
+#define UTREE_BUCKET_FILL 0.5625
 static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32_t F, uint64_t regions[256]) {
     const double m = 4.0 * W - 15.0;
     const uint32_t cap_entries = 16u / utree_rec_words(W, I);
@@ -98,7 +100,8 @@ static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     for (uint32_t i = 0; i < h->n_labels; ++i) blob += (uint64_t)ctr->label_len[i] + 1;
     h->label_blob_bytes = blob;
     h->off_label_blob = off; off = align_up(off + blob + 64, 256);
-    h->off_rank2ix = off; off = align_up(off + (uint64_t)h->n_labels * 4, 4096);
+    h->off_rank2ix = off; off = align_up(off + (uint64_t)h->n_labels * 4, 256);
+    h->off_vote = off; off = align_up(off + (uint64_t)h->n_labels * sizeof(utk_vote_rec), 4096);
     /* last, so that an image without irregular bins can leave it out of what is broadcast */
     h->off_recs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 4096);
     h->total_bytes = off;
@@ -122,6 +125,7 @@ static void bind_image(utree_dev *d) {
     d->kimg.label_off = (const uint32_t *)(b + d->hdr.off_label_off);
     d->kimg.label_blob = b + d->hdr.off_label_blob;
     d->kimg.rank2ix = (const uint32_t *)(b + d->hdr.off_rank2ix);
+    d->kimg.vote_tab = (d->hdr.flags & UTREE_F_VOTE_TABLE) && !getenv("UTREE_VOTE_BYTES") ? (const uint64_t *)(b + d->hdr.off_vote) : NULL;
     d->kimg.n_nodes = d->hdr.n_nodes;
     d->kimg.n_labels = d->hdr.n_labels;
     d->kimg.fine_bits = d->hdr.fine_bits;
@@ -167,11 +171,58 @@ static int move_down(char *img, uint64_t dst, uint64_t src, uint64_t size, hipSt
     return 0;
 }
 
+/* utk_vote_rec of every label, rank order; 0 when some label is not of the shape the table describes (then vote_k reads label
+ * bytes, as it does for databases with 32-bit label indices) */
+static int build_vote_table(const utree_ctr *ctr, utk_vote_rec *out) {
+    const uint32_t n = ctr->info.n_labels;
+    if (!n || n > 65535u || ctr->info.I != 2) return 0;
+    /* prefixes interned in an open-addressing table: {hash, first rank with these bytes} */
+    size_t cap = 1;
+    while (cap < (size_t)n * 16) cap <<= 1;
+    uint64_t *hh = (uint64_t *)calloc(cap, sizeof(uint64_t));
+    uint32_t *hv = (uint32_t *)malloc(cap * sizeof(uint32_t)), *hl = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    int ok = hh && hv && hl;
+    for (uint32_t r = 0; ok && r < n; ++r) {
+        const uint32_t ix = ctr->rank2ix[r];
+        const char *s = ctr->labels[ix];
+        const uint32_t len = ctr->label_len[ix];
+        utk_vote_rec *v = &out[r];
+        if (len > 255u) { ok = 0; break; }
+        uint32_t t = 0;
+        uint64_t h = 1469598103934665603ull;                                    /* FNV-1a over the prefix so far */
+        for (uint32_t i = 0; i <= len; ++i) {
+            if (i < len && s[i] != ';') { h = (h ^ (uint8_t)s[i]) * 1099511628211ull; continue; }
+            if (i < len && s[i] == '\0') { ok = 0; break; }
+            if (t >= 8) { ok = 0; break; }                                       /* more tokens than the table has levels */
+            /* token t ends at i (';' or the label's end): intern bytes [0, i) */
+            const uint64_t key = h | 1ull;                                      /* (0 marks a free slot) */
+            size_t at = (size_t)(key * 0x9E3779B97F4A7C15ull >> 17) & (cap - 1);
+            uint32_t id = r;
+            for (;; at = (at + 1) & (cap - 1)) {
+                if (!hh[at]) { hh[at] = key; hv[at] = r; hl[at] = i; break; }
+                if (hh[at] == key && hl[at] == i && !memcmp(ctr->labels[ctr->rank2ix[hv[at]]], s, i)) { id = hv[at]; break; }
+            }
+            v->pid[t] = (uint16_t)id; v->tok_end[t] = (uint8_t)i;
+            v->exists |= (uint8_t)(1u << t);
+            if (i < len) v->more |= (uint8_t)(1u << t);
+            if (i > 0 && s[i - 1] == '_') v->us |= (uint8_t)(1u << t);
+            ++t;
+            if (i < len) h = (h ^ (uint8_t)';') * 1099511628211ull;
+        }
+        if (!ok) break;
+        v->n_tok = (uint8_t)t;
+        for (; t < 8; ++t) { v->pid[t] = 0xFFFFu; v->tok_end[t] = (uint8_t)len; }
+    }
+    free(hh); free(hv); free(hl);
+    return ok;
+}
+
 typedef struct {
     utree_dev *d;
     const utree_ctr *ctr;
     uint32_t *d_ix2rank;
     unsigned long long *d_counters;
+    unsigned long long *d_invalid;          /* nodes whose label index is >= the number of labels */
     hipStream_t stream;
 } builder;
 
@@ -218,15 +269,25 @@ static int build_begin(builder *b, const utree_ctr *ctr, int device, int fine_bi
         hipError_t e1 = hipMemcpyAsync(img + d->hdr.off_label_off, loff, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, stream);
         hipError_t e2 = hipMemcpyAsync(img + d->hdr.off_label_blob, blob, d->hdr.label_blob_bytes + 64, hipMemcpyHostToDevice, stream);
         hipError_t e3 = hipMemcpyAsync(img + d->hdr.off_rank2ix, ctr->rank2ix, (size_t)n * 4, hipMemcpyHostToDevice, stream);
+        utk_vote_rec *vt = (utk_vote_rec *)calloc((size_t)n + 1, sizeof(utk_vote_rec));
+        hipError_t e5 = hipSuccess;
+        if (vt && build_vote_table(ctr, vt)) {
+            d->hdr.flags |= UTREE_F_VOTE_TABLE;
+            e5 = hipMemcpyAsync(img + d->hdr.off_vote, vt, (size_t)n * sizeof(utk_vote_rec), hipMemcpyHostToDevice, stream);
+        }
         hipError_t e4 = hipStreamSynchronize(stream);
-        free(loff); free(blob);
-        HIPCHK(e1); HIPCHK(e2); HIPCHK(e3); HIPCHK(e4);
+        free(loff); free(blob); free(vt);
+        HIPCHK(e1); HIPCHK(e2); HIPCHK(e3); HIPCHK(e4); HIPCHK(e5);
+        bind_image(d);
         HIPCHK(hipMalloc((void **)&b->d_ix2rank, (size_t)n * 4));
         HIPCHK(hipMemcpyAsync(b->d_ix2rank, ctr->ix2rank, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMalloc((void **)&b->d_invalid, 8));
+        HIPCHK(hipMemsetAsync(b->d_invalid, 0, 8, stream));
     }
     return UTREE_OK;
 fail:
     if (b->d_ix2rank) hipFree(b->d_ix2rank);
+    if (b->d_invalid) hipFree(b->d_invalid);
     if (d->owns && d->image) hipFree(d->image);
     if (d->rank_state) hipFree(d->rank_state);
     if (d->lanes_ring) hipHostFree((void *)d->lanes_ring);
@@ -239,7 +300,7 @@ fail:
 static int build_chunk(builder *b, const void *d_raw, uint64_t first, uint64_t count) {
     utree_dev *d = b->d;
     uint64_t *recs = (uint64_t *)((char *)d->image + d->hdr.off_recs) + first * d->hdr.rec_words;
-    int e = utk_repack(d->hdr.W, d->hdr.I, d_raw, count, b->d_ix2rank, d->hdr.n_labels, recs, b->stream);
+    int e = utk_repack(d->hdr.W, d->hdr.I, d_raw, count, b->d_ix2rank, d->hdr.n_labels, recs, b->d_invalid, b->stream);
     if (e) { utree_dev_set_hip_error(e, "utk_repack"); return UTREE_E_HIP; }
     return UTREE_OK;
 }
@@ -253,7 +314,8 @@ static int build_finish(builder *b, const void *d_binix_raw) {
     uint64_t *recs = (uint64_t *)(img + d->hdr.off_recs);
     void *coarse = img + d->hdr.off_coarse;
     const int off64 = (d->hdr.flags & UTREE_F_OFF64) != 0;
-    unsigned long long counters[2] = {0, 0};
+    unsigned long long counters[2] = {0, 0}, invalid = 0;
+    HIPCHK(hipMemcpyAsync(&invalid, b->d_invalid, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMalloc((void **)&b->d_counters, 16));
     HIPCHK(hipMemsetAsync(b->d_counters, 0, 16, st));
     KCHK(utk_fill_recs_pad(recs + d->hdr.n_nodes * d->hdr.rec_words, 8 * d->hdr.rec_words, st));
@@ -264,6 +326,7 @@ static int build_finish(builder *b, const void *d_binix_raw) {
     HIPCHK(hipStreamSynchronize(st));
     if (timing_on()) fprintf(stderr, "[utree_amd] image: bin table checked (%llu irregular bins%s)\n", counters[0], counters[1] ? ", not monotone" : "");
     d->hdr.n_irregular = counters[0];
+    if (invalid) d->hdr.flags |= UTREE_F_INVALID_RANKS;
     uint64_t full_bytes = d->hdr.total_bytes;
     if (counters[1]) {
         /* bin table not monotone (never written by the reference's COMPRESS): trust it verbatim like the
@@ -306,6 +369,7 @@ static int build_finish(builder *b, const void *d_binix_raw) {
             utree_image_header *h = &d->hdr;
             const uint64_t coarse_b = (uint64_t)UTREE_NUMBINS * ((o.flags & UTREE_F_OFF64) ? 8 : 4), irreg_b = (1u << 24) / 8;
             const uint64_t loff_b = ((uint64_t)o.n_labels + 1) * 4, blob_b = o.label_blob_bytes + 64, r2i_b = (uint64_t)o.n_labels * 4;
+            const uint64_t vote_b = (uint64_t)o.n_labels * sizeof(utk_vote_rec);
             const uint64_t recs_b = (o.n_nodes + 8) * o.rec_words * 8;
             uint64_t off = align_up(o.off_mrecs + (kept + 8) * o.rec_words * 8, 4096);
             h->n_min = kept;
@@ -313,13 +377,14 @@ static int build_finish(builder *b, const void *d_binix_raw) {
             h->off_irreg = off; off = align_up(off + irreg_b, 256);
             h->off_label_off = off; off = align_up(off + loff_b, 256);
             h->off_label_blob = off; off = align_up(off + blob_b, 256);
-            h->off_rank2ix = off; off = align_up(off + r2i_b, 4096);
+            h->off_rank2ix = off; off = align_up(off + r2i_b, 256);
+            h->off_vote = off; off = align_up(off + vote_b, 4096);
             h->off_recs = off;
             if (h->flags & UTREE_F_IRREGULAR) off = align_up(off + recs_b, 4096);
             h->total_bytes = off;
             if (move_down(img, h->off_coarse, o.off_coarse, coarse_b, st) || move_down(img, h->off_irreg, o.off_irreg, irreg_b, st) ||
                 move_down(img, h->off_label_off, o.off_label_off, loff_b, st) || move_down(img, h->off_label_blob, o.off_label_blob, blob_b, st) ||
-                move_down(img, h->off_rank2ix, o.off_rank2ix, r2i_b, st) ||
+                move_down(img, h->off_rank2ix, o.off_rank2ix, r2i_b, st) || move_down(img, h->off_vote, o.off_vote, vote_b, st) ||
                 ((h->flags & UTREE_F_IRREGULAR) && move_down(img, h->off_recs, o.off_recs, recs_b, st))) { rc = UTREE_E_HIP; goto fail; }
             HIPCHK(hipStreamSynchronize(st));
             if (timing_on()) fprintf(stderr, "[utree_amd] image: %llu of %llu nodes in overflow runs; packed image %.2f GiB (built in %.2f GiB)\n",
@@ -342,7 +407,8 @@ static int build_finish(builder *b, const void *d_binix_raw) {
 fail:
     if (b->d_counters) hipFree(b->d_counters);
     if (b->d_ix2rank) hipFree(b->d_ix2rank);
-    b->d_counters = NULL; b->d_ix2rank = NULL;
+    if (b->d_invalid) hipFree(b->d_invalid);
+    b->d_counters = NULL; b->d_ix2rank = NULL; b->d_invalid = NULL;
     if (rc) { utree_dev_free(d); b->d = NULL; }
     return rc;
 }
@@ -355,7 +421,7 @@ int utree_dev_build(const utree_ctr *ctr, int device, int fine_bits, const void 
     int rc = build_begin(&b, ctr, device, fine_bits, d_image, image_bytes, (hipStream_t)stream);
     if (rc) return rc;
     rc = build_chunk(&b, d_records, 0, ctr->info.n_nodes);
-    if (rc) { hipFree(b.d_ix2rank); utree_dev_free(b.d); return rc; }
+    if (rc) { hipFree(b.d_ix2rank); hipFree(b.d_invalid); utree_dev_free(b.d); return rc; }
     rc = build_finish(&b, d_binix);
     if (rc) return rc;
     *out = b.d;
@@ -424,7 +490,7 @@ fail:
         if (ev[i]) hipEventDestroy(ev[i]);
     }
     if (d_binix) hipFree(d_binix);
-    if (rc && b.d) { if (b.d_ix2rank) hipFree(b.d_ix2rank); utree_dev_free(b.d); }
+    if (rc && b.d) { if (b.d_ix2rank) hipFree(b.d_ix2rank); if (b.d_invalid) hipFree(b.d_invalid); utree_dev_free(b.d); }
     return rc;
 }
 
@@ -485,6 +551,8 @@ int utree_dev_get_info(const utree_dev *d, utree_dev_info *info) {
     info->irregular_bins = d->hdr.n_irregular;
     info->generic_mode = (d->hdr.flags & UTREE_F_GENERIC) != 0;
     info->device = d->device;
+    info->vote_table = d->kimg.vote_tab != NULL;
+    info->lane_pass = utk_lanes_image_ok(&d->kimg) != 0;
     return UTREE_OK;
 }
 

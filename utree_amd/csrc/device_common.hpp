@@ -219,10 +219,13 @@ template <int W> __device__ __forceinline__ void min_split(uint64_t khi, uint64_
 
 // MIN records / bucket entries.  flag (top 2 bits of word KW): 0 record, 1 empty entry, 2 (a bucket's LAST entry only)
 // overflow: run {count22 | start40} of the bucket's remaining records in the sorted array
-//   W=8, I=2: {flag2 | 0 | hlow8 pos5 | rank16 | rest32}    W=8, I=4: {flag2 | 0 | hlow8 pos5 | 0 | rest32}{rank32}
+//   W=8, I=2: {flag2 | hlow8 pos5 | 0 | rank16 | rest32}    W=8, I=4: {flag2 | hlow8 pos5 | 0 | 0 | rest32}{rank32}
 //   W=16,I=2: {rest lo64}{flag2 | key_hi46 | rank16}        W=16,I=4: {rest lo64}{flag2 | key_hi46 | 0}{rank32}{0}
-// (W=8, I=2 -- the common format -- keeps the 32 "rest" bits in its low word and everything else in its high word: the bucket
-// scan of the search kernels is then one 32-bit compare and one select per entry, wave_common.hpp::scan_bucket82.)
+// (W=8 keeps the 32 "rest" bits in its low word and everything else in its high word: the bucket scan of the wave-per-read kernels
+// is then one 32-bit compare and one select per entry, wave_common.hpp::scan_bucket82.  The zero bit between position and rank makes
+// `high word >> 16` both the tag {flag, hash bits, position} << 1 -- one subtract and one compare test it against a run's range of
+// tags -- and, in its low six bits, the shift 2 * position that brings a window's outer bases under the entry's rest: the lane-per-read
+// pass, lanes_kernel.hip, checks an entry with five instructions.)
 constexpr uint64_t MFLAG_EMPTY = 1ull << 62, MFLAG_RUN = 2ull << 62;
 constexpr uint64_t M46 = (1ull << 46) - 1;
 
@@ -230,7 +233,7 @@ template <int W, int I> __device__ __forceinline__ uint32_t mrec_flag(const Entr
 template <int W, int I> __device__ __forceinline__ MinKey<W> mrec_key(const Entry<W, I> &e) {
     MinKey<W> k;
     if constexpr (W == 16) { k.lo = e.w[0]; k.hi = (e.w[1] >> 16) & M46; }
-    else { k.hi = 0; k.lo = (((e.w[0] >> 48) & 0x1FFFull) << 32) | (e.w[0] & 0xFFFFFFFFull); }
+    else { k.hi = 0; k.lo = (((e.w[0] >> 49) & 0x1FFFull) << 32) | (e.w[0] & 0xFFFFFFFFull); }
     return k;
 }
 template <int W, int I> __device__ __forceinline__ uint32_t mrec_rank(const Entry<W, I> &e) {
@@ -246,7 +249,7 @@ template <int W, int I> __device__ __forceinline__ Entry<W, I> make_mrec(const M
     for (int j = 0; j < RecTraits<W, I>::EW; ++j) e.w[j] = 0;
     const uint64_t r16 = (I == 2) ? (rank == INVALID ? 0xFFFFull : (uint64_t)(rank & 0xFFFFu)) : 0ull;
     if constexpr (W == 16) { e.w[0] = k.lo; e.w[1] = (k.hi << 16) | r16; }
-    else { e.w[0] = ((k.lo >> 32) << 48) | (r16 << 32) | (k.lo & 0xFFFFFFFFull); }
+    else { e.w[0] = ((k.lo >> 32) << 49) | (r16 << 32) | (k.lo & 0xFFFFFFFFull); }
     if constexpr (I == 4) e.w[RecTraits<W, I>::KW + 1] = rank;
     return e;
 }

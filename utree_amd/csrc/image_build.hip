@@ -25,7 +25,7 @@ namespace {
 
 template <int W, int I>
 __global__ void repack_k(const uint8_t *__restrict__ raw, uint64_t count, const uint32_t *__restrict__ ix2rank,
-                         uint32_t n_labels, uint64_t *__restrict__ recs) {
+                         uint32_t n_labels, uint64_t *__restrict__ recs, unsigned long long *__restrict__ invalid) {
     constexpr int SZ = W + I - 3, SB = W - 3, EW = RecTraits<W, I>::EW;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint8_t *p = raw + i * SZ;
@@ -38,6 +38,7 @@ __global__ void repack_k(const uint8_t *__restrict__ raw, uint64_t count, const 
 #pragma unroll
         for (int b = 0; b < I; ++b) ix |= (uint32_t)p[SB + b] << (8 * b);
         uint32_t rank = ix < n_labels ? ix2rank[ix] : INVALID;      // itree.c:929 `ix < maxIX`
+        if (rank == INVALID) atomicAdd(invalid, 1ull);               // (no well-formed database has such a node)
         uint64_t *o = recs + i * EW;
         const uint64_t r16 = rank == INVALID ? 0xFFFFull : (uint64_t)rank;
         if constexpr (W == 8 && I == 2) { o[0] = lo | (r16 << 40); }
@@ -472,11 +473,11 @@ done:
 extern "C" {
 
 int utk_repack(uint32_t W_, uint32_t I_, const void *d_raw, uint64_t count, const uint32_t *d_ix2rank,
-               uint32_t n_labels, uint64_t *d_recs, void *stream) {
+               uint32_t n_labels, uint64_t *d_recs, unsigned long long *d_invalid, void *stream) {
     if (!count) return 0;
     return dispatch_wi(W_, I_, [&](auto w, auto i) {
         repack_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(count) > 65536 ? 65536 : grid_for(count)), dim3(256), 0, (hipStream_t)stream>>>(
-            (const uint8_t *)d_raw, count, d_ix2rank, n_labels, d_recs);
+            (const uint8_t *)d_raw, count, d_ix2rank, n_labels, d_recs, d_invalid);
     });
 }
 

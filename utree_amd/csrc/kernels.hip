@@ -820,6 +820,125 @@ __device__ __forceinline__ uint64_t stop_flags(uint64_t x1, uint64_t x2) {
     return m;
 }
 
+// One pair of the reference's scan (itree.c:1060-1061) from byte `start` of s1 on: td = the first index where s1 ends, differs from
+// s2 or is ';'; a, b = the bytes of s1, s2 there; before = s1[td - 1] (0 for td == 0: "not '_'").
+__device__ __forceinline__ void pair_scan(const char *s1, const char *s2, uint32_t start, uint32_t &td, uint32_t &a, uint32_t &b, uint32_t &before) {
+    uint32_t base = start, prevlast = start ? (uint32_t)(uint8_t)s1[start - 1] : 0u;
+    for (;;) {
+        uint64_t x1, y1, x2, y2;
+        label16(s1, base, x1, y1); label16(s2, base, x2, y2);
+        uint64_t m = stop_flags(x1, x2);
+        if (!m) { prevlast = (uint32_t)(x1 >> 56); base += 8; x1 = y1; x2 = y2; m = stop_flags(x1, x2); }
+        if (m) {
+            const uint32_t idx = (uint32_t)(__builtin_ctzll(m) >> 3);
+            td = base + idx;
+            a = (uint32_t)(x1 >> (8 * idx)) & 0xFFu; b = (uint32_t)(x2 >> (8 * idx)) & 0xFFu;
+            before = idx ? ((uint32_t)(x1 >> (8 * idx - 8)) & 0xFFu) : prevlast;
+            return;
+        }
+        prevlast = (uint32_t)(x1 >> 56); base += 8;
+    }
+}
+
+// A label's utk_vote_rec (utree_internal.h) and its fields at token level t.
+struct VRec { uint64_t w[4]; };
+__device__ __forceinline__ VRec vrec(const uint64_t *vt, uint32_t rank) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 *p = (const u64x2 *)(vt + (size_t)rank * 4);
+    const u64x2 a = p[0], b = p[1];
+    VRec v; v.w[0] = a.x; v.w[1] = a.y; v.w[2] = b.x; v.w[3] = b.y;
+    return v;
+}
+__device__ __forceinline__ uint32_t v_pid(const VRec &v, uint32_t t) { return (uint32_t)((t < 4 ? v.w[0] : v.w[1]) >> (16u * (t & 3u))) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t v_end(const VRec &v, uint32_t t) { return (uint32_t)(v.w[2] >> (8u * t)) & 0xFFu; }
+__device__ __forceinline__ bool v_exists(const VRec &v, uint32_t t) { return ((uint32_t)v.w[3] >> t) & 1u; }
+__device__ __forceinline__ bool v_more(const VRec &v, uint32_t t) { return ((uint32_t)v.w[3] >> (8u + t)) & 1u; }
+__device__ __forceinline__ bool v_us(const VRec &v, uint32_t t) { return ((uint32_t)v.w[3] >> (16u + t)) & 1u; }
+
+// The vote with the label table (UTREE_F_VOTE_TABLE): the same state machine as below, every byte scan replaced by what the table says
+// about it.  The labels of the active group [st, ed) agree up to byte dv; t is the token that holds byte dv + 1 (0 at the start), the
+// same for all of them.  For a pair (prev, cur) of the group the reference's scan from dv + 1 stops at prev's next terminator e1 =
+// tok_end[t] unless the two differ before:
+//   same id at t (and cur has a token t)   -> both have the bytes up to e1 and a terminator there: td = e1, a / b = ';' or end
+//   ids differ                             -> they differ at or before e1.  The decision needs a = prev[td] and before = prev[td - 1]
+//        only to tell "less specific" (td = e1 and the byte before is '_': an empty rank like s__) from "differs": unless prev's token
+//        ends in '_' the answer is "differs" wherever td lies.  td itself -- the next dv -- matters only when this pair ends the walk
+//        with the group winning and the descent going on: then, and for tokens ending in '_', the bytes are read (pair_scan).
+__device__ __forceinline__ void vote_table(const utk_image &im, utree_result *out_r, const uint64_t *T, uint32_t F, uint32_t uix) {
+    const uint64_t *vt = im.vote_tab;
+    const char *blob = im.label_blob;
+    const uint32_t *loff = im.label_off;
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t cutoff = cut_of(F);
+    uint32_t st = 0, ed = uix, dv = NONE, t = 0, orun = F, sl, ol;
+    for (;;) {
+        const uint64_t t_st = T[st];
+        VRec pv = vrec(vt, (uint32_t)t_st);
+        {
+            // levels at which the whole group carries one token: the group's first and last label agree through token L - 1, each followed
+            // by ';' (ids are equal through the last shared token, `more` bits are set through the last ';')
+            const VRec lv = vrec(vt, (uint32_t)T[ed - 1]);
+            const uint64_t d0 = pv.w[0] ^ lv.w[0], d1 = pv.w[1] ^ lv.w[1];
+            const uint32_t same = d0 ? (uint32_t)__builtin_ctzll(d0) >> 4 : 4u + (d1 ? (uint32_t)__builtin_ctzll(d1) >> 4 : 4u);
+            const uint32_t both = ((uint32_t)(pv.w[3] & lv.w[3]) >> 8) & 0xFFu;             // ';' after token in both
+            const uint32_t semis = (uint32_t)__builtin_ctz(~both);                          // tokens 0 .. semis - 1 end in ';' in both
+            const uint32_t L = same < semis ? same : semis;
+            if (L > t) { dv = v_end(pv, L - 1u); t = L; }
+        }
+        uint32_t run = (uint32_t)(t_st >> 32), td = dv, c1 = run, rp = (uint32_t)t_st;
+        bool td_is_end = false;                                                             // td is prev's terminator at level t
+        for (uint32_t z = st + 1; z < ed; ++z) {
+            const uint64_t tz = T[z];
+            const uint32_t nz = (uint32_t)(tz >> 32), rc = (uint32_t)tz;
+            const VRec cv = vrec(vt, rc);
+            bool aside = false, stop = false;
+            // previous label exhausted at dv (itree.c:1052): it has no token t, or nothing is agreed yet and it is the empty string
+            if (t >= 8u || !v_exists(pv, t) || (dv == NONE && v_end(pv, 0) == 0u && !v_more(pv, 0))) aside = true;
+            else {
+                uint32_t a, b, before;
+                bool known = true;
+                if (v_exists(cv, t) && v_pid(cv, t) == v_pid(pv, t)) {
+                    td = v_end(pv, t); td_is_end = true;
+                    a = v_more(pv, t) ? ';' : 0u; b = v_more(cv, t) ? ';' : 0u; before = v_us(pv, t) ? '_' : 'x';
+                } else if (v_us(pv, t) || !v_exists(cv, t)) {
+                    pair_scan(blob + loff[rp], blob + loff[rc], dv + 1u, td, a, b, before);   // (dv + 1 = 0 while nothing is agreed)
+                    td_is_end = td == v_end(pv, t);
+                } else { a = 'a'; b = 'b'; before = 'x'; known = false; }                     // they differ inside the token or at its end: "differs" either way
+                if (a == b) run += nz;                                                         // same token: itree.c:1062
+                else if ((!a && b == ';') || ((a == ';' || !a) && before == '_')) aside = true;   // less specific: 1063
+                else if (run >= cutoff) {                                                      // group wins: itree.c:1068
+                    ed = z; stop = true;
+                    if (!known) {                                                              // the next dv, should the descent go on
+                        pair_scan(blob + loff[rp], blob + loff[rc], dv + 1u, td, a, b, before);
+                        td_is_end = td == v_end(pv, t);
+                    }
+                } else { run = nz; st = z; }                                                   // restart: itree.c:1069
+            }
+            if (aside) {                                                       // 1053-1056 / 1064-1067
+                run = nz; st = z;
+                orun -= c1;
+                cutoff = cut_of(orun);
+            }
+            if (stop) break;
+            pv = cv; c1 = nz; rp = rc;
+        }
+        sl = run; ol = orun;                                                   // itree.c:1071
+        if (run < cutoff) break;                                               // itree.c:1072
+        if (st + 1 >= ed) {                                                    // itree.c:1073-1079
+            if ((uint32_t)(T[ed - 1] >> 32) >= cutoff) dv = 0xFFFFFFFEu;
+            break;
+        }
+        orun = run; cutoff = cut_of(run);                                      // itree.c:1082-1085
+        if (td != dv) { dv = td; if (td_is_end) ++t; }
+    }
+    const uint32_t rk = (uint32_t)T[ed - 1];
+    int32_t cut;
+    if (dv == NONE) cut = -1;                                                  // itree.c:1087
+    else if (dv == 0xFFFFFFFEu) cut = -2;
+    else { uint32_t Ls = loff[rk + 1] - loff[rk] - 1; cut = (int32_t)(dv < Ls ? dv : Ls); }   // 1088
+    store_result(out_r, im.rank2ix[rk], cut, F, uix, sl, ol);
+}
+
 __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__restrict__ out, utk_workspace ws, uint32_t n_reads) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
@@ -832,6 +951,7 @@ __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__rest
     if ((int32_t)res[1] != CUT_PENDING) return;            // finished by the classify kernel (no hit, or classify_long_k)
     const uint32_t F = res[2], uix = res[3];
     const uint64_t *T = ws.tally + ((uint64_t)res[4] | ((uint64_t)res[5] << 32));
+    if (im.vote_tab) { vote_table(im, &out[r], T, F, uix); return; }
     const char *blob = im.label_blob;
     const uint32_t *loff = im.label_off;
     uint32_t cutoff = cut_of(F);

@@ -325,46 +325,59 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             // such windows is never listed.  `prev` starts as one, and the wave's last step is one for every lane: no flush case.
             uint32_t run_first = 0, prev = 0xFFFFFFFFu;
             const uint32_t lanec = lane << 24;
-            for (uint32_t b = 0;; ++b) {
-#pragma unroll
-                for (int rr = (int)NB - 2; rr >= 0; --rr) A[rr] = umin(A[rr], A[rr + 1]);   // suffix minima of the block
-                uint32_t P = 0;
-                bool done = false;
-#pragma unroll
-                for (uint32_t rr = 0; rr < NB; ++rr) {
-                    const uint32_t s = NB * b + rr;                                   // window (wave-uniform)
-                    uint32_t wmin;
-                    if (rr == 0) wmin = A[0];
-                    else {
-                        const uint32_t p = s + (K - 1u);                              // the window's last base
-                        m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
-                        irregular(m16, s + (NB - 1u));
-                        const uint32_t k = (mix32(m16) & ~0x1FFu) | (s + (NB - 1u));
-                        const uint32_t Sr = A[rr];
-                        A[rr - 1] = k;                                                // next block's key
-                        P = rr == 1 ? k : umin(P, k);                                 // prefix minimum of the next block
-                        wmin = umin(Sr, P);
-                    }
-                    const uint32_t wv = ((badpos - s) > (K - 1u) && s < nwin) ? wmin : 0xFFFFFFFFu;
-                    const bool changed = wv != prev;
-                    const bool emit = changed && prev != 0xFFFFFFFFu;
-                    const uint64_t em = ballot64(emit);
-                    if (em) {
-                        const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, nruns));
-                        // {read | one past the run's last window | first window | minimizer position}
-                        if (emit && idx < RUNS_CAP) runs[idx] = ((prev & 0xFFu) | (run_first << 8)) + ((s << 16) + lanec);
-                        nruns += (uint32_t)__popcll(em);
-                    }
-                    if (changed) run_first = s;
-                    prev = wv;
-                    if ((rr % 6u) == 0u && s >= maxnwin) { done = true; break; }      // (every lane's windows from maxnwin on are none)
-                }
-                if (done) break;
-                const uint32_t p = NB * (b + 1u) + (K - 1u);
-                m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
-                irregular(m16, NB * (b + 1u) + (NB - 1u));
-                A[NB - 1] = (mix32(m16) & ~0x1FFu) | (NB * (b + 1u) + (NB - 1u));
+            // (CLEAN: no read of the grab has a bad base and all have one length -- the usual grab --: whether a window exists is then
+            // a scalar question, three vector instructions per position less)
+            const uint32_t nwin_u = uni32(nwin);
+#define PHASE_A_BLOCKS(CLEAN_) \
+            for (uint32_t b = 0;; ++b) { \
+_Pragma("unroll") \
+                for (int rr = (int)NB - 2; rr >= 0; --rr) A[rr] = umin(A[rr], A[rr + 1]); \
+                uint32_t P = 0; \
+                bool done = false; \
+_Pragma("unroll") \
+                for (uint32_t rr = 0; rr < NB; ++rr) { \
+                    const uint32_t s = NB * b + rr; \
+                    uint32_t wmin; \
+                    if (rr == 0) wmin = A[0]; \
+                    else { \
+                        const uint32_t p = s + (K - 1u); \
+                        m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u); \
+                        irregular(m16, s + (NB - 1u)); \
+                        const uint32_t k = (mix32(m16) & ~0x1FFu) | (s + (NB - 1u)); \
+                        const uint32_t Sr = A[rr]; \
+                        A[rr - 1] = k; \
+                        P = rr == 1 ? k : umin(P, k); \
+                        wmin = umin(Sr, P); \
+                    } \
+                    uint32_t wv; \
+                    if (CLEAN_) wv = s < nwin_u ? wmin : 0xFFFFFFFFu; \
+                    else wv = ((badpos - s) > (K - 1u) && s < nwin) ? wmin : 0xFFFFFFFFu; \
+                    const bool changed = wv != prev; \
+                    const bool emit = changed && prev != 0xFFFFFFFFu; \
+                    const uint64_t em = ballot64(emit); \
+                    if (em) { \
+                        const uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, nruns)); \
+ \
+                        if (emit && idx < RUNS_CAP) runs[idx] = ((prev & 0xFFu) | (run_first << 8)) + ((s << 16) + lanec); \
+                        nruns += (uint32_t)__popcll(em); \
+                    } \
+                    if (changed) run_first = s; \
+                    prev = wv; \
+                    if ((rr % 6u) == 0u && s >= maxnwin) { done = true; break; } \
+                } \
+                if (done) break; \
+                const uint32_t p = NB * (b + 1u) + (K - 1u); \
+                m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u); \
+                irregular(m16, NB * (b + 1u) + (NB - 1u)); \
+                A[NB - 1] = (mix32(m16) & ~0x1FFu) | (NB * (b + 1u) + (NB - 1u)); \
             }
+#ifdef UTREE_LANES_NOCLEAN
+            const bool clean = false;
+#else
+            const bool clean = ballot64(badpos < 0xFFFF0000u || nwin != nwin_u) == 0ull;
+#endif
+            if (clean) { PHASE_A_BLOCKS(true) } else { PHASE_A_BLOCKS(false) }
+#undef PHASE_A_BLOCKS
             nruns = uni32(nruns);
         }
         if (nruns > RUNS_CAP) { wave_full = true; nruns = 0; }                         // every read of the grab goes on the list
@@ -379,9 +392,13 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // quad broadcast (DPP), nothing goes through LDS.  Two more batches of 64 buckets are in flight meanwhile.
         // (a lane beyond the list repeats the list's last run -- its load stays inside the table -- as a run no entry can belong to)
         uint32_t n_ovf = 0;
-        // what a scan needs of a run: {minimizer hash, first window | minimizer position - first << 8 | windows - 1 << 14 | read << 20,
-        // the 16 (k = 64: 48) bases before the minimizer, the 16 (48) bases behind it}
-        struct RunRegs { uint32_t h, pk, A[NA], B[NA]; };
+        // what a scan needs of a run: {minimizer hash (for the bucket's address), first window | minimizer position - first << 8 | windows - 1
+        // << 14 | read << 20, the range of entry tags its windows have, the 16 (k = 64: 48) bases before the minimizer, the 16 (48) behind it}.
+        // An entry's tag is {flag2 | hash low bits | minimizer position in the k-mer} (its high half-word; k = 32: times two, the zero bit
+        // below the position included): the run's windows have the tags tlo .. tlo + span -- hash bits of the run's minimizer, positions
+        // d - (windows - 1) .. d -- so that "a record of this run's minimizer, for one of its windows" is one subtract and one compare.
+        struct RunRegs { uint32_t h, pk, t, A[NA], B[NA]; };
+        constexpr uint32_t TSH = W == 8 ? 1u : 0u, PB = W == 8 ? 5u : 6u;             // tag scale; bits of the position field
         // a run's context from its record: the words around the minimizer come from the slot of the run's read
         auto context = [&](uint32_t q, uint32_t ustar, uint32_t &m, uint32_t (&A)[NA], uint32_t (&B)[NA]) {
             const uint32_t *sq = stream + q * STRIDE + FRONT + (ustar >> 4);
@@ -409,6 +426,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             // (beyond the list: an offset no run has -- no entry's position field names a window of that run)
             const uint32_t dl = act ? ((ustar - first) << 8) | ((end - 1u - first) << 14) : (G::DNONE << 8);
             c.pk = first | dl | (q << 20);
+            // (beyond the list: a range no entry's tag lies in)
+            c.t = act ? (((((c.h & 0xFFu) << PB) | (ustar - (end - 1u))) << TSH) | (((end - 1u - first) << TSH) << 16)) : 0xFFFFu;
         };
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) u32x4 *gptr128;
@@ -440,38 +459,37 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // hits of a batch wait in two registers per lane (lane of the read << QS | rank, the later one in `p0`) and go to the reads' lists
         // once per batch.  `last`: these 16 bytes are the bucket's last in this lane's share (the second load); the quad's fourth lane
         // then holds the bucket's last entry, which says whether the bucket continues in an overflow run
-        auto scan1 = [&](uint32_t ch, uint32_t cpk, const uint32_t (&cA)[NA], const uint32_t (&cB)[NA], const u32x4 &Pk, const bool last,
+        auto scan1 = [&](uint32_t ct, uint32_t cpk, const uint32_t (&cA)[NA], const uint32_t (&cB)[NA], const u32x4 &Pk, const bool last,
                          uint32_t &p0, uint32_t &p1, uint32_t &np) {
-            const uint32_t d = (cpk >> 8) & 63u, lenm1 = (cpk >> 14) & 63u;
-            const uint32_t hlow = ch & 0xFFu;                                           // hash bits the bucket does not imply
+            const uint32_t tlo = ct & 0xFFFFu, span = ct >> 16;
             const uint32_t qs = I == 2 ? ((cpk >> 4) & 0x3F0000u) : (cpk & 0x3F00000u);  // read << QS
             bool hit0, hit1, more;
             uint32_t rank0, rank1;
             if constexpr (W == 8 && I == 2) {
-                // two entries, each rest | {flag2 0 hlow8 pos5 rank16}; the window that starts pos bases before the minimizer has the outer bases AB >> 2 pos
+                // two entries, each rest | {flag2 hlow8 pos5 0 rank16}; the window that starts pos bases before the minimizer has the outer
+                // bases AB >> 2 pos, and 2 pos is what the low six bits of the high word >> 16 hold
                 const uint64_t AB = ((uint64_t)cA[0] << 32) | cB[0];
                 const uint32_t lo0 = Pk.x, hi0 = Pk.y, lo1 = Pk.z, hi1 = Pk.w;
-                const uint32_t pos0 = (hi0 >> 16) & 31u, pos1 = (hi1 >> 16) & 31u;
-                hit0 = (hi0 >> 21) == hlow && (d - pos0) <= lenm1 && (uint32_t)(AB >> (2u * pos0)) == lo0 && (hi0 & 0xFFFFu) != 0xFFFFu;
-                hit1 = (hi1 >> 21) == hlow && (d - pos1) <= lenm1 && (uint32_t)(AB >> (2u * pos1)) == lo1 && (hi1 & 0xFFFFu) != 0xFFFFu;
+                const uint32_t s0 = hi0 >> 16, s1 = hi1 >> 16;
+                hit0 = (s0 - tlo) <= span && (uint32_t)(AB >> (s0 & 63u)) == lo0;
+                hit1 = (s1 - tlo) <= span && (uint32_t)(AB >> (s1 & 63u)) == lo1;
                 rank0 = hi0 & 0xFFFFu; rank1 = hi1 & 0xFFFFu;
                 more = (hi1 >> 30) == 2u;
             } else if constexpr (W == 8) {
-                // one entry: rest | {flag2 0 hlow8 pos5 0} | rank32 | 0
+                // one entry: rest | {flag2 hlow8 pos5 0 | 0} | rank32 | 0
                 const uint64_t AB = ((uint64_t)cA[0] << 32) | cB[0];
                 const uint32_t lo0 = Pk.x, hi0 = Pk.y;
-                const uint32_t pos0 = (hi0 >> 16) & 31u;
-                hit0 = (hi0 >> 21) == hlow && (d - pos0) <= lenm1 && (uint32_t)(AB >> (2u * pos0)) == lo0 && Pk.z != INVALID;
+                const uint32_t s0 = hi0 >> 16;
+                hit0 = (s0 - tlo) <= span && (uint32_t)(AB >> (s0 & 63u)) == lo0;
                 hit1 = false;
                 rank0 = Pk.z; rank1 = 0;
                 more = (hi0 >> 30) == 2u;
             } else {
                 // one entry: {rest low 64}{flag2 | hlow8 pos6 rest-high 32 | rank16}
-                const uint32_t pos = (Pk.w >> 16) & 63u;
+                const uint32_t s0 = Pk.w >> 16, pos = s0 & 63u;
                 uint32_t r0, r1, r2;
                 rest96(cA, cB, pos, r0, r1, r2);
-                hit0 = (Pk.w >> 22) == hlow && (d - pos) <= lenm1 && r0 == __builtin_amdgcn_alignbit(Pk.w, Pk.z, 16u) && r1 == Pk.y && r2 == Pk.x &&
-                       (Pk.z & 0xFFFFu) != 0xFFFFu;
+                hit0 = (s0 - tlo) <= span && r0 == __builtin_amdgcn_alignbit(Pk.w, Pk.z, 16u) && r1 == Pk.y && r2 == Pk.x;
                 hit1 = false;
                 rank0 = Pk.z & 0xFFFFu; rank1 = 0;
                 more = (Pk.w >> 30) == 2u;
@@ -487,6 +505,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             // looked up there after the loop, one lane per WINDOW.  The run's record goes to the front of the run list --
             // phase B has read further than that: the slots of at least 64 more runs than it has scanned.
             if (last) {
+                const uint32_t d = (cpk >> 8) & 63u, lenm1 = (cpk >> 14) & 63u;
                 const uint64_t om = ballot64((lane & 3u) == 3u && d != G::DNONE && more);
                 if (om) {
                     const uint32_t first = cpk & 0xFFu, q = (cpk >> 20) & 63u;
@@ -499,8 +518,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             uint32_t p0 = 0, p1 = 0, np = 0;
 #define SCAN_K(k) { uint32_t bA[NA], bB[NA]; \
                     _Pragma("unroll") for (uint32_t i = 0; i < NA; ++i) { bA[i] = QUAD_BCAST(c.A[i], k); bB[i] = QUAD_BCAST(c.B[i], k); } \
-                    const uint32_t bh = QUAD_BCAST(c.h, k), bpk = QUAD_BCAST(c.pk, k); \
-                    scan1(bh, bpk, bA, bB, P[2 * k], false, p0, p1, np); scan1(bh, bpk, bA, bB, P[2 * k + 1], true, p0, p1, np); }
+                    const uint32_t bt = QUAD_BCAST(c.t, k), bpk = QUAD_BCAST(c.pk, k); \
+                    scan1(bt, bpk, bA, bB, P[2 * k], false, p0, p1, np); scan1(bt, bpk, bA, bB, P[2 * k + 1], true, p0, p1, np); }
             SCAN_K(0) SCAN_K(1) SCAN_K(2) SCAN_K(3)
 #undef SCAN_K
             if (ballot64(np != 0u)) {
@@ -511,6 +530,20 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         if (nruns) {
             // two batches of 64 buckets (16 KB) in flight: one is scanned while the next arrives
             const uint32_t nit = (nruns + 63u) >> 6;
+#ifdef UTREE_LANES_DEPTH3
+            RunRegs R0, R1, R2;
+            u32x4 P0[8], P1[8], P2[8];
+            prepare(0u, R0); issue(R0, P0);
+            prepare(1u, R1); issue(R1, P1);
+            for (uint32_t it = 0; it < nit; it += 3) {
+                prepare(it + 2, R2); issue(R2, P2);
+                scan(R0, P0);
+                prepare(it + 3, R0); issue(R0, P0);
+                if (it + 1 < nit) scan(R1, P1);
+                prepare(it + 4, R1); issue(R1, P1);
+                if (it + 2 < nit) scan(R2, P2);
+            }
+#else
             RunRegs R0, R1;
             u32x4 P0[8], P1[8];
             prepare(0u, R0); issue(R0, P0);
@@ -520,6 +553,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 prepare(it + 2, R0); issue(R0, P0);
                 if (it + 1 < nit) scan(R1, P1);
             }
+#endif
         }
 #undef QUAD_BCAST
         // ---- runs whose bucket overflows.  The bucket's last entry names the run of MIN records that holds the rest of its nodes.  A
@@ -583,8 +617,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                     bool hit;
                     uint32_t rank;
                     if constexpr (W == 8) {
-                        const uint32_t lo = (uint32_t)e.w[0], hi = (uint32_t)(e.w[0] >> 32), pos = (hi >> 16) & 31u;
-                        hit = (hi >> 21) == hlow && (ustar - first - pos) <= lenm1 && (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos)) == lo;
+                        const uint32_t lo = (uint32_t)e.w[0], hi = (uint32_t)(e.w[0] >> 32), pos = (hi >> 17) & 31u;
+                        hit = (hi >> 22) == hlow && (ustar - first - pos) <= lenm1 && (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos)) == lo;
                         if constexpr (I == 2) rank = hi & 0xFFFFu; else { rank = (uint32_t)e.w[1]; hit = hit && rank != INVALID; }
                     } else {
                         const uint32_t z = (uint32_t)e.w[1], wq = (uint32_t)(e.w[1] >> 32), pos = (wq >> 16) & 63u;
@@ -844,7 +878,8 @@ extern "C" {
 // u16 labels; a table with at most four irregular bins; buckets on 128-byte boundaries
 int utk_lanes_image_ok(const utk_image *im) {
     const bool fmt = (im->W == 8 && (im->I == 2 || (im->I == 4 && im->n_labels < (1u << 19) - 1u))) || (im->W == 16 && im->I == 2);
-    return fmt && im->irr_n <= 4u && ((uintptr_t)im->table & 127u) == 0;
+    // (a node whose label index is beyond the label list can never be a hit, itree.c:929: the scan here does not test for that)
+    return fmt && im->irr_n <= 4u && ((uintptr_t)im->table & 127u) == 0 && !(im->flags & UTREE_F_INVALID_RANKS);
 }
 
 // reads of up to this many bases take 2^c lanes (c = 0 .. 4)

@@ -47,6 +47,8 @@ extern "C" {
 #define UTREE_F_IRREGULAR 1u   /* some bins are not strictly ascending: bitmap present, exact probe path   */
 #define UTREE_F_GENERIC   2u   /* bin table not monotone: fine_bits = 0, every lookup takes the exact path  */
 #define UTREE_F_OFF64     4u   /* bin-table offsets are 64-bit (n_nodes >= UINT32_MAX)                       */
+#define UTREE_F_VOTE_TABLE 16u /* labels are short and token-structured: vote_k takes its decisions from the table at off_vote */
+#define UTREE_F_INVALID_RANKS 8u   /* some node's label index is >= the number of labels (itree.c:929: never a hit): wave-per-read kernels only */
 
 /* At offset 0 of the flat device image (position independent: offsets, never pointers). */
 typedef struct {
@@ -60,12 +62,25 @@ typedef struct {
     uint64_t label_blob_bytes;
     uint64_t n_irregular;
     uint64_t total_bytes;
+    uint64_t off_vote;               /* 32 bytes per label, rank order (UTREE_F_VOTE_TABLE): see utk_vote_rec                    */
     /* Bucket addressing: region r = top 8 bits of the minimizer hash h; regions[r] = base_r << 25 | nb_r and
      * bucket = base_r + (((h & 0xFFFFFF) * nb_r) >> 24) with 2^16 <= nb_r <= 2^24 buckets in the region, so a bucket spans at most
      * 256 consecutive hash values and the low 8 bits of h go into the record key.  The hash is a MINIMUM of K-15 hashes, so
      * nodes crowd towards h = 0: every region gets the number of buckets its expected share of the nodes asks for. */
     uint64_t regions[256];
 } utree_image_header;
+
+/* A label as the vote (itree.c:1044-1088) needs it, when every label of the database has at most 8 tokens (';'-separated), at most
+ * 255 bytes, and ranks fit 16 bits: per token t the id of the label's prefix through that token (= the smallest rank of a label with
+ * the same bytes up to the token's end and a terminator there), the byte offset of the token's terminator, and three bits -- the
+ * token exists, a ';' follows it (else the label ends there), the byte before its terminator is '_'.  Two labels that agree up to
+ * token t-1 have the same token t exactly when their ids at t are equal: the vote's byte scans become integer compares. */
+typedef struct {
+    uint16_t pid[8];
+    uint8_t tok_end[8];
+    uint8_t exists, more, us, n_tok;
+    uint8_t pad[4];
+} utk_vote_rec;
 
 /* What kernels take by value. */
 typedef struct {
@@ -78,6 +93,7 @@ typedef struct {
     const uint32_t *label_off;       /* [n_labels+1], rank order                                             */
     const char *label_blob;          /* NUL-terminated labels in strcmp order                                */
     const uint32_t *rank2ix;
+    const uint64_t *vote_tab;        /* utk_vote_rec per rank, or NULL: vote_k reads the label bytes                       */
     uint64_t n_nodes;
     uint32_t n_labels, fine_bits, flags, W, I;
     /* the 24-bit prefixes of the irregular bins when there are at most four of them (COMPRESS' first-bin quirk makes one or two;
@@ -88,8 +104,9 @@ typedef struct {
 static inline uint32_t utree_rec_words(uint32_t W, uint32_t I) { return (W == 16 ? 2u : 1u) * (I == 4 ? 2u : 1u); }
 
 /* ---- launchers implemented in kernels.hip (all asynchronous on `stream`, return hipError_t as int) ---- */
+/* *d_invalid += records whose label index is >= n_labels */
 int utk_repack(uint32_t W, uint32_t I, const void *d_raw, uint64_t count, const uint32_t *d_ix2rank,
-               uint32_t n_labels, uint64_t *d_recs_at_first, void *stream);
+               uint32_t n_labels, uint64_t *d_recs_at_first, unsigned long long *d_invalid, void *stream);
 int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_coarse, void *stream);
 /* counters[0] += irregular bins, counters[1] = 1 if the table is not monotone / exceeds n_nodes */
 int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,

@@ -67,7 +67,7 @@ template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket_at(u
 }
 
 // The 8 entries of half a k = 32 / u16-label bucket against (tag = hash low bits << 5 | minimizer position, rest):
-// an entry's low word is its rest, its high word {flag2 | 0 | tag13 | rank16}.  One compare and one select per entry pick the
+// an entry's low word is its rest, its high word {flag2 | tag13 | 0 | rank16}.  One compare and one select per entry pick the
 // high word of the entry whose rest matches; the tag (and with it the flag: 0 = a record) is checked once.  Two entries with
 // the same rest and different tags are possible (the same 16 outer bases around a minimizer at two positions): then, and when
 // an empty entry or the overflow descriptor happens to carry the rest's bit pattern, every entry is looked at in full.
@@ -76,11 +76,11 @@ __device__ __forceinline__ uint32_t scan_bucket82(const Bucket<8, 2> &b, uint32_
 #pragma unroll
     for (int i = 0; i < 8; ++i) sel = (uint32_t)b.e[i].w[0] == rest ? (uint32_t)(b.e[i].w[0] >> 32) : sel;
     uint32_t rank = INVALID;
-    if ((sel >> 16) == tag) rank = sel & 0xFFFFu;
+    if ((sel >> 17) == tag) rank = sel & 0xFFFFu;
     else if (sel != 0xFFFFFFFFu) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if ((uint32_t)b.e[i].w[0] == rest && (uint32_t)(b.e[i].w[0] >> 48) == tag) rank = (uint32_t)(b.e[i].w[0] >> 32) & 0xFFFFu;
+            if ((uint32_t)b.e[i].w[0] == rest && (uint32_t)(b.e[i].w[0] >> 49) == tag) rank = (uint32_t)(b.e[i].w[0] >> 32) & 0xFFFFu;
     }
     return rank == 0xFFFFu ? INVALID : rank;
 }
@@ -94,7 +94,7 @@ template <int W, int I> __device__ __forceinline__ uint32_t scan_half(const Buck
         // {flag 0 | mk} (an empty entry or the overflow descriptor has a non-zero flag, so neither can): one AND and one
         // 64-bit compare per entry; the label bits of the matching entry are picked up raw and decoded once at the end.
         constexpr int KW = RecTraits<W, I>::KW;
-        const uint64_t want = W == 16 ? mk.hi << 16 : (((mk.lo >> 32) << 48) | (mk.lo & 0xFFFFFFFFull));
+        const uint64_t want = W == 16 ? mk.hi << 16 : (((mk.lo >> 32) << 49) | (mk.lo & 0xFFFFFFFFull));
         uint32_t raw = INVALID;
 #pragma unroll
         for (int i = 0; i < HCAP; ++i) {
