@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--nodes", type=int, default=1_217_000_000, help="synthetic CTR nodes (config 2: 1.217e9 = 8 GB)")
     ap.add_argument("--batch-reads", type=int, default=4_000_000)
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--len-dist", default="fixed", choices=("fixed", "lognormal"),
+                    help="lognormal: SURVEY 8(d)'s config-3 shape -- read lengths ~ lognormal with mean --read-len, clipped to [mean/10, 10 x mean]; "
+                         "the CPU / file legs are for fixed-length batches only")
     ap.add_argument("--kmer", type=int, default=32, choices=(32, 64))
     ap.add_argument("--distinct-batches", type=int, default=0,
                     help="distinct read batches resident in HBM (0 = one per timed step: no batch is classified twice in the timed region)")
@@ -115,9 +118,10 @@ def main():
         else:
             dist.init_process_group(args.backend)
     W = args.kmer // 4
-    want_cpu = (world == 1 and not args.no_cpu_baseline)
-    want_e2e = (world == 1 and not args.no_e2e)
-    want_e2e_dist = (world > 1 and not args.no_e2e)
+    var_len = args.len_dist != "fixed"
+    want_cpu = (world == 1 and not args.no_cpu_baseline and not var_len)
+    want_e2e = (world == 1 and not args.no_e2e and not var_len)
+    want_e2e_dist = (world > 1 and not args.no_e2e and not var_len)
 
     # ---- database: rank 0 builds the image in HBM, the others receive it by ONE broadcast (RCCL / xGMI) ----
     t0 = time.time()
@@ -168,14 +172,23 @@ def main():
     # ---- reads: each rank's own batches, resident in HBM before the timed region ----
     nb = args.distinct_batches if args.distinct_batches > 0 else args.steps
     nb = max(1, min(nb, args.steps + args.warmup))
-    batches = [synth.make_reads(sdb, args.batch_reads, args.read_len, seed=synth.READ_SEED + 1000 * rank + b, device=dev)
-               for b in range(nb)]
-    total_bases = args.batch_reads * args.read_len
+    if var_len:
+        batches = [synth.make_reads_var(sdb, synth.lognormal_lengths(args.batch_reads, mean=float(args.read_len), lo=max(1, args.read_len // 10),
+                                                                     hi=10 * args.read_len, seed=synth.READ_SEED + 1000 * rank + b),
+                                        seed=synth.READ_SEED + 1000 * rank + b, device=dev) for b in range(nb)]
+        totals = [int(b.length.sum().item()) for b in batches]
+        maxlens = [int(b.length.max().item()) for b in batches]
+    else:
+        batches = [synth.make_reads(sdb, args.batch_reads, args.read_len, seed=synth.READ_SEED + 1000 * rank + b, device=dev)
+                   for b in range(nb)]
+        totals = [args.batch_reads * args.read_len] * nb
+        maxlens = [args.read_len] * nb
+    total_bases = totals[0]
     outs = [torch.empty((args.batch_reads, 6), dtype=torch.int32, device=dev) for _ in range(nb)]
     ns = max(1, min(args.streams, nb))
     streams = [torch.cuda.Stream(dev) for _ in range(ns)]
-    wss = [torch.empty(tree.workspace_bytes(args.batch_reads, total_bases, args.read_len, bool(args.rc)), dtype=torch.uint8, device=dev)
-           for _ in range(ns)]
+    ws_bytes = max(tree.workspace_bytes(args.batch_reads, totals[b], maxlens[b], bool(args.rc)) for b in range(nb))
+    wss = [torch.empty(ws_bytes, dtype=torch.uint8, device=dev) for _ in range(ns)]
 
     def step(i):
         # consecutive batches alternate over the streams (each with its own workspace and result buffer), the way a
@@ -183,7 +196,7 @@ def main():
         # The timed steps take batches 0 .. steps-1: with the default (one distinct batch per step) none is classified twice.
         b = batches[i % nb]
         with torch.cuda.stream(streams[i % ns]):
-            tree.classify(b.bases, b.off, b.length, rc=bool(args.rc), total_bases=total_bases, max_len=args.read_len,
+            tree.classify(b.bases, b.off, b.length, rc=bool(args.rc), total_bases=totals[i % nb], max_len=maxlens[i % nb],
                           out=outs[i % nb], workspace=wss[i % ns])
 
     for i in range(args.warmup):
@@ -201,6 +214,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.time() - t1
+    tree.poll()                                  # a batch whose kernels found its workspace too small would have said so by now
     if dist_on:
         elapsed = udist.max_over_ranks(elapsed, dev)
     k_ms, k_launches = tree.kernel_time(reset=True)
@@ -211,7 +225,8 @@ def main():
         value = reads_total / elapsed
         avg_launch_s = (k_ms / 1e3) / max(1, k_launches)
         kernel_sig = tree.kernel_name()
-        roof = roofline(args, tree, batches[0], outs[0], W, avg_launch_s, k_launches, kernel_sig, ulib)
+        roof = roofline(args, tree, batches[0], outs[0], W, avg_launch_s, k_launches, kernel_sig, ulib,
+                        mean_len=(sum(totals) / (len(totals) * args.batch_reads)) if var_len else None)
         nfound = int((outs[(args.steps - 1) % nb][:, 2] > 0).sum().item())
         line = {
             "metric": "reads classified/sec, 8 GB L2 CTR, 150 bp reads",
@@ -219,9 +234,12 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64" if W == 8 else "u128", "data": "synthetic",
             "config": {"workload": "configs[1]: %.3g-node synthetic L2 CTR (k=%d, %d labels, image %.1f GiB, fine_bits=%d), "
-                                   "%d x %d bp reads per GPU (%d steps x %d-read batches, %d distinct batches resident in HBM), RC=%d"
+                                   "%d x %s reads per GPU (%d steps x %d-read batches, %d distinct batches resident in HBM), RC=%d"
                                    % (args.nodes, args.kmer, synth.N_LABELS, tree.info.image_bytes / 2**30, tree.info.fine_bits,
-                                      args.batch_reads * args.steps, args.read_len, args.steps, args.batch_reads, nb, args.rc),
+                                      args.batch_reads * args.steps,
+                                      "%d bp" % args.read_len if not var_len else "lognormal-length (mean %d bp, clipped to [%d, %d]; batch 0: mean %.0f, max %d)" %
+                                      (args.read_len, max(1, args.read_len // 10), 10 * args.read_len, totals[0] / args.batch_reads, maxlens[0]),
+                                      args.steps, args.batch_reads, nb, args.rc),
                        "parallelism": "reads sharded over %d GPU(s), CTR image replicated%s; batches alternate over %d HIP stream(s) per GPU" %
                                       (world, " by %s (%.2f s)" % (bcast_how, bcast_s) if dist_on else "", ns)},
             "roofline": roof,
@@ -383,11 +401,11 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, ulib):
+def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, ulib, mean_len=None):
     """The roofline object: a byte model derived from the image as built, the measured fractions from the kept profile
     (only when it matches this library), and the SURVEY 8(d) contract figure as a labelled legacy number."""
     import torch
-    L = args.read_len
+    L = args.read_len if mean_len is None else mean_len
     nm = max(1, min(args.model_reads, batch.n))
     # distinct 64-byte buckets / 128-byte lines per read, counted on the device with the load-time minimizer code
     mc = tree.model_counts(batch.bases, batch.off[:nm], batch.length[:nm], rc=bool(args.rc))
@@ -398,9 +416,11 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
     # tally entries written for vote_k (reads with more than one distinct label), from the results of batch 0
     multi = out0[:, 3] > 1
     tally_entries = float(out0[multi, 3].sum().item()) / batch.n
-    # bytes a read must move: its bases, each distinct bucket -- a 128-byte line since image version 9 -- once (+ one more line
-    # where the bucket overflows into the sorted records), its 24-byte result and its (rank, count) list
-    model = L + 128.0 * (buckets + over) + 24.0 + 8.0 * tally_entries
+    # bytes a read must move: its bases, each distinct bucket (64 bytes, or a whole 128-byte line when the image was built with
+    # UTREE_BUCKET_BYTES=128) once (+ one more bucket where it overflows into the sorted records), its 24-byte result and its
+    # (rank, count) list
+    bb = float(tree.info.bucket_bytes)
+    model = L + bb * (buckets + over) + 24.0 + 8.0 * tally_entries
     achieved = model * args.batch_reads / avg_launch_s / 1e9 if k_launches else None
     contract, b_win, windows = contract_bytes_per_read(args.nodes, W, 2, L)
     if args.rc:
@@ -408,7 +428,7 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
     roof = {"bound": "hbm", "kernel": kernel_sig, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
             "algorithmic_bytes_per_read": model,
-            "model": {"what": "bases + 128 B x distinct buckets (a bucket is one HBM line; +128 B per overflowing bucket) + 24 B result + 8 B x tally entries",
+            "model": {"what": "bases + %d B x distinct buckets (+%d B per overflowing bucket) + 24 B result + 8 B x tally entries" % (bb, bb), "bucket_bytes": bb,
                       "sample_reads": mc["reads"], "windows_per_read": mc["windows"] / reads, "distinct_buckets_per_read": buckets,
                       "distinct_128B_lines_per_read": lines128, "overflow_buckets_per_read": over, "tally_entries_per_read": tally_entries,
                       "bytes_if_hbm_delivers_128B_lines": L + 128.0 * lines128 + 24.0 + 8.0 * tally_entries},
@@ -422,7 +442,7 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         tj = json.load(open(tp))
-        key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (args.nodes, args.batch_reads, L, args.kmer, args.rc)
+        key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (args.nodes, args.batch_reads, args.read_len, args.kmer, args.rc) + (",dist=%s" % args.len_dist if args.len_dist != "fixed" else "")
         e = tj.get(key)
         src_hash = ulib.kernel_source_sha256()
         if e is None:

@@ -115,6 +115,9 @@ typedef struct {
                                    has at most 8 ';'-separated tokens and 255 bytes, 16-bit label indices)   */
     uint32_t lane_pass;         /* 1: the lane-per-read classify kernels take this image (else the
                                    wave-per-read kernels: k = 64 with 32-bit labels, many irregular bins)   */
+    uint32_t bucket_bytes;      /* 64 (default) or 128 (UTREE_BUCKET_BYTES=128 when the image is built: a third
+                                   less HBM, classify kernels 5-10 % slower)                               */
+    uint32_t reserved;
 } utree_dev_info;
 int utree_dev_get_info(const utree_dev *dev, utree_dev_info *info);
 

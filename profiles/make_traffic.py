@@ -37,6 +37,8 @@ nodes = arg("--nodes", 1_217_000_000)
 reads = arg("--batch-reads", 4_000_000)
 length = arg("--read-len", 150)
 key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (nodes, reads, length, kmer, rc)
+if arg("--len-dist", "fixed") != "fixed":
+    key += ",dist=%s" % arg("--len-dist", "fixed")
 entry = {
     "kernel": name[0],
     "kernel_source_sha256": c["kernel_source_sha256"],

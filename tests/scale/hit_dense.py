@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--complevel", type=int, default=0)
     ap.add_argument("--sample", type=int, default=200_000, help="reads of the parity check against the genuine reference")
+    ap.add_argument("--oracle-reads", type=int, default=0, help="reads of batch 0 compared record by record with the CPU oracle")
     ap.add_argument("--dir", default="/dev/shm/utree_hitdense")
     args = ap.parse_args()
     import numpy as np
@@ -171,6 +172,21 @@ def main():
         out["parity_sorted_lines_identical"] = (a == b)
         out["lines"] = a[1]
         out["reference_reads_per_second_16_threads"] = ns / max(1e-6, t_all - t_load)
+    # ... and the batch results record by record against the CPU oracle (test infrastructure: the checker, not the thing measured)
+    if args.oracle_reads:
+        from oracle import orc
+        no = min(args.oracle_reads, args.reads)
+        o = orc.OracleDB.load(d + "/db.ctr")
+        hostb = batches[0][: no * L].cpu().numpy()
+        want = o.classify_batch(hostb, np.arange(no, dtype=np.uint64) * L, np.full(no, L, dtype=np.uint32), rc=bool(args.rc), threads=16)
+        got = outs[0][:no].cpu().numpy()
+        gu = got.view(np.uint32)
+        hit = want["found"] > 0
+        multi = hit & (want["uix"] > 1)
+        out["oracle_reads"] = no
+        out["oracle_records_identical"] = bool(np.array_equal(gu[:, 2], want["found"]) and np.array_equal(gu[hit, 3], want["uix"][hit]) and
+                                               np.array_equal(gu[hit, 0], want["label"][hit]) and np.array_equal(got[hit, 1], want["cut"][hit]) and
+                                               np.array_equal(gu[multi, 4], want["sl"][multi]) and np.array_equal(gu[multi, 5], want["ol"][multi]))
     print(json.dumps(out, indent=1))
     for f in os.listdir(d):
         os.remove(os.path.join(d, f))

@@ -8,6 +8,8 @@ and through size-independent properties (the fixtures in tests/golden pin the sa
 Databases and reads are seeded synthetic (utree_amd.synth); the oracle gets the same on-disk pieces (bin
 table + packed records + labels).  Run on the MI355X box:  python -m pytest tests -m gpu -x -q
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -93,7 +95,7 @@ def test_long_reads_with_both_strands_on_the_l4_size_database(torch_cuda):
     perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(3))      # lengths interleaved, as a file would have them
     off, ln = off[perm].contiguous(), ln[perm].contiguous()
     got = sdb.tree.classify(bases, off, ln, rc=True)
-    assert "classify_long_k" in sdb.tree.kernel_name() or sdb.tree.kernel_name().startswith("classify_lanes_k<8, 2, 16, false, 2>")   # long reads: in pieces through the lane pass
+    assert "classify_long_k" in sdb.tree.kernel_name() or sdb.tree.kernel_name().startswith("classify_lanes_k<8, 2, 16, false, 2,")   # long reads: in pieces through the lane pass
     again = sdb.tree.classify(bases, off, ln, rc=True)
     assert torch.equal(got, again)
     o = oracle_of(sdb)
@@ -102,3 +104,24 @@ def test_long_reads_with_both_strands_on_the_l4_size_database(torch_cuda):
     assert hits > 0.9 * n and multi > 0.5 * n
     assert int(want["found"].max()) > 3000                                              # thousands of hits per read: the long tally paths
     sdb.tree.close()
+
+
+@pytest.mark.parametrize("rc", [0, 1])
+def test_hit_dense_related_genomes_database(tmp_path, rc):
+    """The shape of a real reference database (README.md:2): related genomes, built by the product's own utree-buildGG +
+    xtree-compress -- k-mers of 25 relatives crowd around each minimizer, so half of a read's buckets continue in overflow runs of
+    dozens to hundreds of records, and reads hit in a quarter of their windows.  240 000 reads cut from the references: batch
+    records against the CPU oracle, the file search's sorted lines against the genuine reference where its binary travelled."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "scale", "hit_dense.py"), "--refs", "100", "--ref-len", "200000",
+                        "--reads", "240000", "--sample", "60000", "--oracle-reads", "240000", "--rc", str(rc), "--steps", "2",
+                        "--dir", str(tmp_path / "hd")], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads(p.stdout[p.stdout.index("{"):])
+    assert j["oracle_records_identical"] and j["oracle_reads"] == 240000
+    assert j.get("parity_sorted_lines_identical", True)
+    assert j["kernel"].startswith("classify_lanes_k<8, 2, 1,")
+    assert j["hits_per_read_mean"] > 15 and j["model_counts_100k_reads"]["overflow_buckets"] > 100_000     # hit-dense, and the buckets do overflow

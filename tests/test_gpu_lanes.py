@@ -304,7 +304,7 @@ def test_long_reads_with_more_labels_than_their_tables_hold(torch_cuda, tmp_path
     for rc in (False, True):
         monkeypatch.setenv("UTREE_LANE_PASS", "1")
         got = classify_fasta_bytes(db, tree, data, rc=rc)
-        assert tree.kernel_name().startswith("classify_lanes_k<8, 2, 16, false, 2>")
+        assert tree.kernel_name().startswith("classify_lanes_k<8, 2, 16, false, 2,")
         want = oracle_text(o, data, tmp_path, rc=rc)
         assert got == want
         uix = {l.split(b"\t")[0]: int(l.split(b"\t")[3]) for l in want.split(b"\n") if l}
@@ -334,3 +334,32 @@ def test_a_workspace_too_small_is_reported_not_overrun(torch_cuda, tmp_path, mon
         monkeypatch.delenv("UTREE_TEST_TALLY_CAP")
         assert classify_fasta_bytes(db, tree, data) == want
     tree.close()
+
+
+@pytest.mark.parametrize("name,rc", [("toy", 1), ("k64", 1), ("ix32", 0), ("vote", 0), ("katq2", 0)])
+def test_line_sized_buckets_option(torch_cuda, name, rc, tmp_path, monkeypatch):
+    """UTREE_BUCKET_BYTES=128 builds the image with one bucket per 128-byte HBM line (a third smaller; the kernels' NL = 2
+    instantiations and the wave-per-read kernels' two-halves lookup): the reference's golden lines, and random reads of every
+    length class against the oracle, through both kernel families."""
+    monkeypatch.setenv("UTREE_BUCKET_BYTES", "128")
+    d = util.load_db_fixture(name)
+    db = CtrDB.open(util.fixture_ctr(name))
+    tree = DeviceTree.upload(db, 0)
+    assert tree.info.bucket_bytes == 128
+    o = orc.OracleDB.load(util.fixture_ctr(name))
+    data = util.fixture_bytes(util.READS_OF.get(name, name) + "_reads.fa.gz")
+    want = util.fixture_bytes("%s_out%s.txt.gz" % (name, "_rc" if rc else ""))
+    rng = np.random.default_rng(3)
+    more = fasta_bytes(random_reads(rng, d, 2000, 1, 160, hit_frac=0.8) + random_reads(rng, d, 200, 161, 2095, hit_frac=0.8) + random_reads(rng, d, 8, 3000, 9000, hit_frac=0.8))
+    for lane_pass in ("1", "0"):
+        monkeypatch.setenv("UTREE_LANE_PASS", lane_pass)
+        if b"\0" not in data:
+            assert classify_fasta_bytes(db, tree, data, rc=bool(rc)) == want
+        assert classify_fasta_bytes(db, tree, more, rc=bool(rc)) == oracle_text(o, more, tmp_path, rc=bool(rc))
+        if lane_pass == "1":
+            assert tree.kernel_name().startswith("classify_lanes_k<") and tree.kernel_name().endswith(", 2>")
+    tree.close()
+    monkeypatch.delenv("UTREE_BUCKET_BYTES")
+    t64 = DeviceTree.upload(db, 0)
+    assert t64.info.bucket_bytes == 64 and t64.info.image_bytes != 0
+    t64.close()

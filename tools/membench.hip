@@ -33,6 +33,8 @@ __global__ __launch_bounds__(256) void gather_k(const uint64_t *__restrict__ tab
             ulonglong2 a[4];
             for (int k = 0; k < 4; ++k) { const ulonglong2 *q = (const ulonglong2 *)(tab + (mix(b0 + k) & lines_mask) * 16) + (tid & 3); a[k] = q[0]; }
             acc += a[0].x + a[1].y + a[2].x + a[3].y; }
+        if (MODE == 8) { const ulonglong2 *q = (const ulonglong2 *)(tab + (mix((tid >> 3) * 0x9E3779B97F4A7C15ull + i + 77) & lines_mask) * 16) + (tid & 7); ulonglong2 a = q[0]; acc += a.x + a.y; }
+        if (MODE == 9) { const ulonglong2 *q = (const ulonglong2 *)(tab + (mix((tid >> 2) * 0x9E3779B97F4A7C15ull + i + 77) & lines_mask) * 16) + (tid & 3); ulonglong2 a = q[0], b = q[4]; acc += a.x + b.y; }
         if (MODE == 5) { const ulonglong2 *q = (const ulonglong2 *)(p + ((s >> 40) & 1) * 8); ulonglong2 a = q[0], b = q[1], c = q[2], d = q[3]; acc += a.x + b.y + c.x + d.y; }
     }
     out[tid] = acc;
@@ -48,9 +50,10 @@ int main(int argc, char **argv) {
     hipMalloc(&out, (size_t)blocks * threads * 8);
     uint64_t lines_mask = bytes / 128 - 1;
     uint64_t per_thread = 512;
-    const char *names[8] = {"A 1x8B/line", "B 2x8B same 128B line", "C 2x8B two lines", "D 2 dependent loads", "E 1x16B/line", "F 64B sector", "G 64B sector per QUAD (x4 iters)", "H 4 sectors per quad, 4 loads in flight"};
+    const char *names[10] = {"A 1x8B/line", "B 2x8B same 128B line", "C 2x8B two lines", "D 2 dependent loads", "E 1x16B/line", "F 64B sector", "G 64B sector per QUAD (x4 iters)", "H 4 sectors per quad, 4 loads in flight",
+                             "I 128B line per OCT (x8 iters), one load", "J 128B line per QUAD (x4 iters), two loads"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < 10; ++m) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             hipEventRecord(e0);
             switch (m) {
@@ -62,11 +65,13 @@ int main(int argc, char **argv) {
                 case 5: gather_k<5><<<blocks, threads>>>(tab, lines_mask, per_thread, out); break;
                 case 6: gather_k<6><<<blocks, threads>>>(tab, lines_mask, per_thread, out); break;
                 case 7: gather_k<7><<<blocks, threads>>>(tab, lines_mask, per_thread, out); break;
+                case 8: gather_k<8><<<blocks, threads>>>(tab, lines_mask, per_thread, out); break;
+                case 9: gather_k<9><<<blocks, threads>>>(tab, lines_mask, per_thread, out); break;
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             double iters = (double)blocks * threads * per_thread;
-            if (rep) printf("%-26s %8.3f ms  %7.2f G iters/s\n", names[m], ms, iters / ms / 1e6);
+            if (rep) printf("%-44s %8.3f ms  %7.2f G iters/s\n", names[m], ms, iters / ms / 1e6);
         }
     return 0;
 }

@@ -37,20 +37,28 @@ static int timing_on(void) { return getenv("UTREE_TIMING") != NULL || getenv("UT
 
 static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
+/* A bucket's size, in 8-byte words: 8 (64 bytes) unless UTREE_BUCKET_BYTES=128 asks for line-sized buckets (16).  Same-box on config 2
+ * (profiles/r03/ab_v8_vs_v9.txt): 64-byte buckets make the classify kernels 5-10 % faster -- half the entries to scan
+ * per lookup, one request per bucket instead of two --, 128-byte buckets make the image a third smaller (twice the nodes per bucket at the
+ * same overflow rate) and every fetched byte one that is looked at. */
+static uint32_t bucket_words_default(void) {
+    const char *e = getenv("UTREE_BUCKET_BYTES");
+    return e && atoi(e) == 128 ? 16u : 8u;
+}
+
 /* Buckets per hash region (utree_image_header.regions) for a tree of N nodes: a node's minimizer hash is the smallest of m = K-15
  * hashes, so region r -- the hashes whose top 8 bits are r -- expects N ((1 - r/256)^m - (1 - (r+1)/256)^m) of the nodes.  The region
- * gets as many 128-byte buckets as bring a bucket to TARGET nodes: any number (bucket = base + ((h24 * nb) >> 24)), between 2^16 -- a
- * bucket spans at most 256 hash values: the record key has 8 bits for them -- and 2^(16+F), at most one bucket per hash value (F =
- * fine_bits: 8 = as many as the density asks, 0 = 256 values per bucket everywhere).  The default TARGET fills a bucket to 56 %:
- * config 2 (k = 32, 16 entries per bucket): 9 nodes, image 17.7 GiB, 0.3 overflowing buckets per 150 bp read (the dense end of the
- * hash range has several nodes per hash VALUE, so buckets there hold the nodes of one, two or three values: a mixture, not one Poisson
- * mean -- DESIGN.md section 3 has the sweep). */
-#define UTREE_BUCKET_FILL 0.5625
-static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32_t F, uint64_t regions[256]) {
+ * gets as many buckets as bring a bucket to TARGET nodes: any number (bucket = base + ((h24 * nb) >> 24)), between 2^16 -- a bucket
+ * spans at most 256 hash values: the record key has 8 bits for them -- and 2^(16+F), at most one bucket per hash value (F = fine_bits:
+ * 8 = as many as the density asks, 0 = 256 values per bucket everywhere).  Default TARGET: 128-byte buckets are filled to 56 % (config
+ * 2: 9 of 16 entries, image 17.6 GiB, 0.3 overflowing buckets per 150 bp read), 64-byte buckets to 31 % (2.5 of 8, 24 GiB, 0.15).  The
+ * dense end of the hash range has several nodes per hash VALUE, so a bucket there holds the nodes of one, two or three values: a
+ * mixture, not one Poisson mean -- which is why the small buckets want the lower load (DESIGN.md section 3 has the sweeps). */
+static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32_t bucket_words, uint32_t F, uint64_t regions[256]) {
     const double m = 4.0 * W - 15.0;
-    const uint32_t cap_entries = 16u / utree_rec_words(W, I);
+    const uint32_t cap_entries = bucket_words / utree_rec_words(W, I);
     const char *te = getenv("UTREE_BUCKET_TARGET");                     /* nodes per bucket; experiments only */
-    const double target = te && atof(te) > 0 ? atof(te) : UTREE_BUCKET_FILL * cap_entries;
+    const double target = te && atof(te) > 0 ? atof(te) : (bucket_words == 16 ? 0.5625 : 0.3125) * cap_entries;
     const uint64_t nb_max = 1ull << (16 + (F > 8 ? 8 : F)), nb_min = 1ull << 16;
     uint64_t base = 0;
     for (int r = 0; r < 256; ++r) {
@@ -73,7 +81,8 @@ int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
         const char *cap_env = getenv("UTREE_TABLE_MAX_GB");
         double cap = (cap_env && atof(cap_env) > 0 ? atof(cap_env) : 48.0) * 1073741824.0;
         int F = 8;
-        while (F > 0 && (double)compute_regions(ctr->info.n_nodes, ctr->info.W, ctr->info.I, (uint32_t)F, NULL) * 128.0 > cap) --F;
+        const uint32_t bw = bucket_words_default();
+        while (F > 0 && (double)compute_regions(ctr->info.n_nodes, ctr->info.W, ctr->info.I, bw, (uint32_t)F, NULL) * 8.0 * bw > cap) --F;
         return F;
     }
     if (fine_bits < 0) fine_bits = 0;
@@ -89,9 +98,10 @@ static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
     /* UTREE_FORCE_OFF64: test hook that runs the 64-bit-offset instantiations (N >= 2^32-1 databases) on small files */
     h->flags = (ctr->info.binix_width == 8 || getenv("UTREE_FORCE_OFF64")) ? UTREE_F_OFF64 : 0;
-    h->n_slots = compute_regions(h->n_nodes, h->W, h->I, F, h->regions);
+    h->bucket_words = bucket_words_default();
+    h->n_slots = compute_regions(h->n_nodes, h->W, h->I, h->bucket_words, F, h->regions);
     uint64_t off = UTREE_IMG_HEADER_BYTES;
-    h->off_table = off; off = align_up(off + h->n_slots * 128, 4096);
+    h->off_table = off; off = align_up(off + h->n_slots * 8 * h->bucket_words, 4096);
     h->off_mrecs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 4096);
     h->off_coarse = off; off = align_up(off + (uint64_t)UTREE_NUMBINS * ((h->flags & UTREE_F_OFF64) ? 8 : 4), 256);
     h->off_irreg = off; off = align_up(off + (1u << 24) / 8, 256);
@@ -131,6 +141,7 @@ static void bind_image(utree_dev *d) {
     d->kimg.fine_bits = d->hdr.fine_bits;
     d->kimg.flags = d->hdr.flags;
     d->kimg.W = d->hdr.W; d->kimg.I = d->hdr.I;
+    d->kimg.bucket_words = d->hdr.bucket_words;
     d->kimg.irr_n = 0;
     for (int i = 0; i < 4; ++i) d->kimg.irr_p[i] = 0xFFFFFFFFu;
     if (d->hdr.flags & UTREE_F_GENERIC) d->kimg.irr_n = 0xFFFFFFFFu;
@@ -345,7 +356,7 @@ static int build_finish(builder *b, const void *d_binix_raw) {
         HIPCHK(hipMemsetAsync(b->d_counters, 0, 16, st));
         HIPCHK(hipMemcpyAsync(img, &d->hdr, sizeof d->hdr, hipMemcpyHostToDevice, st));   /* the kernels read the region table there */
         KCHK(utk_build_min(d->hdr.W, d->hdr.I, off64, coarse, recs, c0, d->hdr.n_min, (const uint64_t *)(img + offsetof(utree_image_header, regions)),
-                           d->hdr.regions, d->hdr.n_slots, (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs),
+                           d->hdr.regions, d->hdr.n_slots, d->hdr.bucket_words, (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs),
                            (uint32_t *)(img + d->hdr.off_irreg), b->d_counters, st));
         KCHK(utk_fill_recs_pad((uint64_t *)(img + d->hdr.off_mrecs) + d->hdr.n_min * d->hdr.rec_words, 8 * d->hdr.rec_words, st));
         HIPCHK(hipMemcpyAsync(counters, b->d_counters, 16, hipMemcpyDeviceToHost, st));
@@ -364,7 +375,7 @@ static int build_finish(builder *b, const void *d_binix_raw) {
         {
             uint64_t kept = 0;
             const utree_image_header o = d->hdr;
-            KCHK(utk_compact_overflow(o.W, o.I, (uint64_t *)(img + o.off_table), o.n_slots, (uint64_t *)(img + o.off_mrecs), &kept, st));
+            KCHK(utk_compact_overflow(o.W, o.I, (uint64_t *)(img + o.off_table), o.n_slots, o.bucket_words, (uint64_t *)(img + o.off_mrecs), &kept, st));
             KCHK(utk_fill_recs_pad((uint64_t *)(img + o.off_mrecs) + kept * o.rec_words, 8 * o.rec_words, st));
             utree_image_header *h = &d->hdr;
             const uint64_t coarse_b = (uint64_t)UTREE_NUMBINS * ((o.flags & UTREE_F_OFF64) ? 8 : 4), irreg_b = (1u << 24) / 8;
@@ -511,7 +522,8 @@ int utree_dev_attach(const utree_ctr *ctr, int device, void *d_image, size_t byt
     d->device = device; d->n_cu = n_cu; d->image = d_image; d->owns = 0;
     lanes_ring_init(d);
     HIPCHK(hipMemcpy(&d->hdr, d_image, sizeof d->hdr, hipMemcpyDeviceToHost));
-    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != UTREE_IMG_VERSION || d->hdr.total_bytes > bytes) { rc = UTREE_E_FORMAT; goto fail; }
+    if (d->hdr.magic != UTREE_IMG_MAGIC || d->hdr.version != UTREE_IMG_VERSION || d->hdr.total_bytes > bytes ||
+        (d->hdr.bucket_words != 8 && d->hdr.bucket_words != 16)) { rc = UTREE_E_FORMAT; goto fail; }
     if (ctr && (ctr->info.W != d->hdr.W || ctr->info.I != d->hdr.I || ctr->info.n_nodes != d->hdr.n_nodes ||
                 ctr->info.n_labels != d->hdr.n_labels)) { rc = UTREE_E_ARG; goto fail; }
     d->image_bytes = d->hdr.total_bytes;
@@ -553,6 +565,7 @@ int utree_dev_get_info(const utree_dev *d, utree_dev_info *info) {
     info->device = d->device;
     info->vote_table = d->kimg.vote_tab != NULL;
     info->lane_pass = utk_lanes_image_ok(&d->kimg) != 0;
+    info->bucket_bytes = 8u * d->hdr.bucket_words;
     return UTREE_OK;
 }
 
@@ -830,12 +843,12 @@ const char *utree_classify_kernel_name(const utree_dev *dc) {
     if (!dc) return "";
     utree_dev *d = (utree_dev *)dc;                       /* the signature string lives in the handle */
     if (d->last_lanes && d->last_pieces) {
-        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, 16, %s, 2>", d->hdr.W, d->hdr.I, d->kimg.irr_n ? "true" : "false");
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, 16, %s, 2, %u>", d->hdr.W, d->hdr.I, d->kimg.irr_n ? "true" : "false", d->hdr.bucket_words / 8);
         return d->kernel_sig;
     }
     if (d->last_lanes) {      /* (a mixed batch: the instantiation its longest read takes) */
-        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, %d, %s, %d>", d->hdr.W, d->hdr.I, d->last_lanes, d->kimg.irr_n ? "true" : "false",
-                 d->last_mixed ? 1 : 0);
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, %d, %s, %d, %u>", d->hdr.W, d->hdr.I, d->last_lanes, d->kimg.irr_n ? "true" : "false",
+                 d->last_mixed ? 1 : 0, d->hdr.bucket_words / 8);
         return d->kernel_sig;
     }
     return d->last_long ? utk_classify_long_name(&d->kimg, d->kernel_sig, sizeof d->kernel_sig)

@@ -20,13 +20,13 @@ namespace utk {
 constexpr uint64_t M40 = (1ull << 40) - 1;
 constexpr uint32_t INVALID = 0xFFFFFFFFu;
 
-// A bucket of the table is one 128-byte HBM line (image version 9: a lookup moves a whole line whatever it reads of it).
-constexpr uint32_t BUCKET_WORDS = 16, BUCKET_BYTES = 8 * BUCKET_WORDS;
+// A bucket of the table is 64 bytes (image.bucket_words = 8: half an HBM line -- the kernels scan half as many entries per lookup and are
+// 5-10 % faster) or one whole 128-byte line (bucket_words = 16: the same lines fetched, fewer overflowing buckets at twice the load: an
+// image a third smaller).  Chosen when the image is built.
 template <int W, int I> struct RecTraits {
     static constexpr int EW = (W == 16 ? 2 : 1) * (I == 4 ? 2 : 1);   // 8-byte words per record / table slot
     static constexpr int KW = (W == 16 ? 1 : 0);                       // word holding the top key bits, flag, rank16
-    static constexpr int CAP = (int)BUCKET_WORDS / EW;                 // entries of a bucket: 16 (k = 32, u16 labels), 8, 8, 4
-    static constexpr int HCAP = CAP / 2;                               // ... of one 64-byte half (what the wave-per-read kernels load at a time)
+    static constexpr int HCAP = 8 / EW;                                // entries of 64 bytes (a small bucket, or half a large one): 8, 4, 4, 2
 };
 template <int W, int I> struct Entry { uint64_t w[RecTraits<W, I>::EW]; };
 

@@ -154,9 +154,10 @@ __global__ void emit_k(const uint64_t *__restrict__ recs, uint64_t c0, const IDX
 // rest of the bucket stays flagged empty); a longer run leaves CAP-1 records inline and an overflow descriptor last.
 template <int W, int I>
 __global__ void bucket_k(const uint32_t *__restrict__ Hs, const uint64_t *__restrict__ mrecs, uint64_t base, uint64_t m,
-                         const uint64_t *__restrict__ regions, uint64_t *__restrict__ table, uint64_t run_max, unsigned long long *overflow) {
+                         const uint64_t *__restrict__ regions, uint64_t *__restrict__ table, uint32_t bw, uint64_t run_max, unsigned long long *overflow) {
     // Hs / mrecs: this part's sorted hashes and records (a part = a range of whole buckets); base = MIN records in earlier parts
-    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = RecTraits<W, I>::CAP;
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+    const int CAP = (int)bw / EW;                                                     // entries of a bucket (bw = its 8-byte words: 8 or 16)
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t b, bp; uint32_t hl;
         bucket_of(regions, Hs[j], b, hl);
@@ -168,7 +169,7 @@ __global__ void bucket_k(const uint32_t *__restrict__ Hs, const uint64_t *__rest
             if (bp != b) break;
             ++n;
         }
-        uint64_t *o = table + b * BUCKET_WORDS;                                       // 128 bytes per bucket
+        uint64_t *o = table + b * bw;
         const uint64_t inl = n <= (uint64_t)CAP ? n : (uint64_t)CAP - 1;
         for (uint64_t q = 0; q < inl; ++q)
 #pragma unroll
@@ -191,13 +192,14 @@ __global__ void bucket_k(const uint32_t *__restrict__ Hs, const uint64_t *__rest
 // hash is 0: all of them share the first bucket).
 template <int W, int I, typename OFF, typename IDX>
 __global__ void flag_saturated_k(const uint32_t *__restrict__ Hs, const IDX *__restrict__ idx, uint64_t m, uint64_t c0,
-                                 const OFF *__restrict__ coarse, const uint64_t *__restrict__ regions, const uint64_t *__restrict__ table,
+                                 const OFF *__restrict__ coarse, const uint64_t *__restrict__ regions, const uint64_t *__restrict__ table, uint32_t bw,
                                  uint32_t *irreg, unsigned long long *counters) {
-    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = RecTraits<W, I>::CAP;
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+    const int CAP = (int)bw / EW;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t b; uint32_t hl;
         bucket_of(regions, Hs[j], b, hl);
-        const uint64_t d = table[b * BUCKET_WORDS + (uint64_t)(CAP - 1) * EW + KW];
+        const uint64_t d = table[b * bw + (uint64_t)(CAP - 1) * EW + KW];
         if ((d >> 62) != 2 || ((d >> 40) & 0x3FFFFFull) != 0x3FFFFFull) continue;
         const uint32_t p = bin_of<OFF>(coarse, c0 + (uint64_t)idx[j]);
         const uint32_t bit = 1u << (p & 31);
@@ -209,22 +211,24 @@ __global__ void flag_saturated_k(const uint32_t *__restrict__ Hs, const IDX *__r
 // are found there).  ovf_count_k / ovf_move_k keep those runs alone, packed in bucket order, and point the descriptors at
 // their new places: the sorted array of ALL nodes (8-32 bytes per node) leaves the image.
 template <int W, int I>
-__global__ void ovf_count_k(const uint64_t *__restrict__ table, uint64_t n_buckets, uint32_t *__restrict__ cnt) {
-    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = RecTraits<W, I>::CAP;
+__global__ void ovf_count_k(const uint64_t *__restrict__ table, uint64_t n_buckets, uint32_t bw, uint32_t *__restrict__ cnt) {
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+    const int CAP = (int)bw / EW;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t d = table[b * BUCKET_WORDS + (uint64_t)(CAP - 1) * EW + KW];
+        const uint64_t d = table[b * bw + (uint64_t)(CAP - 1) * EW + KW];
         uint32_t c = (d >> 62) == 2 ? (uint32_t)((d >> 40) & 0x3FFFFFull) : 0u;
         if (c == 0x3FFFFFu) c = 0;           // a saturated run is never followed (its nodes' bins take the exact-probe path): nothing to keep
         cnt[b] = c;
     }
 }
 template <int W, int I>
-__global__ void ovf_move_k(uint64_t *__restrict__ table, uint64_t n_buckets, const uint32_t *__restrict__ cnt,
+__global__ void ovf_move_k(uint64_t *__restrict__ table, uint64_t n_buckets, uint32_t bw, const uint32_t *__restrict__ cnt,
                            const uint64_t *__restrict__ prefix, const uint64_t *__restrict__ mrecs, uint64_t *__restrict__ packed) {
-    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAP = RecTraits<W, I>::CAP;
+    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+    const int CAP = (int)bw / EW;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t c = cnt[b];
-        uint64_t *dp = table + b * BUCKET_WORDS + (uint64_t)(CAP - 1) * EW + KW;
+        uint64_t *dp = table + b * bw + (uint64_t)(CAP - 1) * EW + KW;
         if (!c) {
             // a saturated descriptor becomes an empty run: a word that is no node finds nothing there (words of nodes never come here)
             if ((*dp >> 62) == 2) *dp = MFLAG_RUN;
@@ -322,9 +326,9 @@ struct in_part {
 // nodes are handled in 2^pb parts by the top bits of the hash -- parts are contiguous in the final order.
 template <int W, int I, typename OFF, typename IDX>
 int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, const uint64_t *regions, const uint64_t *h_regions, uint64_t n_buckets,
-              uint64_t *table, uint64_t *mrecs, uint32_t *irreg, unsigned long long *d_overflow, hipStream_t st) {
+              uint32_t bw, uint64_t *table, uint64_t *mrecs, uint32_t *irreg, unsigned long long *d_overflow, hipStream_t st) {
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
-    const uint64_t nslots = n_buckets * (BUCKET_WORDS / EW);                           // entries, all flagged empty to begin with
+    const uint64_t nslots = n_buckets * (bw / EW);                           // entries, all flagged empty to begin with
     for (int x = 0; x < EW; ++x) fill_u64_k<<<grid_for(nslots), 256, 0, st>>>(table, nslots, x == KW ? MFLAG_EMPTY : 0ull, EW, x);
     if (!m) return (int)hipGetLastError();
     uint32_t *H = nullptr, *Hg = nullptr, *Hg2 = nullptr; (void)Hg2;
@@ -444,14 +448,14 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
         Hg = (uint32_t *)kg; Hg2 = (uint32_t *)kg2;
         // emit_k recomputes the hashes from H[idx]: Hg becomes the array of hashes in the final order
         emit_k<W, I, IDX><<<grid_for(mq), 256, 0, st>>>(recs, c0, idx, H, K1, K2, regions, mq, mrecs + base * EW, Hg);
-        bucket_k<W, I><<<grid_for(mq), 256, 0, st>>>(Hg, mrecs + base * EW, base, mq, regions, table, run_max, d_overflow);
+        bucket_k<W, I><<<grid_for(mq), 256, 0, st>>>(Hg, mrecs + base * EW, base, mq, regions, table, bw, run_max, d_overflow);
         CK(hipGetLastError());
         {
             unsigned long long sat = 0;
             CK(hipMemcpyAsync(&sat, d_overflow, 8, hipMemcpyDeviceToHost, st));
             CK(hipStreamSynchronize(st));
             if (sat != sat_seen) {                  // this part has saturated buckets: their nodes' bins take the exact-probe path
-                flag_saturated_k<W, I, OFF, IDX><<<grid_for(mq), 256, 0, st>>>(Hg, idx, mq, c0, coarse, regions, table, irreg, d_overflow);
+                flag_saturated_k<W, I, OFF, IDX><<<grid_for(mq), 256, 0, st>>>(Hg, idx, mq, c0, coarse, regions, table, bw, irreg, d_overflow);
                 CK(hipGetLastError());
                 sat_seen = sat;
             }
@@ -516,7 +520,7 @@ int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream) {
 
 struct widen32 { __device__ uint64_t operator()(uint32_t v) const { return v; } };
 /* Pack the overflow runs to the front of d_mrecs (bucket order) and repoint the buckets' descriptors; *n_kept = records kept. */
-int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n_buckets, uint64_t *d_mrecs, uint64_t *n_kept, void *stream) {
+int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n_buckets, uint32_t bw, uint64_t *d_mrecs, uint64_t *n_kept, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     uint32_t *cnt = nullptr;
     uint64_t *prefix = nullptr, *packed = nullptr;
@@ -531,7 +535,7 @@ int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n
     CK(hipMemsetAsync(cnt + n_buckets, 0, 4, st));
     {
         int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
-            ovf_count_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(n_buckets) > 65536 ? 65536 : grid_for(n_buckets)), dim3(256), 0, st>>>(d_table, n_buckets, cnt);
+            ovf_count_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(n_buckets) > 65536 ? 65536 : grid_for(n_buckets)), dim3(256), 0, st>>>(d_table, n_buckets, bw, cnt);
         });
         if (drc) { rc = drc; goto done; }
     }
@@ -548,7 +552,7 @@ int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n
             CK(hipMalloc((void **)&packed, (size_t)total * EW * 8));
             int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
                 ovf_move_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(n_buckets) > 65536 ? 65536 : grid_for(n_buckets)), dim3(256), 0, st>>>(
-                    d_table, n_buckets, cnt, prefix, d_mrecs, packed);
+                    d_table, n_buckets, bw, cnt, prefix, d_mrecs, packed);
             });
             if (drc) { rc = drc; goto done; }
             CK(hipMemcpyAsync(d_mrecs, packed, (size_t)total * EW * 8, hipMemcpyDeviceToDevice, st));
@@ -564,16 +568,16 @@ done:
 /* nodes [c0, c0+m) = what the (monotone) bin table reaches.  d_overflow[0] += buckets whose run saturates the descriptor,
  * d_overflow[1] += bins newly flagged in d_irreg because of them. */
 int utk_build_min(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
-                  const uint64_t *d_regions, const uint64_t *h_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
+                  const uint64_t *d_regions, const uint64_t *h_regions, uint64_t n_buckets, uint32_t bw, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
                   unsigned long long *d_overflow, void *stream) {
     int rc = 0;
     int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
         constexpr int W = decltype(w)::value, I = decltype(i)::value;
         hipStream_t st = (hipStream_t)stream;
         const bool idx64 = m >= 0xFFFFFFFFull;
-        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
-        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
-        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, d_table, d_mrecs, d_irreg, d_overflow, st);
+        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, bw, d_table, d_mrecs, d_irreg, d_overflow, st);
+        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, bw, d_table, d_mrecs, d_irreg, d_overflow, st);
+        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, bw, d_table, d_mrecs, d_irreg, d_overflow, st);
     });
     return rc ? rc : drc;
 }

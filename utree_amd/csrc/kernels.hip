@@ -120,8 +120,8 @@ __device__ __forceinline__ void build_minkeys(const uint32_t *s, uint32_t sh, ui
 }
 
 // The block's copy of the image's region table in the form the window loop wants it (stage_regions):
-//   s_reg[r] = the header's entry, first bucket << 25 | buckets of the region: bucket address = table + ((first + mulhi(h << 8, nb)) << 7)
-struct RegionLds { const uint64_t *reg; uint64_t table; };
+//   s_reg[r] = the header's entry, first bucket << 25 | buckets of the region: bucket address = table + ((first + mulhi(h << 8, nb)) << 6 or 7)
+struct RegionLds { const uint64_t *reg; uint64_t table; uint32_t bshift; };   // bshift: log2 of a bucket's bytes
 
 // One wave looks up the windows [w0, w0+n) of a staged buffer (lb / sw = packed bases, sbad = bad-base bit words, both
 // indexed from the buffer's first base; w0 a multiple of 64) and hands every lane's result to on_rank(rank) -- called by all
@@ -156,9 +156,9 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const Lan
             const uint64_t re = rg.reg[h >> 24];
             const uint32_t bl = __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u));
 #ifdef UTREE_ABLATE_L2
-            baddr = rg.table + ((uint64_t)(bl & 0x1FFFu) << 7);             // timing experiment: every bucket inside 1 MB (L2 hits), answers wrong
+            baddr = rg.table + ((uint64_t)(bl & 0x1FFFu) << rg.bshift);     // timing experiment: every bucket inside 1 MB (L2 hits), answers wrong
 #else
-            baddr = rg.table + (((re >> UTREE_REGION_NB_BITS) + bl) << 7);
+            baddr = rg.table + (((re >> UTREE_REGION_NB_BITS) + bl) << rg.bshift);
 #endif
             tag = ((h & 0xFFu) << 6) | pos;                                 // hash bits the bucket does not imply | position (< 64)
         };
@@ -422,7 +422,7 @@ void classify_short_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     static_assert(PREFETCH || sizeof(HIT) * CAP >= 4 * (RawBuf<CAP>::DW + 4), "raw bytes must fit the hit list");
     __shared__ uint32_t s_raw[PREFETCH ? WAVES_PER_BLOCK : 1][PREFETCH ? RawBuf<CAP>::DW + 4 : 1];
     stage_regions(im, s_reg);
-    const RegionLds rg = {s_reg, (uint64_t)(uintptr_t)im.table};
+    const RegionLds rg = {s_reg, (uint64_t)(uintptr_t)im.table, im.bucket_words == 16u ? 7u : 6u};
     const uint32_t lane = lane_id();
     const uint32_t wv = uni32(threadIdx.x >> 6);
     uint32_t *raw = PREFETCH ? s_raw[wv] : (uint32_t *)s_hits[wv];
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(LONG_THREADS, EXC ? 5 : 8) void classify_long_k(utk
     const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
     if (nbw <= LONG_LDS_BITWORDS) for (uint32_t x = tid; x < nbw; x += LONG_THREADS) s_touch[x] = 0;
     stage_regions(im, s_reg);
-    const RegionLds rg = {s_reg, (uint64_t)(uintptr_t)im.table};
+    const RegionLds rg = {s_reg, (uint64_t)(uintptr_t)im.table, im.bucket_words == 16u ? 7u : 6u};
 
     for (;;) {
         // long reads differ in length by orders of magnitude: hand them out one at a time
@@ -1114,11 +1114,12 @@ __global__ __launch_bounds__(256) void model_k(utk_image im, const uint8_t *__re
                 ++c_win;
                 bool first_b = true, first_l = true;
                 for (uint32_t j = 0; j < i; ++j) { const uint64_t x = s_b[wv][j]; first_b = first_b && x != b; }
-                first_l = first_b;                                                       // (a bucket is a 128-byte line)
+                if (im.bucket_words == 16u) first_l = first_b;                           // (the bucket is the 128-byte line)
+                else for (uint32_t j = 0; j < i; ++j) { const uint64_t x = s_b[wv][j]; first_l = first_l && (x == ~0ull || (x >> 1) != (b >> 1)); }
                 c_buck += first_b; c_line += first_l;
                 if (first_b) {
-                    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW, CAPF = RecTraits<W, I>::CAP;
-                    c_over += (im.table[b * BUCKET_WORDS + (uint64_t)(CAPF - 1) * EW + KW] >> 62) == 2;
+                    constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
+                    c_over += (im.table[b * im.bucket_words + (uint64_t)(im.bucket_words / EW - 1) * EW + KW] >> 62) == 2;
                 }
             }
             wave_lds_fence();

@@ -114,7 +114,9 @@ __device__ __forceinline__ void rest96(const uint32_t (&A)[3], const uint32_t (&
 // (ws.ltab_*), which finish_long_k turns into the read's result
 // I: bytes of a label index (2, or 4 with k = 32: tally slots then keep 19 bits of rank and 13 of count, which bounds the labels of such
 // an image -- utk_lanes_image_ok)
-template <int W, int I, int SEGS, bool IRR, int MODE>
+// NL: 16-byte loads a lane makes per bucket -- 1: the image has 64-byte buckets (a quad of lanes fetches one with one request), 2: 128-byte
+// buckets (two requests, the two halves of one line)
+template <int W, int I, int SEGS, bool IRR, int MODE, int NL>
 __global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
 void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
                       uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws, uint32_t cls) {
@@ -145,7 +147,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     // the 128-byte bucket of a minimizer hash (device_common.hpp: bucket_of)
     auto bucket_addr = [&](uint32_t h) -> uint64_t {
         const uint64_t re = s_reg[h >> 24];
-        return tbl + (((re >> UTREE_REGION_NB_BITS) + __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u))) << 7);
+        return tbl + (((re >> UTREE_REGION_NB_BITS) + __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u))) << (NL == 2 ? 7 : 6));
     };
     const uint32_t lane = lane_id();
     const uint32_t wv = uni32(threadIdx.x >> 6);
@@ -432,16 +434,21 @@ _Pragma("unroll") \
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) u32x4 *gptr128;
 #define QUAD_BCAST(v, k) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (k) * 0x55, 0xF, 0xF, true))
-        // (lane j of a quad fetches bytes 16 j .. 16 j + 15 of both 64-byte halves of each of the quad's four buckets: P[2 k] and
-        // P[2 k + 1] of run k; the two requests of a quad for one bucket are the two halves of one 128-byte line)
-        auto issue = [&](const RunRegs &c, u32x4 (&P)[8]) {
-            const uint64_t a = bucket_addr(c.h);                                                       // 128-byte aligned
+        // 64-byte buckets (NL = 1): a batch of 64 runs is fetched with FOUR loads of 16 buckets each -- lane j of a quad fetches bytes 16 j ..
+        // 16 j + 15 of the bucket of each of the quad's four runs: P[k] of run k --, three batches deep.
+        // 128-byte buckets (NL = 2): a batch is fetched and scanned in two HALVES of 32 runs -- the quad takes two of its four runs at a
+        // time (runs 2 half, 2 half + 1); lane j fetches bytes 16 j .. 16 j + 15 of both 64-byte halves of each of the two buckets: P[0],
+        // P[1] of the first run, P[2], P[3] of the second; the two requests of a quad for one bucket are the two halves of one line --,
+        // three half-batches deep.  Either way 16 registers per unit in flight, 8 KB of buckets in flight while one unit is scanned.
+#define ISSUE_K(k, at) { const uint64_t b_ = ((uint64_t)QUAD_BCAST(ahi, k) << 32) | (QUAD_BCAST(alo, k) | mine); \
+                         P[at] = *(gptr128)b_; if constexpr (NL == 2) P[at + 1] = *(gptr128)(b_ | 64u); }
+        auto issue = [&](const RunRegs &c, const uint32_t half, u32x4 (&P)[4]) {
+            const uint64_t a = bucket_addr(c.h);                                                       // aligned to the bucket's size
             const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32), mine = 16u * (lane & 3u);
-#define ISSUE_K(k) { const uint64_t b_ = ((uint64_t)QUAD_BCAST(ahi, k) << 32) | (QUAD_BCAST(alo, k) | mine); \
-                     P[2 * k] = *(gptr128)b_; P[2 * k + 1] = *(gptr128)(b_ | 64u); }
-            ISSUE_K(0) ISSUE_K(1) ISSUE_K(2) ISSUE_K(3)
-#undef ISSUE_K
+            if constexpr (NL == 1) { ISSUE_K(0, 0) ISSUE_K(1, 1) ISSUE_K(2, 2) ISSUE_K(3, 3) }
+            else if (half == 0u) { ISSUE_K(0, 0) ISSUE_K(1, 2) } else { ISSUE_K(2, 0) ISSUE_K(3, 2) }
         };
+#undef ISSUE_K
         auto push = [&](uint32_t q, uint32_t rank) {                  // q: the lane whose slot the hit was found in
             const uint32_t rd = q >> SEGSH;
             uint32_t *t = tab + rd;
@@ -514,13 +521,14 @@ _Pragma("unroll") \
                 }
             }
         };
-        auto scan = [&](const RunRegs &c, const u32x4 (&P)[8]) {
+        auto scan = [&](const RunRegs &c, const uint32_t half, const u32x4 (&P)[4]) {
             uint32_t p0 = 0, p1 = 0, np = 0;
-#define SCAN_K(k) { uint32_t bA[NA], bB[NA]; \
-                    _Pragma("unroll") for (uint32_t i = 0; i < NA; ++i) { bA[i] = QUAD_BCAST(c.A[i], k); bB[i] = QUAD_BCAST(c.B[i], k); } \
-                    const uint32_t bt = QUAD_BCAST(c.t, k), bpk = QUAD_BCAST(c.pk, k); \
-                    scan1(bt, bpk, bA, bB, P[2 * k], false, p0, p1, np); scan1(bt, bpk, bA, bB, P[2 * k + 1], true, p0, p1, np); }
-            SCAN_K(0) SCAN_K(1) SCAN_K(2) SCAN_K(3)
+#define SCAN_K(k, at) { uint32_t bA[NA], bB[NA]; \
+                        _Pragma("unroll") for (uint32_t i = 0; i < NA; ++i) { bA[i] = QUAD_BCAST(c.A[i], k); bB[i] = QUAD_BCAST(c.B[i], k); } \
+                        const uint32_t bt = QUAD_BCAST(c.t, k), bpk = QUAD_BCAST(c.pk, k); \
+                        scan1(bt, bpk, bA, bB, P[at], NL == 1, p0, p1, np); if constexpr (NL == 2) scan1(bt, bpk, bA, bB, P[at + 1], true, p0, p1, np); }
+            if constexpr (NL == 1) { SCAN_K(0, 0) SCAN_K(1, 1) SCAN_K(2, 2) SCAN_K(3, 3) }
+            else if (half == 0u) { SCAN_K(0, 0) SCAN_K(1, 2) } else { SCAN_K(2, 0) SCAN_K(3, 2) }
 #undef SCAN_K
             if (ballot64(np != 0u)) {
                 if (np >= 1u) push(p0 >> QS, p0 & QMASK);
@@ -528,32 +536,42 @@ _Pragma("unroll") \
             }
         };
         if (nruns) {
-            // two batches of 64 buckets (16 KB) in flight: one is scanned while the next arrives
+            // No branch around a load: the waits then count them (a batch beyond the list repeats the list's last run as one no entry
+            // belongs to).
             const uint32_t nit = (nruns + 63u) >> 6;
-#ifdef UTREE_LANES_DEPTH3
             RunRegs R0, R1, R2;
-            u32x4 P0[8], P1[8], P2[8];
-            prepare(0u, R0); issue(R0, P0);
-            prepare(1u, R1); issue(R1, P1);
-            for (uint32_t it = 0; it < nit; it += 3) {
-                prepare(it + 2, R2); issue(R2, P2);
-                scan(R0, P0);
-                prepare(it + 3, R0); issue(R0, P0);
-                if (it + 1 < nit) scan(R1, P1);
-                prepare(it + 4, R1); issue(R1, P1);
-                if (it + 2 < nit) scan(R2, P2);
+            u32x4 P0[4], P1[4], P2[4];
+            if constexpr (NL == 1) {
+                // three batches deep: two (8 KB of buckets) in flight while one is scanned
+                prepare(0u, R0); issue(R0, 0u, P0);
+                prepare(1u, R1); issue(R1, 0u, P1);
+                for (uint32_t it = 0; it < nit; it += 3) {
+                    prepare(it + 2, R2); issue(R2, 0u, P2);
+                    scan(R0, 0u, P0);
+                    prepare(it + 3, R0); issue(R0, 0u, P0);
+                    if (it + 1 < nit) scan(R1, 0u, P1);
+                    prepare(it + 4, R1); issue(R1, 0u, P1);
+                    if (it + 2 < nit) scan(R2, 0u, P2);
+                }
+            } else {
+                // three half-batches deep: batch `it` lives in R[it mod 3], its halves in P[(2 it) mod 3], P[(2 it + 1) mod 3] -- the loop
+                // body is six half-batches, after which the names repeat
+                prepare(0u, R0); issue(R0, 0u, P0); issue(R0, 1u, P1);
+                for (uint32_t it = 0; it < nit; it += 3) {
+                    prepare(it + 1, R1); issue(R1, 0u, P2);
+                    scan(R0, 0u, P0);
+                    issue(R1, 1u, P0);
+                    scan(R0, 1u, P1);
+                    prepare(it + 2, R2); issue(R2, 0u, P1);
+                    if (it + 1 < nit) scan(R1, 0u, P2);
+                    issue(R2, 1u, P2);
+                    if (it + 1 < nit) scan(R1, 1u, P0);
+                    prepare(it + 3, R0); issue(R0, 0u, P0);
+                    if (it + 2 < nit) scan(R2, 0u, P1);
+                    issue(R0, 1u, P1);
+                    if (it + 2 < nit) scan(R2, 1u, P2);
+                }
             }
-#else
-            RunRegs R0, R1;
-            u32x4 P0[8], P1[8];
-            prepare(0u, R0); issue(R0, P0);
-            for (uint32_t it = 0; it < nit; it += 2) {                        // no branch around a load: the waits then count them
-                prepare(it + 1, R1); issue(R1, P1);
-                scan(R0, P0);
-                prepare(it + 2, R0); issue(R0, P0);
-                if (it + 1 < nit) scan(R1, P1);
-            }
-#endif
         }
 #undef QUAD_BCAST
         // ---- runs whose bucket overflows.  The bucket's last entry names the run of MIN records that holds the rest of its nodes.  A
@@ -579,7 +597,7 @@ _Pragma("unroll") \
                 context(rec >> 24, rec & 0xFFu, m, A, B);
                 const uint32_t h = mix32(m);
                 const uint64_t baddr = bucket_addr(h);
-                const uint64_t dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + (BUCKET_BYTES - 8u * EW + 8u * KW));   // the key word of the bucket's last entry
+                const uint64_t dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + (64u * NL - 8u * EW + 8u * KW));   // the key word of the bucket's last entry
                 const uint64_t n = (dsc >> 40) & 0x3FFFFFull;
                 ost[lane] = dsc;
                 if (n <= OVF_SCAN) nrec = (uint32_t)n; else wn = ((rec >> 16) & 0xFFu) - ((rec >> 8) & 0xFFu);
@@ -779,14 +797,15 @@ _Pragma("unroll") \
 #endif
 }
 
-template <int W, int I, int SEGS, bool IRR, int MODE = 0>
+template <int W, int I, int SEGS, bool IRR, int MODE, int NL>
 static int launch_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                         int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream, uint32_t cls = 0) {
+    static_assert(NL == 1 || NL == 2, "bucket size");
     uint32_t blocks = (n_reads + (64u / SEGS) * LANES_WAVES - 1) / ((64u / SEGS) * LANES_WAVES);
     const uint32_t wps = W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS;
     const uint32_t cap = (uint32_t)n_cu * (4u * wps / LANES_WAVES > 0 ? 4u * wps / LANES_WAVES : 1u);
     if (blocks > cap) blocks = cap;
-    classify_lanes_k<W, I, SEGS, IRR, MODE><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws, cls);
+    classify_lanes_k<W, I, SEGS, IRR, MODE, NL><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws, cls);
     return (int)hipGetLastError();
 }
 
@@ -879,17 +898,19 @@ extern "C" {
 int utk_lanes_image_ok(const utk_image *im) {
     const bool fmt = (im->W == 8 && (im->I == 2 || (im->I == 4 && im->n_labels < (1u << 19) - 1u))) || (im->W == 16 && im->I == 2);
     // (a node whose label index is beyond the label list can never be a hit, itree.c:929: the scan here does not test for that)
-    return fmt && im->irr_n <= 4u && ((uintptr_t)im->table & 127u) == 0 && !(im->flags & UTREE_F_INVALID_RANKS);
+    return fmt && im->irr_n <= 4u && ((uintptr_t)im->table & (8u * im->bucket_words - 1u)) == 0 && !(im->flags & UTREE_F_INVALID_RANKS);
 }
 
 // reads of up to this many bases take 2^c lanes (c = 0 .. 4)
 static uint32_t lanes_cap(const utk_image *im, int c) { return ((1u << c) - 1u) * (LCAP - 4u * im->W + 1u) + LCAP; }
 uint32_t utk_lanes_max_len(const utk_image *im) { return lanes_cap(im, 4); }
 
+#define LANES_DISPATCH_NL(SEGS_, MODE_, NL_, ...) do { \
+    if (im->W == 16) return im->irr_n ? launch_lanes<16, 2, SEGS_, true, MODE_, NL_>(__VA_ARGS__) : launch_lanes<16, 2, SEGS_, false, MODE_, NL_>(__VA_ARGS__); \
+    if (im->I == 4) return im->irr_n ? launch_lanes<8, 4, SEGS_, true, MODE_, NL_>(__VA_ARGS__) : launch_lanes<8, 4, SEGS_, false, MODE_, NL_>(__VA_ARGS__); \
+    return im->irr_n ? launch_lanes<8, 2, SEGS_, true, MODE_, NL_>(__VA_ARGS__) : launch_lanes<8, 2, SEGS_, false, MODE_, NL_>(__VA_ARGS__); } while (0)
 #define LANES_DISPATCH(SEGS_, MODE_, ...) do { \
-    if (im->W == 16) return im->irr_n ? launch_lanes<16, 2, SEGS_, true, MODE_>(__VA_ARGS__) : launch_lanes<16, 2, SEGS_, false, MODE_>(__VA_ARGS__); \
-    if (im->I == 4) return im->irr_n ? launch_lanes<8, 4, SEGS_, true, MODE_>(__VA_ARGS__) : launch_lanes<8, 4, SEGS_, false, MODE_>(__VA_ARGS__); \
-    return im->irr_n ? launch_lanes<8, 2, SEGS_, true, MODE_>(__VA_ARGS__) : launch_lanes<8, 2, SEGS_, false, MODE_>(__VA_ARGS__); } while (0)
+    if (im->bucket_words == 16u) LANES_DISPATCH_NL(SEGS_, MODE_, 2, __VA_ARGS__); else LANES_DISPATCH_NL(SEGS_, MODE_, 1, __VA_ARGS__); } while (0)
 
 static int lanes_pieces_launch(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, int do_rc,
                                utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {

@@ -13,7 +13,7 @@ extern "C" {
 #define UTREE_INVALID 0xFFFFFFFFu
 #define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
 #define UTREE_IMG_HEADER_BYTES 4096u
-#define UTREE_IMG_VERSION 9u                     /* 9: a bucket is a 128-byte line; any number of buckets per hash region */
+#define UTREE_IMG_VERSION 9u                     /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region */
 #define UTREE_REGION_NB_BITS 25                  /* regions[r] = base_r << 25 | nb_r (nb_r <= 2^24)                    */
 #define UTREE_TALLY_CHUNK 8192u                  /* tally entries a wave reserves with one atomic              */
 #define UTREE_CUR_LONG 32                        /* cursors[] index of the long-read counter (own 256-B line)   */
@@ -56,13 +56,14 @@ typedef struct {
     uint32_t version, W, I, k;
     uint32_t fine_bits, rec_words, n_labels, flags;
     uint64_t n_nodes;
-    uint64_t n_slots;                /* 128-byte buckets in the table (sum over the 256 hash regions)       */
+    uint64_t n_slots;                /* buckets in the table (sum over the 256 hash regions)                */
     uint64_t n_min;                  /* MIN records = nodes the bin table reaches                          */
     uint64_t off_table, off_mrecs, off_recs, off_coarse, off_irreg, off_label_off, off_label_blob, off_rank2ix;
     uint64_t label_blob_bytes;
     uint64_t n_irregular;
     uint64_t total_bytes;
     uint64_t off_vote;               /* 32 bytes per label, rank order (UTREE_F_VOTE_TABLE): see utk_vote_rec                    */
+    uint32_t bucket_words, pad0;     /* 8-byte words of a bucket: 8 (64 bytes: the faster kernels) or 16 (a whole 128-byte line: the smaller image) */
     /* Bucket addressing: region r = top 8 bits of the minimizer hash h; regions[r] = base_r << 25 | nb_r and
      * bucket = base_r + (((h & 0xFFFFFF) * nb_r) >> 24) with 2^16 <= nb_r <= 2^24 buckets in the region, so a bucket spans at most
      * 256 consecutive hash values and the low 8 bits of h go into the record key.  The hash is a MINIMUM of K-15 hashes, so
@@ -84,7 +85,7 @@ typedef struct {
 
 /* What kernels take by value. */
 typedef struct {
-    const uint64_t *table;           /* 128-byte buckets: 16 / rec_words entries each, ascending by key; see regions[] */
+    const uint64_t *table;           /* buckets of bucket_words x 8 bytes: bucket_words / rec_words entries each, ascending by key; see regions[] */
     const uint64_t *regions;         /* [256] in the image header                                              */
     const uint64_t *mrecs;           /* MIN records: nodes ordered by (minimizer hash, position, rest)        */
     const uint64_t *recs;            /* FILE records: nodes as the file orders them (exact-probe path only)   */
@@ -96,6 +97,7 @@ typedef struct {
     const uint64_t *vote_tab;        /* utk_vote_rec per rank, or NULL: vote_k reads the label bytes                       */
     uint64_t n_nodes;
     uint32_t n_labels, fine_bits, flags, W, I;
+    uint32_t bucket_words;           /* 8 or 16                                                              */
     /* the 24-bit prefixes of the irregular bins when there are at most four of them (COMPRESS' first-bin quirk makes one or two;
      * unused entries are ~0), else irr_n = ~0: what lets the lane-per-read pass tell the reads it must leave alone */
     uint32_t irr_n, irr_p[4];
@@ -112,9 +114,9 @@ int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_
 int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
                  uint32_t *d_irreg, unsigned long long *d_counters, void *stream);
 int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
-                  const uint64_t *d_regions, const uint64_t *h_regions, uint64_t n_buckets, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
-                  unsigned long long *d_overflow, void *stream);
-int utk_compact_overflow(uint32_t W, uint32_t I, uint64_t *d_table, uint64_t n_buckets, uint64_t *d_mrecs, uint64_t *n_kept, void *stream);
+                  const uint64_t *d_regions, const uint64_t *h_regions, uint64_t n_buckets, uint32_t bucket_words, uint64_t *d_table, uint64_t *d_mrecs,
+                  uint32_t *d_irreg, unsigned long long *d_overflow, void *stream);
+int utk_compact_overflow(uint32_t W, uint32_t I, uint64_t *d_table, uint64_t n_buckets, uint32_t bucket_words, uint64_t *d_mrecs, uint64_t *n_kept, void *stream);
 int utk_compress_chunk(uint32_t W, uint32_t I, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
                        void *d_out, void *stream);
 int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream);

@@ -28,20 +28,20 @@ template <int W, int I> static __device__ uint32_t min_find(const uint64_t *mrec
     return INVALID;
 }
 
-// A bucket = one 128-byte line = RecTraits::CAP entries, ascending by key and filled from entry 0, unused ones flagged empty; when more
-// nodes fall into a bucket its LAST entry is an overflow descriptor instead.  The wave-per-read kernels take a bucket one 64-byte HALF
-// at a time (16 registers, what they have room for): the lower half first, the upper half -- the same line: an L1 / L2 hit -- only when
-// the lower half is full and did not hold the key.  (The lane-per-read pass, lanes_kernel.hip, fetches the whole line with a quad of
-// lanes.)
+// A bucket = 64 or 128 bytes (image.bucket_words) of entries, ascending by key and filled from entry 0, unused ones flagged empty; when
+// more nodes fall into a bucket its LAST entry is an overflow descriptor instead.  The wave-per-read kernels take 64 bytes at a time (16
+// registers, what they have room for): of a 128-byte bucket the lower half first, the upper half -- the same line: an L1 / L2 hit -- only
+// when the lower half is full and did not hold the key.  (The lane-per-read pass, lanes_kernel.hip, fetches a whole bucket with a quad
+// of lanes.)
 template <int W, int I> struct BucketOf { static constexpr int CAP = RecTraits<W, I>::HCAP; };   // entries of a half
 template <int W, int I> struct Bucket { Entry<W, I> e[BucketOf<W, I>::CAP]; };
 
-// lower half of bucket `bucket` of the table
-template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket(const uint64_t *__restrict__ table, uint64_t bucket) {
+// first 64 bytes of bucket `bucket` of the table
+template <int W, int I> __device__ __forceinline__ Bucket<W, I> load_bucket(const uint64_t *__restrict__ table, uint64_t bucket, uint32_t bucket_words) {
     Bucket<W, I> b;
-    constexpr int HCAP = BucketOf<W, I>::CAP;
+    constexpr int HCAP = BucketOf<W, I>::CAP, EW = RecTraits<W, I>::EW;
 #pragma unroll
-    for (int i = 0; i < HCAP; ++i) b.e[i] = load_slot<W, I>(table, bucket * (2 * HCAP) + i);   // contiguous: 16-byte non-temporal loads
+    for (int i = 0; i < HCAP; ++i) b.e[i] = load_slot<W, I>(table, bucket * (bucket_words / EW) + i);   // contiguous: 16-byte non-temporal loads
     return b;
 }
 
@@ -126,14 +126,15 @@ __device__ __forceinline__ uint32_t resolve_bucket(const utk_image &im, const Bu
     }
     constexpr int HCAP = BucketOf<W, I>::CAP;
     uint32_t rank = scan_half<W, I>(b, mk);
-    if (rank == INVALID && mrec_flag<W, I>(b.e[HCAP - 1]) != 1) {                         // the lower half is full: the upper one
+    uint64_t last = b.e[HCAP - 1].w[RecTraits<W, I>::KW];                                 // the key word of the last entry looked at
+    if (im.bucket_words == 16u && rank == INVALID && (last >> 62) != 1) {                 // a 128-byte bucket whose lower half is full: the upper one
         const Bucket<W, I> u = load_bucket_at<W, I>(baddr + 64);
         rank = scan_half<W, I>(u, mk);
-        if (mrec_flag<W, I>(u.e[HCAP - 1]) == 2 && rank == INVALID) {                      // the rest of the bucket's nodes
-            const uint64_t d = u.e[HCAP - 1].w[RecTraits<W, I>::KW];
-            const uint64_t start = d & M40, n = (d >> 40) & 0x3FFFFFull;
-            rank = min_find<W, I>(im.mrecs, start, start + n, mk);
-        }
+        last = u.e[HCAP - 1].w[RecTraits<W, I>::KW];
+    } else if (im.bucket_words == 16u) last = 0;                                           // (the lower half's last entry is never a descriptor)
+    if ((last >> 62) == 2 && rank == INVALID) {                                            // the rest of the bucket's nodes
+        const uint64_t start = last & M40, n = (last >> 40) & 0x3FFFFFull;
+        rank = min_find<W, I>(im.mrecs, start, start + n, mk);
     }
     return rank;
 }
@@ -150,8 +151,8 @@ template <int W, int I, bool EXC, typename OFF>
 __device__ __forceinline__ uint32_t lookup_word(const utk_image &im, uint64_t khi, uint64_t klo) {
     uint64_t bucket; MinKey<W> mk;
     min_split<W>(khi, klo, im.regions, bucket, mk);
-    const Bucket<W, I> b = load_bucket<W, I>(im.table, bucket);
-    return resolve_bucket<W, I, EXC, OFF>(im, b, (uint64_t)(uintptr_t)im.table + bucket * BUCKET_BYTES, mk, khi, klo);
+    const Bucket<W, I> b = load_bucket<W, I>(im.table, bucket, im.bucket_words);
+    return resolve_bucket<W, I, EXC, OFF>(im, b, (uint64_t)(uintptr_t)im.table + bucket * (8u * im.bucket_words), mk, khi, klo);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -205,6 +205,70 @@ def make_reads(db: SynthDB, n_reads: int, read_len: int = 150, seed: int = READ_
     return SynthReads(bases=seq.contiguous().view(-1), off=off, length=length, n=n_reads, read_len=read_len)
 
 
+def lognormal_lengths(n_reads: int, mean: float = 10_000.0, sigma: float = 1.0, lo: int = 1_000, hi: int = 100_000, seed: int = READ_SEED):
+    """read lengths ~ lognormal with the given mean, clipped to [lo, hi] (numpy int32 array)."""
+    rng = np.random.default_rng(seed)
+    mu = np.log(mean) - 0.5 * sigma * sigma
+    return np.clip(rng.lognormal(mu, sigma, n_reads), lo, hi).astype(np.int32)
+
+
+def make_reads_var(db: SynthDB, lengths, seed: int = READ_SEED, device=None) -> SynthReads:
+    """Reads of DIFFERENT lengths with the content rule of make_reads: uniform bases, floor(L/k) non-overlapping planted k-mers (70 %
+    from the read's leaf label, 20 % an ancestor's, 10 % a sibling's), 5 % of the reads fully random, 1 % with one 'N'.  Every read's
+    storage starts at a multiple of k in the buffer (reads need not be adjacent: offsets say where they are), so the planted k-mers are
+    rows of the buffer seen as [rows, k]."""
+    import torch
+    dev = db.tree2file.device if device is None else torch.device(device)
+    k = 4 * db.W
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    ln = torch.as_tensor(np.asarray(lengths, dtype=np.int64), device=dev)
+    n = ln.numel()
+    rows = (ln + k - 1) // k
+    row0 = torch.cumsum(rows, 0) - rows
+    total_rows = int(rows.sum().item())
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    seq = torch.empty((total_rows, k), dtype=torch.uint8, device=dev)
+    step = 1 << 22
+    for lo in range(0, total_rows, step):                                     # (randint in pieces: the int64 draw is 8 x the bytes)
+        hi = min(total_rows, lo + step)
+        seq[lo:hi] = acgt[torch.randint(0, 4, (hi - lo, k), generator=g, device=dev)]
+    slots = ln // k
+    total_slots = int(slots.sum().item())
+    if total_slots:
+        read_of = torch.repeat_interleave(torch.arange(n, device=dev), slots)
+        slot0 = torch.cumsum(slots, 0) - slots
+        j = torch.arange(total_slots, device=dev) - slot0[read_of]
+        leaf_r = torch.randint(0, N_LEAVES, (n,), generator=g, device=dev)
+        random_read = torch.rand(n, generator=g, device=dev) < 0.05
+        leaf = leaf_r[read_of]
+        u = torch.rand(total_slots, generator=g, device=dev)
+        depth = torch.randint(1, 7, (total_slots,), generator=g, device=dev)
+        anc_off = torch.from_numpy(ANC_OFFSETS.astype(np.int64)).to(dev)
+        anc = anc_off[depth - 1] + (leaf >> (2 * (7 - depth)))
+        sib = leaf ^ torch.randint(1, 4, (total_slots,), generator=g, device=dev)
+        lab = torch.where(u < 0.7, leaf, torch.where(u < 0.9, anc, sib))
+        node = torch.clamp(lab * db.block + torch.randint(0, db.block, (total_slots,), generator=g, device=dev), max=db.n_nodes - 1)
+        keep = ~random_read[read_of]
+        shifts = torch.arange(62, -2, -2, device=dev, dtype=torch.int64)
+        target = (row0[read_of] + j)[keep]
+        node = node[keep]
+        for lo in range(0, node.numel(), step):
+            nd = node[lo:lo + step]
+            codes = (mix64(nd ^ _s64(db.seed)).unsqueeze(-1) >> shifts) & 3
+            if db.W == 16:
+                codes = torch.cat([codes, (mix64((~nd) ^ _s64(db.seed)).unsqueeze(-1) >> shifts) & 3], dim=-1)
+            seq[target[lo:lo + step]] = acgt[codes]
+    off = row0 * k
+    with_n = torch.rand(n, generator=g, device=dev) < 0.01
+    pos = (torch.rand(n, generator=g, device=dev) * ln).long().clamp(max=int(ln.max().item()) - 1)
+    pos = torch.minimum(pos, ln - 1)
+    rws = torch.nonzero(with_n).squeeze(1)
+    flat = seq.view(-1)
+    flat[off[rws] + pos[rws]] = ord("N")
+    return SynthReads(bases=flat, off=off.contiguous(), length=ln.to(torch.int32), n=n, read_len=int(ln.max().item()))
+
+
 def fasta_tensor(reads: SynthReads, first_index: int = 0):
     """The same FASTA text as reads_to_fasta, assembled on the device (uint8 tensor): reads whose index has the same number of
     digits have records of one size, so each such group is one 2-D byte tensor."""
