@@ -51,14 +51,14 @@ static uint32_t bucket_words_default(void) {
  * gets as many buckets as bring a bucket to TARGET nodes: any number (bucket = base + ((h24 * nb) >> 24)), between 2^16 -- a bucket
  * spans at most 256 hash values: the record key has 8 bits for them -- and 2^(16+F), at most one bucket per hash value (F = fine_bits:
  * 8 = as many as the density asks, 0 = 256 values per bucket everywhere).  Default TARGET: 128-byte buckets are filled to 56 % (config
- * 2: 9 of 16 entries, image 17.6 GiB, 0.3 overflowing buckets per 150 bp read), 64-byte buckets to 31 % (2.5 of 8, 24 GiB, 0.15).  The
+ * 2: 9 of 16 entries, image 17.6 GiB, 0.3 overflowing buckets per 150 bp read), 64-byte buckets to 37.5 % (3 of 8, 22.9 GiB, 0.28).  The
  * dense end of the hash range has several nodes per hash VALUE, so a bucket there holds the nodes of one, two or three values: a
  * mixture, not one Poisson mean -- which is why the small buckets want the lower load (DESIGN.md section 3 has the sweeps). */
 static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32_t bucket_words, uint32_t F, uint64_t regions[256]) {
     const double m = 4.0 * W - 15.0;
     const uint32_t cap_entries = bucket_words / utree_rec_words(W, I);
     const char *te = getenv("UTREE_BUCKET_TARGET");                     /* nodes per bucket; experiments only */
-    const double target = te && atof(te) > 0 ? atof(te) : (bucket_words == 16 ? 0.5625 : 0.3125) * cap_entries;
+    const double target = te && atof(te) > 0 ? atof(te) : (bucket_words == 16 ? 0.5625 : 0.375) * cap_entries;
     const uint64_t nb_max = 1ull << (16 + (F > 8 ? 8 : F)), nb_min = 1ull << 16;
     uint64_t base = 0;
     for (int r = 0; r < 256; ++r) {

@@ -1,0 +1,41 @@
+// lanes_part.hip -- the instantiations of classify_lanes_k (lanes_core.hpp) for ONE (W, I, NL) = (k / 4, label-index bytes, 16-byte loads per
+// bucket), compiled once per combination (Makefile: -DLANES_W= -DLANES_I= -DLANES_NL=) so that the six sets build side by side.
+#include "lanes_core.hpp"
+
+#define CAT_(a, b, c, d) a##b##_##c##_##d
+#define CAT(a, b, c, d) CAT_(a, b, c, d)
+
+extern "C" int CAT(utk_lanes_part_, LANES_W, LANES_I, LANES_NL)(int segs, int irr, int mode, const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off,
+                                                                const uint32_t *d_len, uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws,
+                                                                int n_cu, void *stream, uint32_t cls) {
+#define GO(S_, M_) return irr ? launch_lanes<LANES_W, LANES_I, S_, true, M_, LANES_NL>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls) \
+                              : launch_lanes<LANES_W, LANES_I, S_, false, M_, LANES_NL>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
+    if (mode == 0 && segs == 1) GO(1, 0);                      // a batch of reads of up to 160 bases, whole
+    if (mode == 2 && segs == 16) GO(16, 2);                    // pieces of long reads
+    if (mode == 1) {                                           // one length class of a mixed batch
+        if (segs == 1) GO(1, 1);
+        if (segs == 2) GO(2, 1);
+        if (segs == 4) GO(4, 1);
+        if (segs == 8) GO(8, 1);
+        if (segs == 16) GO(16, 1);
+    }
+#undef GO
+    return (int)hipErrorInvalidValue;
+}
+
+// (phase timers, a debugging build: the counters of the k = 32 / u16 labels / 64-byte buckets set)
+#if defined(UTREE_LANES_TIMERS) && LANES_W == 8 && LANES_I == 2 && LANES_NL == 1
+extern "C" {
+void utk_lanes_phase_dump(void) {
+    unsigned long long h[8];
+    static const char *nm[5] = {"grab", "phase 0: bytes -> codes", "phase A: minimizer runs", "phase B: buckets", "phase C: tally, results"};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lphase), sizeof h) != hipSuccess) return;
+    unsigned long long tot = 0;
+    for (int q = 0; q < 5; ++q) tot += h[q];
+    fprintf(stderr, "[lanes phase timers] %llu waves, %.4g cycles per wave\n", h[7], h[7] ? (double)tot / h[7] : 0.0);
+    for (int q = 0; q < 5; ++q) fprintf(stderr, "  %-28s %5.1f %%\n", nm[q], tot ? 100.0 * h[q] / tot : 0.0);
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lphase), h, sizeof h);
+}
+}
+#endif

@@ -133,7 +133,7 @@ def kernel_source_sha256() -> str:
     for the library built from exactly these files (bench.py checks it)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip", "lanes_kernel.hip", "wave_common.hpp", "device_common.hpp", "utree_internal.h", "Makefile"):
+    for f in ("kernels.hip", "lanes_kernel.hip", "lanes_core.hpp", "lanes_part.hip", "wave_common.hpp", "device_common.hpp", "utree_internal.h", "Makefile"):
         with open(os.path.join(_HERE, "csrc", f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read() + b"\0")
     return h.hexdigest()
