@@ -442,7 +442,7 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         tj = json.load(open(tp))
-        key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (args.nodes, args.batch_reads, args.read_len, args.kmer, args.rc) + (",dist=%s" % args.len_dist if args.len_dist != "fixed" else "")
+        key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (args.nodes, args.batch_reads, args.read_len, args.kmer, args.rc) + (",dist=%s" % args.len_dist if args.len_dist != "fixed" else "") + (",bucket=%d" % tree.info.bucket_bytes if tree.info.bucket_bytes != 64 else "")
         e = tj.get(key)
         src_hash = ulib.kernel_source_sha256()
         if e is None:

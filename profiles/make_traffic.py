@@ -39,6 +39,9 @@ length = arg("--read-len", 150)
 key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (nodes, reads, length, kmer, rc)
 if arg("--len-dist", "fixed") != "fixed":
     key += ",dist=%s" % arg("--len-dist", "fixed")
+bb = int(line["roofline"].get("model", {}).get("bucket_bytes", 64))
+if bb != 64:
+    key += ",bucket=%d" % bb
 entry = {
     "kernel": name[0],
     "kernel_source_sha256": c["kernel_source_sha256"],

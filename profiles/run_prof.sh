@@ -21,7 +21,8 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INS
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 4
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -- python3 $R/bench.py $ARGS > $OUT/pmc_tcc.json 2> $OUT/pmc_tcc.err || exit 5
-# keep only small files
-find $OUT -name "*.csv" -size +8M -delete
 python3 $R/profiles/summarize.py $OUT > $OUT/summary.txt 2> $OUT/summary.err || echo "summary failed"
+# keep only small files (gpurun brings back at most 64 MiB): the raw traces and counter tables are folded into summary.txt / counters.json
+find $OUT -name "*.csv" -size +256k -delete
+find $OUT -name "*.err" -size +64k -delete
 echo done
