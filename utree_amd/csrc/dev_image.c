@@ -221,7 +221,7 @@ static int build_vote_table(const utree_ctr *ctr, utk_vote_rec *out) {
             if (i < len) h = (h ^ (uint8_t)';') * 1099511628211ull;
         }
         if (!ok) break;
-        v->n_tok = (uint8_t)t;
+        v->n_tok = (uint8_t)t; v->len = (uint8_t)len;
         for (; t < 8; ++t) { v->pid[t] = 0xFFFFu; v->tok_end[t] = (uint8_t)len; }
     }
     free(hh); free(hv); free(hl);
@@ -775,6 +775,8 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
         d->last_lanes = utk_lanes_segs(&d->kimg, max_len); d->last_mixed = mixed; d->last_pieces = w.long_blocks != 0;
         if (e0 && !w.long_blocks) HIPCHK(hipEventRecord(e0, st));
         if (!mixed) KCHK(utk_classify_lanes(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
+        /* (the classes' launches go one after the other on `stream`: forked onto side streams with events they were 3-5 % slower,
+         * profiles/r03/mixed_batches*.json) */
         else KCHK(utk_classify_lanes_mixed(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
         if (e0 && !w.long_blocks) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
         if (w.long_blocks) {

@@ -854,6 +854,7 @@ __device__ __forceinline__ uint32_t v_end(const VRec &v, uint32_t t) { return (u
 __device__ __forceinline__ bool v_exists(const VRec &v, uint32_t t) { return ((uint32_t)v.w[3] >> t) & 1u; }
 __device__ __forceinline__ bool v_more(const VRec &v, uint32_t t) { return ((uint32_t)v.w[3] >> (8u + t)) & 1u; }
 __device__ __forceinline__ bool v_us(const VRec &v, uint32_t t) { return ((uint32_t)v.w[3] >> (16u + t)) & 1u; }
+__device__ __forceinline__ uint32_t v_len(const VRec &v) { return (uint32_t)(v.w[3] >> 32) & 0xFFu; }   // the label's length
 
 // The vote with the label table (UTREE_F_VOTE_TABLE): the same state machine as below, every byte scan replaced by what the table says
 // about it.  The labels of the active group [st, ed) agree up to byte dv; t is the token that holds byte dv + 1 (0 at the start), the
@@ -871,13 +872,17 @@ __device__ __forceinline__ void vote_table(const utk_image &im, utree_result *ou
     constexpr uint32_t NONE = 0xFFFFFFFFu;
     uint32_t cutoff = cut_of(F);
     uint32_t st = 0, ed = uix, dv = NONE, t = 0, orun = F, sl, ol;
+    // (every list entry and label record is loaded once per level at most: the group's last entry -- needed for the shared levels -- is
+    // also the walk's last `cur`, and whatever ends the descent has its record in registers already)
+    uint32_t rk, n_last, len_last;                                           // the label the result is cut from: rank, count, length
     for (;;) {
         const uint64_t t_st = T[st];
         VRec pv = vrec(vt, (uint32_t)t_st);
+        const uint64_t t_ed = ed - 1u == st ? t_st : T[ed - 1u];
+        const VRec lv = ed - 1u == st ? pv : vrec(vt, (uint32_t)t_ed);
         {
             // levels at which the whole group carries one token: the group's first and last label agree through token L - 1, each followed
             // by ';' (ids are equal through the last shared token, `more` bits are set through the last ';')
-            const VRec lv = vrec(vt, (uint32_t)T[ed - 1]);
             const uint64_t d0 = pv.w[0] ^ lv.w[0], d1 = pv.w[1] ^ lv.w[1];
             const uint32_t same = d0 ? (uint32_t)__builtin_ctzll(d0) >> 4 : 4u + (d1 ? (uint32_t)__builtin_ctzll(d1) >> 4 : 4u);
             const uint32_t both = ((uint32_t)(pv.w[3] & lv.w[3]) >> 8) & 0xFFu;             // ';' after token in both
@@ -887,10 +892,12 @@ __device__ __forceinline__ void vote_table(const utk_image &im, utree_result *ou
         }
         uint32_t run = (uint32_t)(t_st >> 32), td = dv, c1 = run, rp = (uint32_t)t_st;
         bool td_is_end = false;                                                             // td is prev's terminator at level t
+        bool stopped = false;
         for (uint32_t z = st + 1; z < ed; ++z) {
-            const uint64_t tz = T[z];
+            const bool is_last = z == ed - 1u;
+            const uint64_t tz = is_last ? t_ed : T[z];
             const uint32_t nz = (uint32_t)(tz >> 32), rc = (uint32_t)tz;
-            const VRec cv = vrec(vt, rc);
+            const VRec cv = is_last ? lv : vrec(vt, rc);
             bool aside = false, stop = false;
             // previous label exhausted at dv (itree.c:1052): it has no token t, or nothing is agreed yet and it is the empty string
             if (t >= 8u || !v_exists(pv, t) || (dv == NONE && v_end(pv, 0) == 0u && !v_more(pv, 0))) aside = true;
@@ -919,24 +926,45 @@ __device__ __forceinline__ void vote_table(const utk_image &im, utree_result *ou
                 orun -= c1;
                 cutoff = cut_of(orun);
             }
-            if (stop) break;
+            if (stop) { stopped = true; break; }
             pv = cv; c1 = nz; rp = rc;
         }
+        // the group's last label [ed - 1]: the one before the pair that stopped the walk, else the list's last
+        rk = stopped ? rp : (uint32_t)t_ed;
+        n_last = stopped ? c1 : (uint32_t)(t_ed >> 32);
+        len_last = stopped ? v_len(pv) : v_len(lv);
         sl = run; ol = orun;                                                   // itree.c:1071
         if (run < cutoff) break;                                               // itree.c:1072
         if (st + 1 >= ed) {                                                    // itree.c:1073-1079
-            if ((uint32_t)(T[ed - 1] >> 32) >= cutoff) dv = 0xFFFFFFFEu;
+            if (n_last >= cutoff) dv = 0xFFFFFFFEu;
             break;
         }
         orun = run; cutoff = cut_of(run);                                      // itree.c:1082-1085
         if (td != dv) { dv = td; if (td_is_end) ++t; }
     }
-    const uint32_t rk = (uint32_t)T[ed - 1];
     int32_t cut;
     if (dv == NONE) cut = -1;                                                  // itree.c:1087
     else if (dv == 0xFFFFFFFEu) cut = -2;
-    else { uint32_t Ls = loff[rk + 1] - loff[rk] - 1; cut = (int32_t)(dv < Ls ? dv : Ls); }   // 1088
+    else cut = (int32_t)(dv < len_last ? dv : len_last);                       // 1088
     store_result(out_r, im.rank2ix[rk], cut, F, uix, sl, ol);
+}
+
+// vote_table_k: vote_k for images with the label table (a kernel of its own: with both in one, the byte scans' registers cost the table path
+// three of its eight wavefronts per SIMD)
+#ifdef UTREE_VOTE_WPE8
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+__global__ __launch_bounds__(256) void vote_table_k(utk_image im, utree_result *__restrict__ out, utk_workspace ws, uint32_t n_reads) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t *res = (const uint32_t *)&out[r];
+    if ((int32_t)res[1] == RANK_PENDING) {                 // one distinct label: only its file-order index is missing
+        uint32_t *o = (uint32_t *)&out[r];
+        o[0] = im.rank2ix[res[0]]; o[1] = (uint32_t)-2;
+        return;
+    }
+    if ((int32_t)res[1] != CUT_PENDING) return;            // finished by the classify kernel (no hit, or classify_long_k)
+    vote_table(im, &out[r], ws.tally + ((uint64_t)res[4] | ((uint64_t)res[5] << 32)), res[2], res[3]);
 }
 
 __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__restrict__ out, utk_workspace ws, uint32_t n_reads) {
@@ -951,7 +979,6 @@ __global__ __launch_bounds__(256) void vote_k(utk_image im, utree_result *__rest
     if ((int32_t)res[1] != CUT_PENDING) return;            // finished by the classify kernel (no hit, or classify_long_k)
     const uint32_t F = res[2], uix = res[3];
     const uint64_t *T = ws.tally + ((uint64_t)res[4] | ((uint64_t)res[5] << 32));
-    if (im.vote_tab) { vote_table(im, &out[r], T, F, uix); return; }
     const char *blob = im.label_blob;
     const uint32_t *loff = im.label_off;
     uint32_t cutoff = cut_of(F);
@@ -1214,7 +1241,8 @@ int utk_classify_long(const utk_image *im, const uint8_t *d_bases, const uint64_
 
 int utk_vote(const utk_image *im, utree_result *d_out, const utk_workspace *ws, uint32_t n_reads, void *stream) {
     if (!n_reads) return 0;
-    vote_k<<<dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(*im, d_out, *ws, n_reads);
+    if (im->vote_tab) vote_table_k<<<dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(*im, d_out, *ws, n_reads);
+    else vote_k<<<dim3((n_reads + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(*im, d_out, *ws, n_reads);
     return (int)hipGetLastError();
 }
 

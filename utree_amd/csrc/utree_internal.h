@@ -80,7 +80,7 @@ typedef struct {
     uint16_t pid[8];
     uint8_t tok_end[8];
     uint8_t exists, more, us, n_tok;
-    uint8_t pad[4];
+    uint8_t len, pad[3];             /* the label's length */
 } utk_vote_rec;
 
 /* What kernels take by value. */
