@@ -787,7 +787,7 @@ _Pragma("unroll") \
         }
         if (live) {
             if (F == 0) store_result(&out[r], 0, -2, 0, 0, 0, 0);
-            else if (nu == 1) store_result(&out[r], first_rank, RANK_PENDING, F, 1, 0, 0);
+            else if (nu == 1) store_result(&out[r], first_rank, RANK_PENDING, F, 1, 0, 0);      // (vote_k looks the file-order index up: doing it here is +-0, same box)
             else store_result(&out[r], 0, CUT_PENDING, F, nu, (uint32_t)my_base, (uint32_t)(my_base >> 32));
         }
         wave_lds_fence();
