@@ -62,6 +62,11 @@ def main():
     ap.add_argument("--len-dist", default="fixed", choices=("fixed", "lognormal"),
                     help="lognormal: SURVEY 8(d)'s config-3 shape -- read lengths ~ lognormal with mean --read-len, clipped to [mean/10, 10 x mean]; "
                          "the CPU / file legs are for fixed-length batches only")
+    ap.add_argument("--workload", default="config", choices=("config", "hit_dense"),
+                    help="hit_dense: a database of RELATED genomes built by the product's own utree-buildGG + xtree-compress (--refs x --ref-len) and "
+                         "reads cut from them (a secondary workload, DESIGN.md section 11; N = 1, no CPU / file legs)")
+    ap.add_argument("--refs", type=int, default=1000)
+    ap.add_argument("--ref-len", type=int, default=1_000_000)
     ap.add_argument("--kmer", type=int, default=32, choices=(32, 64))
     ap.add_argument("--distinct-batches", type=int, default=0,
                     help="distinct read batches resident in HBM (0 = one per timed step: no batch is classified twice in the timed region)")
@@ -119,8 +124,11 @@ def main():
             dist.init_process_group(args.backend)
     W = args.kmer // 4
     var_len = args.len_dist != "fixed"
-    want_cpu = (world == 1 and not args.no_cpu_baseline and not var_len)
-    want_e2e = (world == 1 and not args.no_e2e and not var_len)
+    hit_dense = args.workload == "hit_dense"
+    if hit_dense and (world > 1 or var_len or args.kmer != 32):
+        raise SystemExit("bench.py --workload hit_dense: one GPU, fixed read length, k = 32")
+    want_cpu = (world == 1 and not args.no_cpu_baseline and not var_len and not hit_dense)
+    want_e2e = (world == 1 and not args.no_e2e and not var_len and not hit_dense)
     want_e2e_dist = (world > 1 and not args.no_e2e and not var_len)
 
     # ---- database: rank 0 builds the image in HBM, the others receive it by ONE broadcast (RCCL / xGMI) ----
@@ -128,7 +136,14 @@ def main():
     bcast_s = 0.0
     bcast_how = ""
     sdb = None
-    if rank == 0:
+    hd_dir = None
+    if hit_dense:
+        import tempfile
+        hd_dir = tempfile.mkdtemp(prefix="utree_bench_hd_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        sdb = synth.make_related_db(dev, hd_dir, refs=args.refs, ref_len=args.ref_len)
+        tree, ctr = sdb.tree, sdb.ctr
+        args.nodes = sdb.n_nodes
+    elif rank == 0:
         sdb = synth.make_db(dev, args.nodes, W=W, fine_bits=args.fine_bits, keep_raw=(want_cpu or want_e2e))
         tree, ctr = sdb.tree, sdb.ctr
     if dist_on:
@@ -179,8 +194,12 @@ def main():
         totals = [int(b.length.sum().item()) for b in batches]
         maxlens = [int(b.length.max().item()) for b in batches]
     else:
-        batches = [synth.make_reads(sdb, args.batch_reads, args.read_len, seed=synth.READ_SEED + 1000 * rank + b, device=dev)
-                   for b in range(nb)]
+        if hit_dense:
+            nb = min(nb, 3)
+            batches = [synth.make_related_reads(sdb, args.batch_reads, args.read_len, seed=100 + b) for b in range(nb)]
+        else:
+            batches = [synth.make_reads(sdb, args.batch_reads, args.read_len, seed=synth.READ_SEED + 1000 * rank + b, device=dev)
+                       for b in range(nb)]
         totals = [args.batch_reads * args.read_len] * nb
         maxlens = [args.read_len] * nb
     total_bases = totals[0]
@@ -233,9 +252,10 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64" if W == 8 else "u128", "data": "synthetic",
-            "config": {"workload": "configs[1]: %.3g-node synthetic L2 CTR (k=%d, %d labels, image %.1f GiB, fine_bits=%d), "
+            "config": {"workload": ("configs[1]" if not hit_dense else "hit-dense (secondary; %d related references x %d bp through utree-buildGG + xtree-compress; nodes_exact=%d)" % (args.refs, args.ref_len, args.nodes)) +
+                                   ": %.3g-node synthetic L2 CTR (k=%d, %d labels, image %.1f GiB, fine_bits=%d), "
                                    "%d x %s reads per GPU (%d steps x %d-read batches, %d distinct batches resident in HBM), RC=%d"
-                                   % (args.nodes, args.kmer, synth.N_LABELS, tree.info.image_bytes / 2**30, tree.info.fine_bits,
+                                   % (args.nodes, args.kmer, ctr.n_labels, tree.info.image_bytes / 2**30, tree.info.fine_bits,
                                       args.batch_reads * args.steps,
                                       "%d bp" % args.read_len if not var_len else "lognormal-length (mean %d bp, clipped to [%d, %d]; batch 0: mean %.0f, max %d)" %
                                       (args.read_len, max(1, args.read_len // 10), 10 * args.read_len, totals[0] / args.batch_reads, maxlens[0]),
@@ -279,6 +299,9 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
+    if hd_dir:
+        import shutil
+        shutil.rmtree(hd_dir, ignore_errors=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
@@ -442,7 +465,8 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         tj = json.load(open(tp))
-        key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (args.nodes, args.batch_reads, args.read_len, args.kmer, args.rc) + (",dist=%s" % args.len_dist if args.len_dist != "fixed" else "") + (",bucket=%d" % tree.info.bucket_bytes if tree.info.bucket_bytes != 64 else "")
+        key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (args.nodes, args.batch_reads, args.read_len, args.kmer, args.rc) + (",dist=%s" % args.len_dist if args.len_dist != "fixed" else "") + (",bucket=%d" % tree.info.bucket_bytes if tree.info.bucket_bytes != 64 else "") + \
+              (",workload=hit_dense" if args.workload == "hit_dense" else "")
         e = tj.get(key)
         src_hash = ulib.kernel_source_sha256()
         if e is None:

@@ -28,7 +28,7 @@ import re
 m = re.search(r"\(k=(\d+),", ap)
 kmer = int(m.group(1))
 rc = int(re.search(r"RC=(\d)", ap).group(1))
-nodes = int(float(re.search(r"configs\[1\]: ([0-9.e+]+)-node", ap).group(1)))
+nodes = int(float(re.search(r": ([0-9.e+]+)-node", ap).group(1)))
 # exact figures from the args (the workload string rounds the node count)
 args = c.get("bench_args", "").split()
 def arg(flag, default):
@@ -39,6 +39,11 @@ length = arg("--read-len", 150)
 key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (nodes, reads, length, kmer, rc)
 if arg("--len-dist", "fixed") != "fixed":
     key += ",dist=%s" % arg("--len-dist", "fixed")
+if arg("--workload", "config") == "hit_dense":
+    nodes = int(float(re.search(r": ([0-9.e+]+)-node", ap).group(1)))          # (the builder decides the node count: take it from the line)
+    m_nodes = re.search(r"nodes_exact=(\d+)", ap)
+    nodes = int(m_nodes.group(1)) if m_nodes else nodes
+    key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d,workload=hit_dense" % (nodes, reads, length, kmer, rc)
 bb = int(line["roofline"].get("model", {}).get("bucket_bytes", 64))
 if bb != 64:
     key += ",bucket=%d" % bb

@@ -48,68 +48,26 @@ def main():
     os.makedirs(args.dir, exist_ok=True)
     d = args.dir
     out = {"refs": args.refs, "ref_len": args.ref_len, "reads": args.reads, "read_len": args.read_len, "rc": args.rc, "complevel": args.complevel}
-    g = torch.Generator(device=dev)
-    g.manual_seed(11)
-    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    n_roots = max(4, args.refs // 25)
-    roots = torch.randint(0, 4, (n_roots, args.ref_len), generator=g, device=dev, dtype=torch.uint8)
-    ranks = "kpcofgst"
-    keep = min(args.refs, 256)                                   # references the reads are cut from (kept on the device)
-    kept = torch.empty((keep, args.ref_len), dtype=torch.uint8, device=dev)
-    t0 = time.time()
-    with open(d + "/refs.fa", "wb") as f, open(d + "/refs.map", "wb") as m:
-        for i in range(args.refs):
-            r = i % n_roots
-            s = roots[r].clone()
-            mut = torch.rand(args.ref_len, generator=g, device=dev) < 0.02
-            s[mut] = torch.randint(0, 4, (int(mut.sum()),), generator=g, device=dev, dtype=torch.uint8)
-            if i < keep:
-                kept[i] = s
-            f.write(b">ref%06d\n" % i)
-            acgt[s.long()].cpu().numpy().tofile(f)
-            f.write(b"\n")
-            path = [r % 2, r % 3, r % 5, r % 7, r % 11, r, i % 9, i]
-            m.write(b"ref%06d\t" % i + ";".join("%s__%d" % (ranks[k], path[k]) for k in range(8)).encode() + b"\n")
-    out["generate_refs_seconds"] = time.time() - t0
-    del roots
+    from utree_amd import synth
+    rdb = synth.make_related_db(dev, d, refs=args.refs, ref_len=args.ref_len, complevel=args.complevel)
+    db, tree = rdb.ctr, rdb.tree
+    out["generate_refs_seconds"] = rdb.seconds["generate_refs"]
+    out["build_seconds"] = rdb.seconds["build"]
+    out["compress_seconds"] = rdb.seconds["compress"]
+    out["upload_seconds"] = rdb.seconds["upload"]
+    out["nodes"] = int(db.n_nodes)
+    out["labels"] = int(db.n_labels)
+    out["image_GiB"] = tree.info.image_bytes / 2**30
+    out["bucket_bytes"] = int(tree.info.bucket_bytes)
+    L = args.read_len
 
     def run(cmd):
         t = time.time()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         return time.time() - t, r
-    secs, r = run([lib.BUILD_GG_CLI_PATH, d + "/refs.fa", d + "/refs.map", d + "/db.ubt", "0", str(args.complevel)])
-    assert r.returncode == 0, r.stderr.decode()
-    out["build_seconds"] = secs
-    out["build_stdout"] = [l for l in r.stdout.decode().splitlines() if "k-mers" in l or "Total nodes" in l]
-    secs, r = run([lib.COMPRESS_CLI_PATH, d + "/db.ubt", d + "/db.ctr"])
-    assert r.returncode == 0, r.stderr.decode()
-    out["compress_seconds"] = secs
-    os.remove(d + "/db.ubt")
-    os.remove(d + "/refs.fa")
-    db = CtrDB.open(d + "/db.ctr")
-    t0 = time.time()
-    tree = DeviceTree.upload(db, 0)
-    torch.cuda.synchronize()
-    out["nodes"] = int(db.n_nodes)
-    out["labels"] = int(db.n_labels)
-    out["image_GiB"] = tree.info.image_bytes / 2**30
-    out["upload_seconds"] = time.time() - t0
-
-    # reads: slices of the kept references, 1 % substitutions, a quarter reverse-complemented
-    L = args.read_len
-    comp = torch.tensor([3, 2, 1, 0], dtype=torch.uint8, device=dev)
 
     def make_batch(seed):
-        g.manual_seed(seed)
-        which = torch.randint(0, keep, (args.reads,), generator=g, device=dev)
-        pos = torch.randint(0, args.ref_len - L, (args.reads,), generator=g, device=dev)
-        idx = (which * args.ref_len + pos).unsqueeze(1) + torch.arange(L, device=dev).unsqueeze(0)
-        s = kept.view(-1)[idx]
-        mm = torch.rand((args.reads, L), generator=g, device=dev) < 0.01
-        s = torch.where(mm, torch.randint(0, 4, (args.reads, L), generator=g, device=dev, dtype=torch.uint8), s)
-        rcm = (torch.arange(args.reads, device=dev) & 3) == 0
-        s = torch.where(rcm.unsqueeze(1), comp[s.flip(1).long()], s)
-        return acgt[s.long()].contiguous().view(-1)
+        return synth.make_related_reads(rdb, args.reads, L, seed=seed).bases
     nb = min(3, args.steps)
     batches = [make_batch(100 + b) for b in range(nb)]
     off = torch.arange(args.reads, dtype=torch.int64, device=dev) * L

@@ -11,6 +11,7 @@ profiles/run_prof.sh r03_config3_long_rc --nodes 72000000 --read-len 10000 --rc 
 profiles/run_prof.sh r03_config3_lognormal_rc --nodes 72000000 --read-len 10000 --rc 1 --batch-reads 100000 --len-dist lognormal > gpurun_out/r03/p5.log 2>&1
 UTREE_BUCKET_BYTES=128 profiles/run_prof.sh r03_config2_bucket128 > gpurun_out/r03/p6.log 2>&1
 UTREE_BUCKET_BYTES=128 profiles/run_prof.sh r03_config5_k64_bucket128 --kmer 64 --nodes 568000000 > gpurun_out/r03/p7.log 2>&1
+profiles/run_prof.sh r03_hit_dense --workload hit_dense > gpurun_out/r03/p8.log 2>&1
 echo "== 64-byte buckets (default), UTREE_BUCKET_TARGET = nodes per bucket ==" > gpurun_out/r03/footprint_sweep.txt
 for t in 2 3 4 5 6; do UTREE_BUCKET_TARGET=$t tools/bq.sh >> gpurun_out/r03/footprint_sweep.txt 2>&1; done
 echo "== 128-byte buckets (UTREE_BUCKET_BYTES=128) ==" >> gpurun_out/r03/footprint_sweep.txt

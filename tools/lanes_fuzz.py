@@ -23,6 +23,12 @@ def main():
         k = 4 * W
         nodes = int(10 ** rng.uniform(5.0, 7.7))
         os.environ["UTREE_FINE_BITS"] = str(int(rng.choice([8, 8, 6, 4, 2, 0])))
+        os.environ["UTREE_BUCKET_BYTES"] = str(int(rng.choice([64, 64, 128])))
+        os.environ["UTREE_BUCKET_TARGET"] = "%.2f" % float(rng.choice([0, 0, 0.7, 1.5, 3, 6, 12, 30]))     # 0: the default load; small: few overflow runs, large: most buckets overflow
+        if rng.random() < 0.25:
+            os.environ["UTREE_VOTE_BYTES"] = "1"
+        else:
+            os.environ.pop("UTREE_VOTE_BYTES", None)
         sdb = synth.make_db(dev, nodes, W=W)
         for sub in range(3):
             cap = (2095 if W == 8 else 1615)
@@ -52,9 +58,11 @@ def main():
                 name = sdb.tree.kernel_name()
                 os.environ["UTREE_LANE_PASS"] = "0"
                 b = sdb.tree.classify(buf[shift:], reads.off, length, rc=rc)
+                torch.cuda.synchronize()
+                sdb.tree.poll()
                 if not torch.equal(a, b):
                     bad = torch.nonzero((a != b).any(dim=1)).squeeze(1)
-                    print("MISMATCH", dict(W=W, nodes=nodes, L=L, n=n, rc=rc, fine=os.environ["UTREE_FINE_BITS"], kernel=name, first=bad[:5].tolist()),
+                    print("MISMATCH", dict(W=W, nodes=nodes, L=L, n=n, rc=rc, fine=os.environ["UTREE_FINE_BITS"], bucket=os.environ["UTREE_BUCKET_BYTES"], target=os.environ["UTREE_BUCKET_TARGET"], kernel=name, first=bad[:5].tolist()),
                           a[bad[0]].tolist(), b[bad[0]].tolist())
                     sys.exit(1)
                 checked += n
@@ -62,7 +70,7 @@ def main():
         sdb.tree.close()
         del sdb
         torch.cuda.empty_cache()
-        print("round %d ok: W=%d nodes=%d fine=%s (%d reads so far, %d batches through the pass)" % (it, W, nodes, os.environ["UTREE_FINE_BITS"], checked, lanes_used), flush=True)
+        print("round %d ok: W=%d nodes=%d fine=%s bucket=%s target=%s (%d reads so far, %d batches through the pass)" % (it, W, nodes, os.environ["UTREE_FINE_BITS"], os.environ["UTREE_BUCKET_BYTES"], os.environ["UTREE_BUCKET_TARGET"], checked, lanes_used), flush=True)
     print("fuzz ok: %d reads, %d batches through the lane-per-read pass" % (checked, lanes_used))
 
 

@@ -306,3 +306,93 @@ def reads_to_fasta(reads: SynthReads, first_index: int = 0) -> bytes:
         out += seq[i].tobytes()
         out += b"\n"
     return bytes(out)
+
+
+@dataclass
+class RelatedDB:
+    """A database of RELATED genomes built by the product's own tools (utree-buildGG + xtree-compress), and the references reads are cut from."""
+    ctr: CtrDB
+    tree: DeviceTree
+    kept: "object"            # torch uint8 [keep, ref_len] base codes 0..3 of the first `keep` references
+    ref_len: int
+    n_nodes: int
+    W: int
+    seconds: dict
+
+
+def make_related_db(device, workdir: str, refs: int = 1000, ref_len: int = 1_000_000, complevel: int = 0, seed: int = 11) -> RelatedDB:
+    """`refs` references = mutated copies (2 % substitutions) of refs/25 random roots with GG-style 8-rank labels -> utree-buildGG
+    (complevel 0: every k-mer) -> xtree-compress -> device image.  k-mers of the ~25 relatives of a root crowd around each minimizer: the
+    shape of a real reference database (README.md:2 of the reference), unlike make_db's independent k-mers."""
+    import os
+    import subprocess
+    import time
+    import torch
+    dev = torch.device(device)
+    os.makedirs(workdir, exist_ok=True)
+    d = workdir
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    n_roots = max(4, refs // 25)
+    roots = torch.randint(0, 4, (n_roots, ref_len), generator=g, device=dev, dtype=torch.uint8)
+    ranks = "kpcofgst"
+    keep = min(refs, 256)
+    kept = torch.empty((keep, ref_len), dtype=torch.uint8, device=dev)
+    secs = {}
+    t0 = time.time()
+    with open(d + "/refs.fa", "wb") as f, open(d + "/refs.map", "wb") as m:
+        for i in range(refs):
+            r = i % n_roots
+            s_ = roots[r].clone()
+            mut = torch.rand(ref_len, generator=g, device=dev) < 0.02
+            s_[mut] = torch.randint(0, 4, (int(mut.sum()),), generator=g, device=dev, dtype=torch.uint8)
+            if i < keep:
+                kept[i] = s_
+            f.write(b">ref%06d\n" % i)
+            acgt[s_.long()].cpu().numpy().tofile(f)
+            f.write(b"\n")
+            path = [r % 2, r % 3, r % 5, r % 7, r % 11, r, i % 9, i]
+            m.write(b"ref%06d\t" % i + ";".join("%s__%d" % (ranks[k], path[k]) for k in range(8)).encode() + b"\n")
+    secs["generate_refs"] = time.time() - t0
+    del roots
+
+    def run(cmd):
+        t = time.time()
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            raise RuntimeError("%s failed: %s" % (cmd[0], r.stderr.decode()[-500:]))
+        return time.time() - t, r
+    secs["build"], r = run([_lib.BUILD_GG_CLI_PATH, d + "/refs.fa", d + "/refs.map", d + "/db.ubt", "0", str(complevel)])
+    secs["compress"], r = run([_lib.COMPRESS_CLI_PATH, d + "/db.ubt", d + "/db.ctr"])
+    os.remove(d + "/db.ubt")
+    os.remove(d + "/refs.fa")
+    db = CtrDB.open(d + "/db.ctr")
+    t0 = time.time()
+    tree = DeviceTree.upload(db, dev.index or 0)
+    torch.cuda.synchronize(dev)
+    secs["upload"] = time.time() - t0
+    return RelatedDB(ctr=db, tree=tree, kept=kept, ref_len=ref_len, n_nodes=int(db.n_nodes), W=int(db.W), seconds=secs)
+
+
+def make_related_reads(rdb: RelatedDB, n_reads: int, read_len: int = 150, seed: int = 100) -> SynthReads:
+    """Reads cut from the kept references: 1 % substitutions, a quarter reverse-complemented -- they hit in most of their windows."""
+    import torch
+    dev = rdb.kept.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    L = read_len
+    keep = rdb.kept.shape[0]
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    comp = torch.tensor([3, 2, 1, 0], dtype=torch.uint8, device=dev)
+    which = torch.randint(0, keep, (n_reads,), generator=g, device=dev)
+    pos = torch.randint(0, rdb.ref_len - L, (n_reads,), generator=g, device=dev)
+    idx = (which * rdb.ref_len + pos).unsqueeze(1) + torch.arange(L, device=dev).unsqueeze(0)
+    s_ = rdb.kept.view(-1)[idx]
+    mm = torch.rand((n_reads, L), generator=g, device=dev) < 0.01
+    s_ = torch.where(mm, torch.randint(0, 4, (n_reads, L), generator=g, device=dev, dtype=torch.uint8), s_)
+    rcm = (torch.arange(n_reads, device=dev) & 3) == 0
+    s_ = torch.where(rcm.unsqueeze(1), comp[s_.flip(1).long()], s_)
+    off = torch.arange(n_reads, dtype=torch.int64, device=dev) * L
+    ln = torch.full((n_reads,), L, dtype=torch.int32, device=dev)
+    return SynthReads(bases=acgt[s_.long()].contiguous().view(-1), off=off, length=ln, n=n_reads, read_len=L)
