@@ -218,6 +218,7 @@ def main():
             tree.classify(b.bases, b.off, b.length, rc=bool(args.rc), total_bases=totals[i % nb], max_len=maxlens[i % nb],
                           out=outs[i % nb], workspace=wss[i % ns])
 
+    torch.cuda.synchronize()                     # the batches were made on torch's default stream; the steps run on streams of their own (non-blocking ones)
     for i in range(args.warmup):
         step(nb - 1 - (i % nb))
     torch.cuda.synchronize()

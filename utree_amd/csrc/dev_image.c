@@ -606,6 +606,7 @@ static void ring_collect(utree_dev *d) {
         d->lanes_ring[2 * i] = ~0ull; d->lanes_ring[2 * i + 1] = ~0ull;
         d->ring_inflight[i] = 0;
         if (err && !d->dev_error) d->dev_error = err;
+        if (timing_on()) fprintf(stderr, "[utree_amd] batch report: %llu of %u reads left by the lane pass, error word %llu\n", left, d->lanes_ring_reads[i], err);
         if (d->lanes_ring_reads[i]) {
             /* (a batch the pass did well on ends a bad spell at once: the window starts again with it) */
             if (left * 4 <= d->lanes_ring_reads[i]) { unsigned long long n = 0, l = 0; for (unsigned w = 0; w < UTREE_LANES_WINDOW; ++w) { n += d->win_reads[w]; l += d->win_left[w]; }
