@@ -15,7 +15,10 @@ args = open(d + "/bench_args.txt").read().strip() if os.path.exists(d + "/bench_
 out.append("bench args: %s   kernel sources sha256: %s" % (args or "(default)", sha))
 j = json.loads(open(d + "/trace.json").read().strip().splitlines()[-1])
 out.append("bench line under rocprofv3 --kernel-trace: value=%.4g reads/s  roofline=%s" % (j["value"], json.dumps(j["roofline"])))
-f = glob.glob(d + "/trace/*/*_kernel_stats.csv")[0]
+# (a bench run that starts child processes -- the hit-dense workload runs the product's builder -- leaves one file per process: the one
+# that holds the classify kernels is the bench's own)
+cands = glob.glob(d + "/trace/*/*_kernel_stats.csv")
+f = next((c for c in cands if "classify" in open(c).read()), cands[0])
 out.append("\n== rocprofv3 --kernel-trace --stats (top kernels) ==")
 out.append("%-110s %8s %14s %14s %7s" % ("Name", "Calls", "TotalNs", "AverageNs", "Pct"))
 stats = {}
@@ -33,7 +36,7 @@ for tag in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_tcc"):
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
-    for r in csv.DictReader(open(fs[0])):
+    for r in (row for one in fs for row in csv.DictReader(open(one))):
         k = r["Kernel_Name"]
         if "classify" in k or "vote_k" in k:
             k = k.replace("void ", "", 1).replace("(anonymous namespace)::", "").split("(")[0].strip()
