@@ -695,7 +695,9 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
     w->short_cap = max_total > UTREE_SHORT_CAP ? UTREE_SHORT2_CAP : UTREE_SHORT_CAP;
     w->mid_reads = max_total > w->short_cap;
     w->mid_limit = mid_limit();
-    const int lanes_img = lanes_enabled() && utk_lanes_image_ok(&d->kimg);
+    /* (what the image allows, not what UTREE_LANE_PASS says at this moment: a workspace sized once -- the whole-file search keeps its
+     * lanes' workspaces -- must hold for every batch whichever kernels take it) */
+    const int lanes_img = utk_lanes_image_ok(&d->kimg);
     if (max_total > w->mid_limit || (lanes_img && max_len > utk_lanes_max_len(&d->kimg))) {
         w->long_blocks = (uint32_t)d->n_cu * LONG_BLOCKS_PER_CU;
         if (w->long_blocks > n_reads) w->long_blocks = n_reads;
