@@ -517,7 +517,15 @@ _Pragma("unroll") \
                 const uint64_t om = ballot64((lane & 3u) == 3u && d != G::DNONE && more);
                 if (om) {
                     const uint32_t first = cpk & 0xFFu, q = (cpk >> 20) & 63u;
-                    if ((om >> lane) & 1ull) runs[n_ovf + lanes_below(om)] = (first + d) | (first << 8) | ((first + lenm1 + 1u) << 16) | (q << 24);
+                    if ((om >> lane) & 1ull) {
+                        const uint32_t at = n_ovf + lanes_below(om);
+                        runs[at] = (first + d) | (first << 8) | ((first + lenm1 + 1u) << 16) | (q << 24);
+#ifndef UTREE_LANES_REFETCH_DESC
+                        // (the descriptor is in this lane's registers: the first 64 of a grab's overflowing runs keep it, and the
+                        // overflow stage's first round starts without the trip that fetches it again)
+                        if (at < 64u) ost[at] = (W == 8 && I == 4) ? (((uint64_t)Pk.y << 32) | Pk.x) : (((uint64_t)Pk.w << 32) | Pk.z);
+#endif
+                    }
                     n_ovf += (uint32_t)__popcll(om);
                 }
             }
@@ -594,11 +602,17 @@ _Pragma("unroll") \
             uint32_t nrec = 0, wn = 0;                                             // records to scan / windows to search of the lane's item
             if (i < n_ovf) {
                 const uint32_t rec = runs[i];
-                uint32_t m, A[NA], B[NA];
-                context(rec >> 24, rec & 0xFFu, m, A, B);
-                const uint32_t h = mix32(m);
-                const uint64_t baddr = bucket_addr(h);
-                const uint64_t dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + (64u * NL - 8u * EW + 8u * KW));   // the key word of the bucket's last entry
+                uint64_t dsc;
+#ifndef UTREE_LANES_REFETCH_DESC
+                if (ib == 0u) dsc = ost[lane];                                     // kept by the scan that found the run
+                else
+#endif
+                {
+                    uint32_t m, A[NA], B[NA];
+                    context(rec >> 24, rec & 0xFFu, m, A, B);
+                    const uint64_t baddr = bucket_addr(mix32(m));
+                    dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + (64u * NL - 8u * EW + 8u * KW));   // the key word of the bucket's last entry
+                }
                 const uint64_t n = (dsc >> 40) & 0x3FFFFFull;
                 ost[lane] = dsc;
                 if (n <= OVF_SCAN) nrec = (uint32_t)n; else wn = ((rec >> 16) & 0xFFu) - ((rec >> 8) & 0xFFu);
