@@ -596,23 +596,33 @@ _Pragma("unroll") \
 #define UTREE_LANES_OVF_WAYS 4
 #endif
         constexpr uint32_t OVF_SCAN = UTREE_LANES_OVF_SCAN, OVF_WAYS = UTREE_LANES_OVF_WAYS;
+        // the descriptor of overflowing run i: the key word of its bucket's last entry (a line phase B has fetched: an L2 hit mostly)
+        auto fetch_desc = [&](uint32_t i) -> uint64_t {
+            uint64_t dsc = 0;
+            if (i < n_ovf) {
+                const uint32_t rec = runs[i];
+                uint32_t m, A[NA], B[NA];
+                context(rec >> 24, rec & 0xFFu, m, A, B);
+                const uint64_t baddr = bucket_addr(mix32(m));
+                dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + (64u * NL - 8u * EW + 8u * KW));
+            }
+            return dsc;
+        };
+        uint64_t dsc_next = 0;                                                     // requested one round ahead
         for (uint32_t ib = 0; ib < n_ovf; ib += 64) {
             wave_lds_fence();
             const uint32_t i = ib + lane;
             uint32_t nrec = 0, wn = 0;                                             // records to scan / windows to search of the lane's item
+            // round 0's descriptors were kept by the scans that found the runs; every later round's were requested during the round
+            // before it: no round waits for them
+#ifdef UTREE_LANES_REFETCH_DESC
+            uint64_t dsc = fetch_desc(i);
+#else
+            uint64_t dsc = ib == 0u ? ost[lane] : dsc_next;
+            if (ib + 64u < n_ovf) dsc_next = fetch_desc(i + 64u);
+#endif
             if (i < n_ovf) {
                 const uint32_t rec = runs[i];
-                uint64_t dsc;
-#ifndef UTREE_LANES_REFETCH_DESC
-                if (ib == 0u) dsc = ost[lane];                                     // kept by the scan that found the run
-                else
-#endif
-                {
-                    uint32_t m, A[NA], B[NA];
-                    context(rec >> 24, rec & 0xFFu, m, A, B);
-                    const uint64_t baddr = bucket_addr(mix32(m));
-                    dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + (64u * NL - 8u * EW + 8u * KW));   // the key word of the bucket's last entry
-                }
                 const uint64_t n = (dsc >> 40) & 0x3FFFFFull;
                 ost[lane] = dsc;
                 if (n <= OVF_SCAN) nrec = (uint32_t)n; else wn = ((rec >> 16) & 0xFFu) - ((rec >> 8) & 0xFFu);
