@@ -142,6 +142,10 @@ static void bind_image(utree_dev *d) {
     d->kimg.flags = d->hdr.flags;
     d->kimg.W = d->hdr.W; d->kimg.I = d->hdr.I;
     d->kimg.bucket_words = d->hdr.bucket_words;
+    {   /* n_min = records kept in overflow runs */
+        const char *e = getenv("UTREE_OVF_SCAN");
+        d->kimg.ovf_scan = e && atoi(e) > 0 && atoi(e) <= 1024 ? (uint32_t)atoi(e) : (d->hdr.n_min * 4 > d->hdr.n_nodes ? 16u : 32u);
+    }
     d->kimg.irr_n = 0;
     for (int i = 0; i < 4; ++i) d->kimg.irr_p[i] = 0xFFFFFFFFu;
     if (d->hdr.flags & UTREE_F_GENERIC) d->kimg.irr_n = 0xFFFFFFFFu;

@@ -169,6 +169,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     const uint32_t wave_gid = blockIdx.x * LANES_WAVES + wv;
     if constexpr (PIECE) n_reads = (uint32_t)ws.cursors[UTREE_CUR_PIECES];    // (the items: pieces)
     if constexpr (LISTED) n_reads = (uint32_t)ws.cursors[UTREE_CUR_CLASS + cls];
+    if constexpr (MODE != 0) { if (!n_reads) return; }                  // (a length class no read of the batch fell into, no long read: nothing to set up)
     const uint32_t *const lst = LISTED ? ws.cls_list + (size_t)cls * ws.cls_stride : nullptr;
     unsigned long long *parts = ws.cursors + 64 + (PIECE ? 2 : LISTED ? 3 + cls : 0) * (UTREE_WORK_PARTS * UTREE_WORK_STRIDE);
     const uint32_t part_len = ((n_reads + UTREE_WORK_PARTS - 1) / UTREE_WORK_PARTS + 63u) / 64u * 64u;
@@ -589,13 +590,13 @@ _Pragma("unroll") \
         // (descriptor, records) however many windows the run has.  A long one (a minimizer shared by the k-mers of many related
         // genomes) is searched per window by bisection like the wave-per-read kernel does (wave_common.hpp: min_find), one lane per
         // WINDOW and OVF_WAYS windows per lane at a time: the searches' dependent loads overlap. ----
-#ifndef UTREE_LANES_OVF_SCAN
-#define UTREE_LANES_OVF_SCAN 32
-#endif
 #ifndef UTREE_LANES_OVF_WAYS
 #define UTREE_LANES_OVF_WAYS 4
 #endif
-        constexpr uint32_t OVF_SCAN = UTREE_LANES_OVF_SCAN, OVF_WAYS = UTREE_LANES_OVF_WAYS;
+        // (the threshold is the image's: 32 records, 16 for a database most of whose nodes sit in overflow runs -- related genomes --, where
+        // same-box 16 is 3.5 % faster and 64 or more 12-20 % slower; UTREE_OVF_SCAN overrides)
+        constexpr uint32_t OVF_WAYS = UTREE_LANES_OVF_WAYS;
+        const uint32_t OVF_SCAN = im.ovf_scan;
         // the descriptor of overflowing run i: the key word of its bucket's last entry (a line phase B has fetched: an L2 hit mostly)
         auto fetch_desc = [&](uint32_t i) -> uint64_t {
             uint64_t dsc = 0;

@@ -98,6 +98,7 @@ typedef struct {
     uint64_t n_nodes;
     uint32_t n_labels, fine_bits, flags, W, I;
     uint32_t bucket_words;           /* 8 or 16                                                              */
+    uint32_t ovf_scan;               /* overflow runs of up to this many records are read whole by the lane pass, longer ones searched */
     /* the 24-bit prefixes of the irregular bins when there are at most four of them (COMPRESS' first-bin quirk makes one or two;
      * unused entries are ~0), else irr_n = ~0: what lets the lane-per-read pass tell the reads it must leave alone */
     uint32_t irr_n, irr_p[4];
