@@ -109,7 +109,8 @@ __device__ __forceinline__ void rest96(const uint32_t (&A)[3], const uint32_t (&
 // hold) and the LCAP bases from s SW on that they lie in -- reads of up to (SEGS - 1) SW + LCAP bases, 64 / SEGS of them per wavefront
 // IRR: the table has a few irregular bins (COMPRESS' first-bin quirk): their words need the reference's own probe sequence
 // (wave_common.hpp: resolve_bucket), so a read with a window in one of them is left to the wave-per-read kernel
-// MODE 0: the items are the batch's reads 0 .. n_reads - 1.  MODE 1 (LISTED): the reads of one length class of a mixed batch, listed by
+// MODE 0: the items are the batch's reads 0 .. n_reads - 1 (with `cls` set: of a mixed batch, whose longer reads are on other launches'
+// lists -- they are passed over here; the one-lane class needs no list and no trip for it).  MODE 1 (LISTED): the reads of one length class of a mixed batch, listed by
 // lanes_route_k (ws.cls_list, class `cls`; their number is on the device).  MODE 2 (PIECE): the items are not reads but pieces of
 // long reads (ws.pieces: SEGS SW windows of a read on ws.long_list each); a piece's tally goes into its read's table in HBM
 // (ws.ltab_*), which finish_long_k turns into the read's result
@@ -170,6 +171,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     if constexpr (PIECE) n_reads = (uint32_t)ws.cursors[UTREE_CUR_PIECES];    // (the items: pieces)
     if constexpr (LISTED) n_reads = (uint32_t)ws.cursors[UTREE_CUR_CLASS + cls];
     if constexpr (MODE != 0) { if (!n_reads) return; }                  // (a length class no read of the batch fell into, no long read: nothing to set up)
+    if constexpr (MODE == 0) { if (cls && !ws.cursors[UTREE_CUR_CLASS]) return; }   // (a mixed batch without a read of one lane)
     const uint32_t *const lst = LISTED ? ws.cls_list + (size_t)cls * ws.cls_stride : nullptr;
     unsigned long long *parts = ws.cursors + 64 + (PIECE ? 2 : LISTED ? 3 + cls : 0) * (UTREE_WORK_PARTS * UTREE_WORK_STRIDE);
     const uint32_t part_len = ((n_reads + UTREE_WORK_PARTS - 1) / UTREE_WORK_PARTS + 63u) / 64u * 64u;
@@ -203,7 +205,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         // (L, o: the lane's piece of its read -- the whole read with one lane per read)
         uint32_t L = 0;
         uint64_t o = 0;
-        bool exc = false;
+        bool exc = false, other = false;                                  // other: the read is another launch's (MODE 0 of a mixed batch)
         {
             const uint32_t r0 = item + (lane >> SEGSH), piece = lane & (SEGS - 1u);
             if (r0 < item_end) {
@@ -216,7 +218,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 } else {
                     const uint32_t rd = LISTED ? lst[r0] : r0;
                     const uint32_t Lr = len[rd];
-                    if (Lr > (SEGS - 1u) * SW + LCAP) exc = true;                 // longer than this instantiation holds
+                    if (Lr > (SEGS - 1u) * SW + LCAP) { if (MODE == 0 && SEGS == 1 && cls) other = true; else exc = true; }   // longer than this instantiation holds
                     else if (Lr > piece * SW) { L = umin(LCAP, Lr - piece * SW); o = off[rd] + piece * SW; }
                 }
             }
@@ -584,6 +586,7 @@ _Pragma("unroll") \
             }
         }
 #undef QUAD_BCAST
+        LT(5);
         // ---- runs whose bucket overflows.  The bucket's last entry names the run of MIN records that holds the rest of its nodes.  A
         // short run (up to OVF_SCAN records: a minimizer with a few more nodes than a bucket holds) is read whole, one lane per RECORD,
         // and every record treated like a bucket entry -- which window of the run is it the record of? --: two round trips
@@ -735,7 +738,7 @@ _Pragma("unroll") \
         // ---- phase C: tally (itree.c:1028-1040), result records, the list of reads left to the wave-per-read kernel ----
         // (lane i < 64 / SEGS finishes read i of the grab; what its lanes could not take is in their `exc`)
         const uint64_t excm = ballot64(exc);
-        const bool have = lane < RPW && item + lane < item_end;
+        const bool have = lane < RPW && item + lane < item_end && !other;
         const uint32_t r = LISTED ? (have ? lst[item + lane] : 0u) : item + lane;    // the read (PIECE: the piece)
         exc = ((excm >> ((lane * SEGS) & 63u)) & ((1ull << SEGS) - 1ull)) != 0ull || ((full[lane >> 5] >> (lane & 31u)) & 1u) != 0u || wave_full;
         if constexpr (PIECE) {
@@ -819,7 +822,7 @@ _Pragma("unroll") \
         LT(4);
     }
 #ifdef UTREE_LANES_TIMERS
-    if (lane == 0) { for (int q = 0; q < 5; ++q) atomicAdd(&g_lphase[q], lt_acc[q]); atomicAdd(&g_lphase[7], 1ull); }
+    if (lane == 0) { for (int q = 0; q < 6; ++q) atomicAdd(&g_lphase[q], lt_acc[q]); atomicAdd(&g_lphase[7], 1ull); }
 #endif
 }
 

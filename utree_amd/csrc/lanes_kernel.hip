@@ -136,8 +136,9 @@ __global__ __launch_bounds__(256) void lanes_route_k(const uint32_t *__restrict_
 #pragma unroll
     for (uint32_t j = 0; j < ROUTE_CHUNK / 256; ++j) {
         const uint32_t r = lo + j * 256u + threadIdx.x, c = cls[j];
+        // (the reads of one lane, class 0, are counted, not listed: their launch walks the batch itself and passes over the others)
 #pragma unroll
-        for (uint32_t v = 0; v < 6; ++v) {
+        for (uint32_t v = 1; v < 6; ++v) {
             const uint64_t m = ballot64(c == v);
             if (!m) continue;
             const uint32_t lead = (uint32_t)__builtin_ctzll(m);
@@ -223,8 +224,10 @@ int utk_classify_lanes_mixed(const utk_image *im, const uint8_t *d_bases, const 
     lc.mid_cap = UTREE_MID_CAP;
     lanes_route_k<<<dim3((n_reads + ROUTE_CHUNK - 1) / ROUTE_CHUNK), dim3(256), 0, (hipStream_t)stream>>>(d_len, n_reads, do_rc, *ws, lc);
     int rc = (int)hipGetLastError();
-    for (int c = 0; c < 5 && !rc; ++c) {
-        if (c && max_len <= lc.cap[c - 1]) break;                          // no read of the batch needs this many lanes
+    // the reads of one lane: the plain launch over the batch, told to pass over the longer ones (no list, no trip to it per grab)
+    if (!rc) rc = lanes_launch(im, 1, 0, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, 1u);
+    for (int c = 1; c < 5 && !rc; ++c) {
+        if (max_len <= lc.cap[c - 1]) break;                               // no read of the batch needs this many lanes
         rc = lanes_class_launch(im, c, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream);
     }
     return rc;

@@ -23,17 +23,20 @@ extern "C" int CAT(utk_lanes_part_, LANES_W, LANES_I, LANES_NL)(int segs, int ir
     return (int)hipErrorInvalidValue;
 }
 
-// (phase timers, a debugging build: the counters of the k = 32 / u16 labels / 64-byte buckets set)
-#if defined(UTREE_LANES_TIMERS) && LANES_W == 8 && LANES_I == 2 && LANES_NL == 1
+// (phase timers, a debugging build: the counters of the k = 32 (-DUTREE_LANES_TIMERS_W=16: k = 64) / u16 labels / 64-byte buckets set)
+#ifndef UTREE_LANES_TIMERS_W
+#define UTREE_LANES_TIMERS_W 8
+#endif
+#if defined(UTREE_LANES_TIMERS) && LANES_W == UTREE_LANES_TIMERS_W && LANES_I == 2 && LANES_NL == 1
 extern "C" {
 void utk_lanes_phase_dump(void) {
     unsigned long long h[8];
-    static const char *nm[5] = {"grab", "phase 0: bytes -> codes", "phase A: minimizer runs", "phase B: buckets", "phase C: tally, results"};
+    static const char *nm[6] = {"grab", "phase 0: bytes -> codes", "phase A: minimizer runs", "phase B: overflow runs", "phase C: tally, results", "phase B: buckets"};
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lphase), sizeof h) != hipSuccess) return;
     unsigned long long tot = 0;
-    for (int q = 0; q < 5; ++q) tot += h[q];
+    for (int q = 0; q < 6; ++q) tot += h[q];
     fprintf(stderr, "[lanes phase timers] %llu waves, %.4g cycles per wave\n", h[7], h[7] ? (double)tot / h[7] : 0.0);
-    for (int q = 0; q < 5; ++q) fprintf(stderr, "  %-28s %5.1f %%\n", nm[q], tot ? 100.0 * h[q] / tot : 0.0);
+    for (int q = 0; q < 6; ++q) fprintf(stderr, "  %-28s %5.1f %%\n", nm[q], tot ? 100.0 * h[q] / tot : 0.0);
     memset(h, 0, sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lphase), h, sizeof h);
 }
