@@ -649,33 +649,52 @@ _Pragma("unroll") \
                 return lo;
             };
             const uint32_t total_rec = spread(nrec);
-            for (uint32_t t0 = 0; t0 < total_rec; t0 += 64) {
-                const uint32_t t = t0 + lane;
-                if (t < total_rec) {
-                    uint32_t j;
-                    const uint32_t it_ = item_of(t, j);
-                    const uint32_t rec = runs[ib + it_];
-                    const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu, lenm1 = ((rec >> 16) & 0xFFu) - 1u - first;
-                    const Entry<W, I> e = load_entry<W, I>(im.mrecs, (ost[it_] & M40) + j);
-                    uint32_t m, A[NA], B[NA];
-                    context(q, ustar, m, A, B);
-                    const uint32_t h = mix32(m);
-                    const uint32_t hlow = h & 0xFFu;
-                    bool hit;
-                    uint32_t rank;
-                    if constexpr (W == 8) {
-                        const uint32_t lo = (uint32_t)e.w[0], hi = (uint32_t)(e.w[0] >> 32), pos = (hi >> 17) & 31u;
-                        hit = (hi >> 22) == hlow && (ustar - first - pos) <= lenm1 && (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos)) == lo;
-                        if constexpr (I == 2) rank = hi & 0xFFFFu; else { rank = (uint32_t)e.w[1]; hit = hit && rank != INVALID; }
-                    } else {
-                        const uint32_t z = (uint32_t)e.w[1], wq = (uint32_t)(e.w[1] >> 32), pos = (wq >> 16) & 63u;
-                        uint32_t r0, r1, r2;
-                        rest96(A, B, pos, r0, r1, r2);
-                        hit = (wq >> 22) == hlow && (ustar - first - pos) <= lenm1 && r0 == __builtin_amdgcn_alignbit(wq, z, 16u) &&
-                              r1 == (uint32_t)(e.w[0] >> 32) && r2 == (uint32_t)e.w[0];
-                        rank = z & 0xFFFFu;
+            // (k = 64: two blocks of 64 records per step, both blocks' records requested before the first is looked at -- the loop is one memory
+            // round trip per step, and a grab of a k = 64 database has a few hundred such records: same box 1.33 -> 1.31 ms; k = 32, config 2, with
+            // twenty overflowing runs per grab: +2-3 % with two blocks, one it is)
+            constexpr uint32_t RB = W == 16 ? 2 : 1;
+            for (uint32_t t0 = 0; t0 < total_rec; t0 += 64 * RB) {
+                Entry<W, I> e[RB];
+                uint32_t recs[RB];
+#pragma unroll
+                for (uint32_t u = 0; u < RB; ++u) {
+                    const uint32_t t = t0 + 64u * u + lane;
+                    recs[u] = 0;
+#pragma unroll
+                    for (int x = 0; x < EW; ++x) e[u].w[x] = 0;
+                    if (t < total_rec) {
+                        uint32_t j;
+                        const uint32_t it_ = item_of(t, j);
+                        recs[u] = runs[ib + it_];
+                        e[u] = load_entry<W, I>(im.mrecs, (ost[it_] & M40) + j);
                     }
-                    if (hit && (I == 4 || rank != 0xFFFFu)) push(q, rank);
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < RB; ++u) {
+                    const uint32_t t = t0 + 64u * u + lane;
+                    if (t < total_rec) {
+                        const uint32_t rec = recs[u];
+                        const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu, lenm1 = ((rec >> 16) & 0xFFu) - 1u - first;
+                        uint32_t m, A[NA], B[NA];
+                        context(q, ustar, m, A, B);
+                        const uint32_t h = mix32(m);
+                        const uint32_t hlow = h & 0xFFu;
+                        bool hit;
+                        uint32_t rank;
+                        if constexpr (W == 8) {
+                            const uint32_t lo = (uint32_t)e[u].w[0], hi = (uint32_t)(e[u].w[0] >> 32), pos = (hi >> 17) & 31u;
+                            hit = (hi >> 22) == hlow && (ustar - first - pos) <= lenm1 && (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos)) == lo;
+                            if constexpr (I == 2) rank = hi & 0xFFFFu; else { rank = (uint32_t)e[u].w[1]; hit = hit && rank != INVALID; }
+                        } else {
+                            const uint32_t z = (uint32_t)e[u].w[1], wq = (uint32_t)(e[u].w[1] >> 32), pos = (wq >> 16) & 63u;
+                            uint32_t r0, r1, r2;
+                            rest96(A, B, pos, r0, r1, r2);
+                            hit = (wq >> 22) == hlow && (ustar - first - pos) <= lenm1 && r0 == __builtin_amdgcn_alignbit(wq, z, 16u) &&
+                                  r1 == (uint32_t)(e[u].w[0] >> 32) && r2 == (uint32_t)e[u].w[0];
+                            rank = z & 0xFFFFu;
+                        }
+                        if (hit && (I == 4 || rank != 0xFFFFu)) push(q, rank);
+                    }
                 }
             }
             const uint32_t total_win = spread(wn);
