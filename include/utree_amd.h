@@ -44,6 +44,9 @@ enum {
 };
 
 const char *utree_strerror(int code);
+/* what the calling thread's last UTREE_E_HIP / UTREE_E_DEVICE was: the failing HIP call and the runtime's message for it (no
+ * counterpart in the reference, which has no device; "" when there was none) */
+const char *utree_last_hip_error(void);
 int utree_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -21,12 +21,14 @@
 #include "ctr_host.h"
 #include "dev_image.h"
 
-#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { utree_dev_set_hip_error((int)e_, #x); rc = UTREE_E_HIP; goto fail; } } while (0)
-#define KCHK(x) do { int e_ = (x); if (e_ != 0) { utree_dev_set_hip_error(e_, #x); rc = UTREE_E_HIP; goto fail; } } while (0)
+/* (HBM exhausted is UTREE_E_NOMEM, not "no device": a database too large for what is free says so) */
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { utree_dev_set_hip_error((int)e_, #x); rc = e_ == hipErrorOutOfMemory ? UTREE_E_NOMEM : UTREE_E_HIP; goto fail; } } while (0)
+#define KCHK(x) do { int e_ = (x); if (e_ != 0) { utree_dev_set_hip_error(e_, #x); rc = e_ == (int)hipErrorOutOfMemory ? UTREE_E_NOMEM : UTREE_E_HIP; goto fail; } } while (0)
 
 static __thread char g_hip_msg[256];
 void utree_dev_set_hip_error(int err, const char *what) {
-    snprintf(g_hip_msg, sizeof g_hip_msg, "%s: %s", what, hipGetErrorString((hipError_t)err));
+    /* (the runtime's message first: `what` is the text of the failing call and may be longer than the buffer) */
+    snprintf(g_hip_msg, sizeof g_hip_msg, "%s (%d) in %s", hipGetErrorString((hipError_t)err), err, what);
     if (getenv("UTREE_DEBUG")) fprintf(stderr, "[utree_amd] HIP error: %s\n", g_hip_msg);
 }
 const char *utree_last_hip_error(void) { return g_hip_msg; }
@@ -41,9 +43,17 @@ static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
  * (profiles/r03/ab_v8_vs_v9.txt): 64-byte buckets make the classify kernels 5-10 % faster -- half the entries to scan
  * per lookup, one request per bucket instead of two --, 128-byte buckets make the image a third smaller (twice the nodes per bucket at the
  * same overflow rate) and every fetched byte one that is looked at. */
-static uint32_t bucket_words_default(void) {
+/* The default depends on the database: a 16-mer's hash is one of 2^32 values and the minimizer is a MINIMUM, so at the dense end of the hash
+ * range a single value is shared by N (K - 15) / 2^32 nodes -- 4.8 for config 2 (1.217 G 32-mers), 6.5 for config 5 (568 M 64-mers) -- and there is
+ * at most one bucket per value.  Once that number passes what a 64-byte bucket holds, most dense-end lookups continue in an overflow run and the
+ * line-sized bucket is the faster one (same box, kernel ms per 4 M reads, 64 / 128 bytes: k = 32: 2.0 G nodes 1.76 / 1.78, 2.7 G 1.96 / 1.87, 3.5 G
+ * 2.23 / 1.86; k = 64: 568 M 1.29 / 1.53, 1.2 G 1.68 / 1.67, 2.0 G 2.46 / 2.26; profiles/r03/scale_bucket_sizes.txt).  UTREE_BUCKET_BYTES=64|128
+ * overrides. */
+static uint32_t bucket_words_default(uint64_t n_nodes, uint32_t W) {
     const char *e = getenv("UTREE_BUCKET_BYTES");
-    return e && atoi(e) == 128 ? 16u : 8u;
+    if (e && atoi(e) == 128) return 16u;
+    if (e && atoi(e) == 64) return 8u;
+    return n_nodes > (W == 16 ? 1250000000ull : 2200000000ull) ? 16u : 8u;
 }
 
 /* Buckets per hash region (utree_image_header.regions) for a tree of N nodes: a node's minimizer hash is the smallest of m = K-15
@@ -81,7 +91,7 @@ int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
         const char *cap_env = getenv("UTREE_TABLE_MAX_GB");
         double cap = (cap_env && atof(cap_env) > 0 ? atof(cap_env) : 48.0) * 1073741824.0;
         int F = 8;
-        const uint32_t bw = bucket_words_default();
+        const uint32_t bw = bucket_words_default(ctr->info.n_nodes, ctr->info.W);
         while (F > 0 && (double)compute_regions(ctr->info.n_nodes, ctr->info.W, ctr->info.I, bw, (uint32_t)F, NULL) * 8.0 * bw > cap) --F;
         return F;
     }
@@ -98,7 +108,7 @@ static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     h->n_labels = ctr->info.n_labels; h->n_nodes = ctr->info.n_nodes;
     /* UTREE_FORCE_OFF64: test hook that runs the 64-bit-offset instantiations (N >= 2^32-1 databases) on small files */
     h->flags = (ctr->info.binix_width == 8 || getenv("UTREE_FORCE_OFF64")) ? UTREE_F_OFF64 : 0;
-    h->bucket_words = bucket_words_default();
+    h->bucket_words = bucket_words_default(h->n_nodes, h->W);
     h->n_slots = compute_regions(h->n_nodes, h->W, h->I, h->bucket_words, F, h->regions);
     uint64_t off = UTREE_IMG_HEADER_BYTES;
     h->off_table = off; off = align_up(off + h->n_slots * 8 * h->bucket_words, 4096);

@@ -73,6 +73,7 @@ class Result(C.Structure):
 SYMBOLS = {
     "utree_strerror": (C.c_char_p, [C.c_int]),
     "utree_abi_version": (C.c_int, []),
+    "utree_last_hip_error": (C.c_char_p, []),
     "utree_ctr_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "utree_ctr_from_memory": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p,
                                         C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -143,6 +144,10 @@ class UtreeError(RuntimeError):
     def __init__(self, code, what=""):
         self.code = code
         msg = load().utree_strerror(code).decode() if _LIB is not None else str(code)
+        if _LIB is not None and code in (4, 5, 11):        # UTREE_E_NOMEM, UTREE_E_HIP, UTREE_E_DEVICE: which call, and what the runtime said
+            hip = (_LIB.utree_last_hip_error() or b"").decode(errors="replace")
+            if hip:
+                msg += " [" + hip + "]"
         super().__init__("%s: %s (code %d)" % (what, msg, code))
 
 

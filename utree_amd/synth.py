@@ -119,10 +119,34 @@ def make_db(device, n_nodes: int, seed: int = DB_SEED, W: int = 8, fine_bits: in
         file_labels[f] = labels_tree[t]
     block = max(1, n_nodes // N_LABELS)
     MIN = _s64(1 << 63)
-    idx = torch.arange(n_nodes, dtype=torch.int64, device=dev)
-    words = mix64(idx ^ _s64(seed))
-    del idx
-    words = torch.sort(words ^ MIN).values ^ MIN                     # unsigned ascending
+    if n_nodes < (1 << 31) - 1:
+        idx = torch.arange(n_nodes, dtype=torch.int64, device=dev)
+        words = mix64(idx ^ _s64(seed))
+        del idx
+        words = torch.sort(words ^ MIN).values ^ MIN                 # unsigned ascending
+    else:
+        # torch sorts (and selects by mask) at most 2^31 - 1 elements at a time: the node indices are walked in chunks, every chunk's
+        # words go to the eighth of the value range they fall into, and the eighths are sorted one by one
+        CH = 1 << 30
+        parts = [[] for _ in range(8)]
+        for lo in range(0, n_nodes, CH):
+            idx = torch.arange(lo, min(n_nodes, lo + CH), dtype=torch.int64, device=dev)
+            w = mix64(idx ^ _s64(seed))
+            del idx
+            top = (w >> 61) & 7                                      # the unsigned value's top three bits
+            for q in range(8):
+                parts[q].append(w[top == q])
+            del w, top
+        words = torch.empty(n_nodes, dtype=torch.int64, device=dev)
+        at = 0
+        for q in range(8):
+            e = torch.cat(parts[q])
+            parts[q] = None
+            e = torch.sort(e ^ MIN).values ^ MIN
+            words[at:at + e.numel()] = e
+            at += e.numel()
+            del e
+        assert at == n_nodes
     orig = unmix64(words) ^ _s64(seed)                               # node index of each sorted word
     tree_id = torch.clamp(orig // block, max=N_LABELS - 1)
     ix = perm.to(dev)[tree_id]
@@ -147,6 +171,7 @@ def make_db(device, n_nodes: int, seed: int = DB_SEED, W: int = 8, fine_bits: in
     label_text = b"".join(lab.encode() + b"\t" + str(int(c)).encode() + b"\n" for lab, c in zip(file_labels, counts))
     ctr = CtrDB.from_memory(W, 2, n_nodes, binix.cpu().numpy().astype(np.uint64), None, label_text)
     torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()                                          # (the image builder allocates with hipMalloc: what torch has freed must be free)
     tree = DeviceTree.build_from_device(ctr, binix32, records.view(-1), device=dev.index or 0, fine_bits=fine_bits,
                                         image=image)
     torch.cuda.synchronize(dev)
