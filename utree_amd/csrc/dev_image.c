@@ -235,7 +235,7 @@ static int build_vote_table(const utree_ctr *ctr, utk_vote_rec *out) {
             if (i < len) h = (h ^ (uint8_t)';') * 1099511628211ull;
         }
         if (!ok) break;
-        v->n_tok = (uint8_t)t; v->len = (uint8_t)len;
+        v->n_tok = (uint8_t)t; v->len = (uint8_t)len; v->ix = (uint16_t)ix;
         for (; t < 8; ++t) { v->pid[t] = 0xFFFFu; v->tok_end[t] = (uint8_t)len; }
     }
     free(hh); free(hv); free(hl);

@@ -855,6 +855,7 @@ __device__ __forceinline__ bool v_exists(const VRec &v, uint32_t t) { return ((u
 __device__ __forceinline__ bool v_more(const VRec &v, uint32_t t) { return ((uint32_t)v.w[3] >> (8u + t)) & 1u; }
 __device__ __forceinline__ bool v_us(const VRec &v, uint32_t t) { return ((uint32_t)v.w[3] >> (16u + t)) & 1u; }
 __device__ __forceinline__ uint32_t v_len(const VRec &v) { return (uint32_t)(v.w[3] >> 32) & 0xFFu; }   // the label's length
+__device__ __forceinline__ uint32_t v_ix(const VRec &v) { return (uint32_t)(v.w[3] >> 48); }             // its file-order index
 
 // The vote with the label table (UTREE_F_VOTE_TABLE): the same state machine as below, every byte scan replaced by what the table says
 // about it.  The labels of the active group [st, ed) agree up to byte dv; t is the token that holds byte dv + 1 (0 at the start), the
@@ -874,7 +875,7 @@ __device__ __forceinline__ void vote_table(const utk_image &im, utree_result *ou
     uint32_t st = 0, ed = uix, dv = NONE, t = 0, orun = F, sl, ol;
     // (every list entry and label record is loaded once per level at most: the group's last entry -- needed for the shared levels -- is
     // also the walk's last `cur`, and whatever ends the descent has its record in registers already)
-    uint32_t rk, n_last, len_last;                                           // the label the result is cut from: rank, count, length
+    uint32_t ix_last, n_last, len_last;                                      // the label the result is cut from: file-order index, count, length
     for (;;) {
         const uint64_t t_st = T[st];
         VRec pv = vrec(vt, (uint32_t)t_st);
@@ -930,7 +931,7 @@ __device__ __forceinline__ void vote_table(const utk_image &im, utree_result *ou
             pv = cv; c1 = nz; rp = rc;
         }
         // the group's last label [ed - 1]: the one before the pair that stopped the walk, else the list's last
-        rk = stopped ? rp : (uint32_t)t_ed;
+        ix_last = stopped ? v_ix(pv) : v_ix(lv);                                // (pv is the record of rank rp)
         n_last = stopped ? c1 : (uint32_t)(t_ed >> 32);
         len_last = stopped ? v_len(pv) : v_len(lv);
         sl = run; ol = orun;                                                   // itree.c:1071
@@ -946,7 +947,7 @@ __device__ __forceinline__ void vote_table(const utk_image &im, utree_result *ou
     if (dv == NONE) cut = -1;                                                  // itree.c:1087
     else if (dv == 0xFFFFFFFEu) cut = -2;
     else cut = (int32_t)(dv < len_last ? dv : len_last);                       // 1088
-    store_result(out_r, im.rank2ix[rk], cut, F, uix, sl, ol);
+    store_result(out_r, ix_last, cut, F, uix, sl, ol);
 }
 
 // vote_table_k: vote_k for images with the label table (a kernel of its own: with both in one, the byte scans' registers cost the table path
@@ -955,15 +956,52 @@ __device__ __forceinline__ void vote_table(const utk_image &im, utree_result *ou
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
 __global__ __launch_bounds__(256) void vote_table_k(utk_image im, utree_result *__restrict__ out, utk_workspace ws, uint32_t n_reads) {
+#ifndef UTREE_VOTE_UNSORTED
+    // The vote is a per-lane state machine: a wavefront executes the union of its lanes' paths, and a read of two labels takes a fraction of
+    // the steps a read of four takes.  The workgroup's 256 reads are therefore dealt out again by what they need: reads of two labels fill the
+    // workgroup's lanes from the bottom, reads of more from the top (the two kinds meet in one wavefront at most); a read of one label or none
+    // is finished where it stands.
+    __shared__ uint32_t s_n[2][4];
+    __shared__ uint16_t s_who[256];
+    const uint32_t tid = threadIdx.x, wv = tid >> 6, lane = tid & 63u;
+    const uint32_t r0 = blockIdx.x * blockDim.x + tid;
+    uint32_t cls = 2;                                      // 0: two labels, 1: more, 2: nothing left to do
+    if (r0 < n_reads) {
+        const uint32_t *res = (const uint32_t *)&out[r0];
+        const int32_t cut = (int32_t)res[1];
+        if (cut == RANK_PENDING) {                         // one distinct label: only its file-order index is missing
+            uint32_t *o = (uint32_t *)&out[r0];
+            o[0] = im.rank2ix[res[0]]; o[1] = (uint32_t)-2;
+        } else if (cut == CUT_PENDING) cls = res[3] == 2u ? 0u : 1u;
+    }
+    const uint64_t m0 = __builtin_amdgcn_ballot_w64(cls == 0u), m1 = __builtin_amdgcn_ballot_w64(cls == 1u);
+    s_who[tid] = 0xFFFFu;
+    if (lane == 0) { s_n[0][wv] = (uint32_t)__popcll(m0); s_n[1][wv] = (uint32_t)__popcll(m1); }
+    __syncthreads();
+    if (cls < 2u) {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wv; ++w) before += s_n[cls][w];
+        before += (uint32_t)__popcll((cls ? m1 : m0) & ((1ull << lane) - 1ull));
+        s_who[cls ? 255u - before : before] = (uint16_t)tid;
+    }
+    __syncthreads();
+    const uint32_t who = s_who[tid];
+    if (who == 0xFFFFu) return;
+    const uint32_t r = blockIdx.x * blockDim.x + who;
+#else
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
-    const uint32_t *res = (const uint32_t *)&out[r];
-    if ((int32_t)res[1] == RANK_PENDING) {                 // one distinct label: only its file-order index is missing
-        uint32_t *o = (uint32_t *)&out[r];
-        o[0] = im.rank2ix[res[0]]; o[1] = (uint32_t)-2;
-        return;
+    {
+        const uint32_t *res = (const uint32_t *)&out[r];
+        if ((int32_t)res[1] == RANK_PENDING) {             // one distinct label: only its file-order index is missing
+            uint32_t *o = (uint32_t *)&out[r];
+            o[0] = im.rank2ix[res[0]]; o[1] = (uint32_t)-2;
+            return;
+        }
+        if ((int32_t)res[1] != CUT_PENDING) return;        // finished by the classify kernel (no hit, or classify_long_k)
     }
-    if ((int32_t)res[1] != CUT_PENDING) return;            // finished by the classify kernel (no hit, or classify_long_k)
+#endif
+    const uint32_t *res = (const uint32_t *)&out[r];
     vote_table(im, &out[r], ws.tally + ((uint64_t)res[4] | ((uint64_t)res[5] << 32)), res[2], res[3]);
 }
 

@@ -13,7 +13,7 @@ extern "C" {
 #define UTREE_INVALID 0xFFFFFFFFu
 #define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
 #define UTREE_IMG_HEADER_BYTES 4096u
-#define UTREE_IMG_VERSION 9u                     /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region */
+#define UTREE_IMG_VERSION 10u                    /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region; 10: the vote records carry the file-order index */
 #define UTREE_REGION_NB_BITS 25                  /* regions[r] = base_r << 25 | nb_r (nb_r <= 2^24)                    */
 #define UTREE_TALLY_CHUNK 8192u                  /* tally entries a wave reserves with one atomic              */
 #define UTREE_CUR_LONG 32                        /* cursors[] index of the long-read counter (own 256-B line)   */
@@ -80,7 +80,8 @@ typedef struct {
     uint16_t pid[8];
     uint8_t tok_end[8];
     uint8_t exists, more, us, n_tok;
-    uint8_t len, pad[3];             /* the label's length */
+    uint8_t len, pad;                /* the label's length */
+    uint16_t ix;                     /* its index in the file's order (rank2ix): the vote's result needs no further lookup */
 } utk_vote_rec;
 
 /* What kernels take by value. */
