@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- reads classified / second on BASELINE.json's config 2: 8 GB L2 CTR (1 217 000 000 synthetic
-32-mer nodes, 21 844 labels), 150 bp synthetic reads, 40 M reads per GPU (10 steps x 4 M-read batches).
+32-mer nodes, 21 844 labels), 150 bp synthetic reads, 160 M reads per GPU by default (10 steps x 16 M-read batches; a
+launch over 16 M reads classifies a read 10-12 % faster than one over 4 M: profiles/r03/batch_sizes.txt).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -36,6 +37,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_CLOCK_HZ = 2.4e9          # MI355X_MICROARCH.md: peak engine clock
 N_SIMD = 256 * 4               # 256 CUs x 4 SIMD16
+DEFAULT_BATCH_READS = 16_000_000   # reads per step of the default workload (hit_dense keeps 4 M: its kept profile is of that size)
+CONFIG_READS = 40_000_000          # BASELINE.json configs[1]: reads of the file -> file leg
 RANDOM_LINE_GBS = 48.6 * 128   # random 128-byte lines/s this chip serves (tools/membench.hip, profiles/r02/membench_random_lines.txt) x 128 B
 
 
@@ -57,7 +60,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nodes", type=int, default=1_217_000_000, help="synthetic CTR nodes (config 2: 1.217e9 = 8 GB)")
-    ap.add_argument("--batch-reads", type=int, default=4_000_000)
+    ap.add_argument("--batch-reads", type=int, default=0,
+                    help="reads per step / per launch (0 = %d; hit_dense: 4 000 000)" % DEFAULT_BATCH_READS)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--len-dist", default="fixed", choices=("fixed", "lognormal"),
                     help="lognormal: SURVEY 8(d)'s config-3 shape -- read lengths ~ lognormal with mean --read-len, clipped to [mean/10, 10 x mean]; "
@@ -79,7 +83,7 @@ def main():
     ap.add_argument("--reference-threads", type=int, default=16, help="threads for the genuine reference (its best on a 256-core box)")
     ap.add_argument("--reference-reads", type=int, default=1_000_000)
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> file leg")
-    ap.add_argument("--e2e-reads", type=int, default=0, help="reads of the file -> file leg (0 = steps x batch-reads, config 2: 40 M)")
+    ap.add_argument("--e2e-reads", type=int, default=0, help="reads of the file -> file leg (0 = config 2's 40 M, or steps x batch-reads when that is less)")
     ap.add_argument("--model-reads", type=int, default=200_000, help="reads of batch 0 the byte model's bucket counts are taken on")
     ap.add_argument("--replicate", default="c", choices=("c", "torch"),
                     help="N>1: image broadcast issued from C (utree_dev_replicate_rank, RCCL) or through torch.distributed.broadcast")
@@ -87,6 +91,12 @@ def main():
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo --replicate torch)")
     ap.add_argument("--e2e-reads-per-rank", type=int, default=8_000_000, help="N>1: reads of each rank's shard in the file -> file leg")
     args = ap.parse_args()
+    if args.batch_reads <= 0:
+        args.batch_reads = 4_000_000 if args.workload == "hit_dense" else DEFAULT_BATCH_READS
+        if args.read_len > 400:                        # long reads: about the same bases per batch
+            args.batch_reads = max(100_000, DEFAULT_BATCH_READS * 150 // args.read_len // 100_000 * 100_000)
+    if args.e2e_reads <= 0:
+        args.e2e_reads = min(CONFIG_READS, args.steps * args.batch_reads)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("UTREE_BENCH_FORCE_DIST"):
         raise SystemExit(self_launch(args))
@@ -187,6 +197,10 @@ def main():
     # ---- reads: each rank's own batches, resident in HBM before the timed region ----
     nb = args.distinct_batches if args.distinct_batches > 0 else args.steps
     nb = max(1, min(nb, args.steps + args.warmup))
+    # ... as far as they fit: the batches (bases, offsets, lengths, results) may take 40 % of this GPU's HBM (16 M x 150 bp: 3 GB each, 38 of them);
+    # beyond that the steps go round the resident batches again (every step still classifies its batch from scratch)
+    per_batch = args.batch_reads * (args.read_len + 8 + 4 + 24)
+    nb = max(1, min(nb, int(0.4 * torch.cuda.get_device_properties(dev).total_memory) // max(1, per_batch)))
     if var_len:
         batches = [synth.make_reads_var(sdb, synth.lognormal_lengths(args.batch_reads, mean=float(args.read_len), lo=max(1, args.read_len // 10),
                                                                      hi=10 * args.read_len, seed=synth.READ_SEED + 1000 * rank + b),

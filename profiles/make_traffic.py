@@ -34,7 +34,7 @@ args = c.get("bench_args", "").split()
 def arg(flag, default):
     return type(default)(args[args.index(flag) + 1]) if flag in args else default
 nodes = arg("--nodes", 1_217_000_000)
-reads = arg("--batch-reads", 4_000_000)
+reads = arg("--batch-reads", int(line["roofline"].get("reads_per_launch", 4_000_000)))      # (bench.py's default differs by workload: take it from the line)
 length = arg("--read-len", 150)
 key = "nodes=%d,reads=%d,len=%d,k=%d,rc=%d" % (nodes, reads, length, kmer, rc)
 if arg("--len-dist", "fixed") != "fixed":

@@ -76,6 +76,35 @@ def test_150bp_reads_on_the_full_size_database(torch_cuda, W, nodes):
     sdb.tree.close()
 
 
+def test_a_batch_of_sixteen_million_reads_equals_its_slices(torch_cuda):
+    """bench.py's default launch is 16 M reads (2.4 GB of bases: offsets beyond 2^31).  Every read is independent of its batch: slices from
+    the head, the middle and the very end of the big batch, classified as small batches of their own, must give the records the big batch
+    gave them, and the last slice also equals the CPU oracle."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    sdb = synth.make_db(dev, 150_000_000, W=8, keep_raw=True)
+    n, L, m = 16_000_000, 150, 60_000
+    reads = synth.make_reads(sdb, n, L, seed=synth.READ_SEED + 99)
+    big = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=False)
+    sdb.tree.poll()
+    assert sdb.tree.kernel_name().startswith("classify_lanes_k<8, 2, 1,")
+    assert int((big[:, 2] > 0).sum().item()) > 0.9 * n
+    for lo in (0, 7_999_968, n - m):
+        part = sdb.tree.classify(reads.bases[lo * L:(lo + m) * L].contiguous(), reads.off[:m].contiguous(), reads.length[:m].contiguous(), rc=False)
+        assert torch.equal(part, big[lo:lo + m]), "slice at %d" % lo
+    o = oracle_of(sdb)
+    host = reads.bases[(n - m) * L:].cpu().numpy()
+    want = o.classify_batch(host, np.arange(m, dtype=np.uint64) * L, np.full(m, L, dtype=np.uint32), rc=False, threads=16)
+    hits, multi = assert_records_equal(big[n - m:].cpu().numpy(), want, m)
+    assert hits > 0.9 * m and multi > 0.3 * m
+    # both strands: the same invariance on the last slice
+    big_rc = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=True)
+    part = sdb.tree.classify(reads.bases[(n - m) * L:].contiguous(), reads.off[:m].contiguous(), reads.length[:m].contiguous(), rc=True)
+    assert torch.equal(part, big_rc[n - m:])
+    sdb.tree.poll()
+    sdb.tree.close()
+
+
 def test_long_reads_with_both_strands_on_the_l4_size_database(torch_cuda):
     """configs[2]: 72 M nodes; reads of 1 kb ... 100 kb (hit-dense: a planted k-mer every 32 bases), RC on."""
     torch = torch_cuda
