@@ -1,17 +1,22 @@
 # round-3 evidence: the default bench line with every leg, rocprofv3 passes for the BASELINE configurations (both bucket sizes for configs 2 and 5),
-# footprint sweeps, the hit-dense workload under the kernel trace
+# footprint sweeps, the hit-dense workload under the kernel trace (the profiles of the first two sessions are of 4 M-read launches: said explicitly since the default moved to 16 M)
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
 python3 bench.py > gpurun_out/r03/bench_r03_n1.json 2> gpurun_out/r03/bench_r03_n1.err
-profiles/run_prof.sh r03_config2 > gpurun_out/r03/p1.log 2>&1
-profiles/run_prof.sh r03_config2_rc --rc 1 > gpurun_out/r03/p2.log 2>&1
-profiles/run_prof.sh r03_config5_k64 --kmer 64 --nodes 568000000 > gpurun_out/r03/p3.log 2>&1
+profiles/run_prof.sh r03_config2 --batch-reads 4000000 > gpurun_out/r03/p1.log 2>&1
+profiles/run_prof.sh r03_config2_rc --rc 1 --batch-reads 4000000 > gpurun_out/r03/p2.log 2>&1
+profiles/run_prof.sh r03_config5_k64 --kmer 64 --nodes 568000000 --batch-reads 4000000 > gpurun_out/r03/p3.log 2>&1
 profiles/run_prof.sh r03_config3_long_rc --nodes 72000000 --read-len 10000 --rc 1 --batch-reads 100000 > gpurun_out/r03/p4.log 2>&1
 profiles/run_prof.sh r03_config3_lognormal_rc --nodes 72000000 --read-len 10000 --rc 1 --batch-reads 100000 --len-dist lognormal > gpurun_out/r03/p5.log 2>&1
-UTREE_BUCKET_BYTES=128 profiles/run_prof.sh r03_config2_bucket128 > gpurun_out/r03/p6.log 2>&1
-UTREE_BUCKET_BYTES=128 profiles/run_prof.sh r03_config5_k64_bucket128 --kmer 64 --nodes 568000000 > gpurun_out/r03/p7.log 2>&1
+UTREE_BUCKET_BYTES=128 profiles/run_prof.sh r03_config2_bucket128 --batch-reads 4000000 > gpurun_out/r03/p6.log 2>&1
+UTREE_BUCKET_BYTES=128 profiles/run_prof.sh r03_config5_k64_bucket128 --kmer 64 --nodes 568000000 --batch-reads 4000000 > gpurun_out/r03/p7.log 2>&1
 profiles/run_prof.sh r03_hit_dense --workload hit_dense > gpurun_out/r03/p8.log 2>&1
+# the long launches (bench.py's default since the round's third session: 16 M reads per launch)
+profiles/run_prof.sh r03_config2_16M > gpurun_out/r03/p9.log 2>&1
+profiles/run_prof.sh r03_config2_rc_16M --rc 1 > gpurun_out/r03/p10.log 2>&1
+profiles/run_prof.sh r03_config5_k64_16M --kmer 64 --nodes 568000000 > gpurun_out/r03/p11.log 2>&1
+profiles/run_prof.sh r03_config3_lognormal_rc_400k --nodes 72000000 --read-len 10000 --rc 1 --batch-reads 400000 --len-dist lognormal --model-reads 2000 > gpurun_out/r03/p12.log 2>&1
 echo "== 64-byte buckets (default), UTREE_BUCKET_TARGET = nodes per bucket ==" > gpurun_out/r03/footprint_sweep.txt
 for t in 2 3 4 5 6; do UTREE_BUCKET_TARGET=$t tools/bq.sh >> gpurun_out/r03/footprint_sweep.txt 2>&1; done
 echo "== 128-byte buckets (UTREE_BUCKET_BYTES=128) ==" >> gpurun_out/r03/footprint_sweep.txt
