@@ -54,6 +54,19 @@ def contract_bytes_per_read(n_nodes: int, W: int, I: int, read_len: int):
     return windows * b_win + read_len + 24, b_win, windows
 
 
+def resolve_defaults(args):
+    """Launch size and file-leg size when the command line leaves them open: 16 M reads per launch (about the same
+    number of BASES per launch for long reads; 4 M for the hit-dense workload, whose kept profile is of that size), and config 2's 40 M
+    reads -- or all the reads of the run, if fewer -- through the file -> file leg."""
+    if args.batch_reads <= 0:
+        args.batch_reads = 4_000_000 if args.workload == "hit_dense" else DEFAULT_BATCH_READS
+        if args.read_len > 400:
+            args.batch_reads = max(100_000, DEFAULT_BATCH_READS * 150 // args.read_len // 100_000 * 100_000)
+    if args.e2e_reads <= 0:
+        args.e2e_reads = min(CONFIG_READS, args.steps * args.batch_reads)
+    return args
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,13 +103,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse on one GPU")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo --replicate torch)")
     ap.add_argument("--e2e-reads-per-rank", type=int, default=8_000_000, help="N>1: reads of each rank's shard in the file -> file leg")
-    args = ap.parse_args()
-    if args.batch_reads <= 0:
-        args.batch_reads = 4_000_000 if args.workload == "hit_dense" else DEFAULT_BATCH_READS
-        if args.read_len > 400:                        # long reads: about the same bases per batch
-            args.batch_reads = max(100_000, DEFAULT_BATCH_READS * 150 // args.read_len // 100_000 * 100_000)
-    if args.e2e_reads <= 0:
-        args.e2e_reads = min(CONFIG_READS, args.steps * args.batch_reads)
+    args = resolve_defaults(ap.parse_args())
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("UTREE_BENCH_FORCE_DIST"):
         raise SystemExit(self_launch(args))

@@ -100,6 +100,28 @@ def test_bench_gpus_flag_launches_one_rank_per_gpu(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_bench_launch_size_defaults():
+    """What bench.py runs when the command line leaves the launch size open: 16 M reads per launch for the 150-bp
+    configurations, about as many bases per launch for long reads, the kept profile's 4 M for the hit-dense workload; the file -> file leg
+    takes config 2's 40 M reads, or the whole run when that is less.  An explicit --batch-reads / --e2e-reads stands."""
+    import argparse
+    import bench
+
+    def r(**kw):
+        a = dict(batch_reads=0, workload="config", read_len=150, e2e_reads=0, steps=10)
+        a.update(kw)
+        return bench.resolve_defaults(argparse.Namespace(**a))
+
+    a = r()
+    assert (a.batch_reads, a.e2e_reads) == (16_000_000, 40_000_000)
+    assert r(steps=2).e2e_reads == 32_000_000
+    assert r(workload="hit_dense").batch_reads == 4_000_000
+    assert r(read_len=10_000).batch_reads == 200_000
+    assert r(read_len=250).batch_reads == 16_000_000
+    a = r(batch_reads=4_000_000, e2e_reads=1_000_000)
+    assert (a.batch_reads, a.e2e_reads) == (4_000_000, 1_000_000)
+
+
 def test_bench_gpus_flag_cold_start_reaches_every_rank(tmp_path):
     """The real thing from a cold start, on this GPU-less box: two ranks come up under torch.distributed.run and each one refuses
     to run without an MI355X (there is no CPU fallback); the launcher's exit code comes back."""
