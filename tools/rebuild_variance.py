@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Where does the run-to-run spread of the lane pass (+-4 %, DESIGN.md sections 0.10 / 0.12) come from?  ONE process builds the config-2 image several
+times (same seed: the same bytes, a new allocation every time) and times the same 16 M-read batch on each; a spread between the builds of one
+process is a property of where the image landed in HBM, not of the box or the clock.
+usage (GPU box): python3 tools/rebuild_variance.py [--builds 4] [--reads 16000000]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--builds", type=int, default=4)
+    ap.add_argument("--reads", type=int, default=16_000_000)
+    ap.add_argument("--nodes", type=int, default=1_217_000_000)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    import torch
+    from utree_amd import synth
+    dev = torch.device("cuda:0")
+    out = {"nodes": args.nodes, "reads_per_launch": args.reads, "builds": []}
+    reads = None
+    for b in range(args.builds):
+        sdb = synth.make_db(dev, args.nodes, W=8)
+        tree = sdb.tree
+        if reads is None:
+            reads = synth.make_reads(sdb, args.reads, 150, seed=synth.READ_SEED)
+            tot = args.reads * 150
+            res = torch.empty((args.reads, 6), dtype=torch.int32, device=dev)
+        ws = torch.empty(tree.workspace_bytes(args.reads, tot, 150, False), dtype=torch.uint8, device=dev)
+        tree.classify(reads.bases, reads.off, reads.length, rc=False, total_bases=tot, max_len=150, out=res, workspace=ws)
+        torch.cuda.synchronize()
+        tree.kernel_time(reset=True)
+        t0 = time.time()
+        for _ in range(args.reps):
+            tree.classify(reads.bases, reads.off, reads.length, rc=False, total_bases=tot, max_len=150, out=res, workspace=ws)
+        torch.cuda.synchronize()
+        step_ms = 1e3 * (time.time() - t0) / args.reps
+        k_ms, k_n = tree.kernel_time(reset=True)
+        tree.poll()
+        ptr = tree.image_ptr()[0]
+        out["builds"].append({"build": b, "step_ms": step_ms, "kernel_ms": k_ms / max(1, k_n), "us_per_M_reads": 1e3 * k_ms / max(1, k_n) / (args.reads / 1e6),
+                              "image_ptr": hex(ptr), "image_ptr_mod_1GiB_MiB": (ptr % (1 << 30)) >> 20, "classified": int((res[:, 2] > 0).sum().item())})
+        print(json.dumps(out["builds"][-1]), file=sys.stderr, flush=True)
+        tree.close()
+        del sdb, tree, ws
+        torch.cuda.empty_cache()
+    ks = [x["kernel_ms"] for x in out["builds"]]
+    out["spread"] = (max(ks) - min(ks)) / min(ks)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
