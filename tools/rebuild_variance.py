@@ -14,13 +14,14 @@ def main():
     ap.add_argument("--reads", type=int, default=16_000_000)
     ap.add_argument("--nodes", type=int, default=1_217_000_000)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--same-workspace", action="store_true", help="with --same-image: the workspace and the result buffer are allocated once too")
     ap.add_argument("--same-image", action="store_true", help="build ONCE and time the batch --builds times, with the work of a build (a 1.2 G-element sort) between the timings: "
                                                                 "a spread here is the chip's state, not the image's pages")
     args = ap.parse_args()
     import torch
     from utree_amd import synth
     dev = torch.device("cuda:0")
-    out = {"same_image": bool(args.same_image), "nodes": args.nodes, "reads_per_launch": args.reads, "builds": []}
+    out = {"same_workspace": bool(args.same_workspace), "same_image": bool(args.same_image), "nodes": args.nodes, "reads_per_launch": args.reads, "builds": []}
     reads = None
     sdb = None
     for b in range(args.builds):
@@ -36,7 +37,8 @@ def main():
             reads = synth.make_reads(sdb, args.reads, 150, seed=synth.READ_SEED)
             tot = args.reads * 150
             res = torch.empty((args.reads, 6), dtype=torch.int32, device=dev)
-        ws = torch.empty(tree.workspace_bytes(args.reads, tot, 150, False), dtype=torch.uint8, device=dev)
+        if not (args.same_workspace and b):
+            ws = torch.empty(tree.workspace_bytes(args.reads, tot, 150, False), dtype=torch.uint8, device=dev)
         tree.classify(reads.bases, reads.off, reads.length, rc=False, total_bases=tot, max_len=150, out=res, workspace=ws)
         torch.cuda.synchronize()
         tree.kernel_time(reset=True)
@@ -49,13 +51,14 @@ def main():
         tree.poll()
         ptr = tree.image_ptr()[0]
         out["builds"].append({"build": b, "step_ms": step_ms, "kernel_ms": k_ms / max(1, k_n), "us_per_M_reads": 1e3 * k_ms / max(1, k_n) / (args.reads / 1e6),
-                              "image_ptr": hex(ptr), "image_ptr_mod_1GiB_MiB": (ptr % (1 << 30)) >> 20, "classified": int((res[:, 2] > 0).sum().item())})
+                              "image_ptr": hex(ptr), "workspace_ptr": hex(ws.data_ptr()), "image_ptr_mod_1GiB_MiB": (ptr % (1 << 30)) >> 20, "classified": int((res[:, 2] > 0).sum().item())})
         print(json.dumps(out["builds"][-1]), file=sys.stderr, flush=True)
         if not args.same_image:
             tree.close()
             del sdb, tree
             sdb = None
-        del ws
+        if not args.same_workspace:
+            del ws
         torch.cuda.empty_cache()
     ks = [x["kernel_ms"] for x in out["builds"]]
     out["spread"] = (max(ks) - min(ks)) / min(ks)
