@@ -14,6 +14,8 @@ def main():
     ap.add_argument("--reads", type=int, default=16_000_000)
     ap.add_argument("--nodes", type=int, default=1_217_000_000)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--image-first-gib", type=int, default=0, help="allocate this many GiB for the image as the process's FIRST device allocation (before torch has "
+                                                                   "allocated and freed anything) and build every image in it")
     ap.add_argument("--same-workspace", action="store_true", help="with --same-image: the workspace and the result buffer are allocated once too")
     ap.add_argument("--same-image", action="store_true", help="build ONCE and time the batch --builds times, with the work of a build (a 1.2 G-element sort) between the timings: "
                                                                 "a spread here is the chip's state, not the image's pages")
@@ -21,7 +23,8 @@ def main():
     import torch
     from utree_amd import synth
     dev = torch.device("cuda:0")
-    out = {"same_workspace": bool(args.same_workspace), "same_image": bool(args.same_image), "nodes": args.nodes, "reads_per_launch": args.reads, "builds": []}
+    first = torch.empty(args.image_first_gib << 30, dtype=torch.uint8, device=dev) if args.image_first_gib else None
+    out = {"image_first_gib": args.image_first_gib, "same_workspace": bool(args.same_workspace), "same_image": bool(args.same_image), "nodes": args.nodes, "reads_per_launch": args.reads, "builds": []}
     reads = None
     sdb = None
     for b in range(args.builds):
@@ -31,7 +34,7 @@ def main():
             del junk
             torch.cuda.empty_cache()
         else:
-            sdb = synth.make_db(dev, args.nodes, W=8)
+            sdb = synth.make_db(dev, args.nodes, W=8, image=first)
         tree = sdb.tree
         if reads is None:
             reads = synth.make_reads(sdb, args.reads, 150, seed=synth.READ_SEED)
