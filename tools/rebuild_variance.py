@@ -8,8 +8,41 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+class Sampler:
+    """Reads the card's DPM tables and sensors from sysfs (read-only, an ordinary user may) every few ms while a timing runs: which clock levels
+    were current (the line with the '*'), junction / memory temperature, power."""
+    def __init__(self):
+        import glob
+        self.files = {}
+        for c in sorted(glob.glob("/sys/class/drm/card*/device")):
+            for n in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_socclk"):
+                if os.path.exists(os.path.join(c, n)) and n not in self.files:
+                    self.files[n] = os.path.join(c, n)
+            for h in glob.glob(os.path.join(c, "hwmon/hwmon*")):
+                for n in ("temp1_input", "temp2_input", "temp3_input", "power1_average", "power1_input", "freq1_input", "freq2_input"):
+                    if os.path.exists(os.path.join(h, n)) and n not in self.files:
+                        self.files[n] = os.path.join(h, n)
+
+    def run(self, stop, acc):
+        while not stop.is_set():
+            for n, f in self.files.items():
+                try:
+                    t = open(f).read()
+                except OSError:
+                    continue
+                if n.startswith("pp_dpm"):
+                    cur = [l.strip() for l in t.splitlines() if "*" in l]
+                    v = cur[0] if cur else "?"
+                else:
+                    v = t.strip()
+                acc.setdefault(n, {}).setdefault(v, 0)
+                acc[n][v] += 1
+            time.sleep(0.002)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--sample-clocks", action="store_true", help="sample the card's clock levels / sensors from sysfs during every timing")
     ap.add_argument("--builds", type=int, default=4)
     ap.add_argument("--reads", type=int, default=16_000_000)
     ap.add_argument("--nodes", type=int, default=1_217_000_000)
@@ -45,16 +78,26 @@ def main():
         tree.classify(reads.bases, reads.off, reads.length, rc=False, total_bases=tot, max_len=150, out=res, workspace=ws)
         torch.cuda.synchronize()
         tree.kernel_time(reset=True)
+        acc, stop, th = {}, None, None
+        if args.sample_clocks:
+            import threading
+            stop = threading.Event()
+            th = threading.Thread(target=Sampler().run, args=(stop, acc), daemon=True)
+            th.start()
         t0 = time.time()
         for _ in range(args.reps):
             tree.classify(reads.bases, reads.off, reads.length, rc=False, total_bases=tot, max_len=150, out=res, workspace=ws)
         torch.cuda.synchronize()
         step_ms = 1e3 * (time.time() - t0) / args.reps
+        if th is not None:
+            stop.set()
+            th.join()
         k_ms, k_n = tree.kernel_time(reset=True)
         tree.poll()
         ptr = tree.image_ptr()[0]
         out["builds"].append({"build": b, "step_ms": step_ms, "kernel_ms": k_ms / max(1, k_n), "us_per_M_reads": 1e3 * k_ms / max(1, k_n) / (args.reads / 1e6),
-                              "image_ptr": hex(ptr), "workspace_ptr": hex(ws.data_ptr()), "image_ptr_mod_1GiB_MiB": (ptr % (1 << 30)) >> 20, "classified": int((res[:, 2] > 0).sum().item())})
+                              "image_ptr": hex(ptr), "workspace_ptr": hex(ws.data_ptr()), "image_ptr_mod_1GiB_MiB": (ptr % (1 << 30)) >> 20, "classified": int((res[:, 2] > 0).sum().item()),
+                              "sensors": {n: dict(sorted(v.items(), key=lambda kv: -kv[1])[:3]) for n, v in acc.items()}})
         print(json.dumps(out["builds"][-1]), file=sys.stderr, flush=True)
         if not args.same_image:
             tree.close()
