@@ -151,6 +151,7 @@ def main():
     # ---- database: rank 0 builds the image in HBM, the others receive it by ONE broadcast (RCCL / xGMI) ----
     t0 = time.time()
     bcast_s = 0.0
+    bcast_image_s = None
     bcast_how = ""
     sdb = None
     hd_dir = None
@@ -189,7 +190,8 @@ def main():
                 tree = t_c
                 if rank != 0:
                     ctr = c2
-                bcast_how = "one ncclBroadcast issued from C (utree_dev_replicate_rank)"
+                bcast_how = "ncclBroadcast in <= 1 GiB pieces issued from C (utree_dev_replicate_rank)"
+                bcast_image_s = DeviceTree.replicate_seconds()      # the image's pieces alone (bcast_s also holds ncclCommInitRank and the attach)
         if not use_c:
             image, m, bcast_s = udist.broadcast_image(tree.image_tensor()[:used] if rank == 0 else None, meta, 0, dev)
             if rank != 0:
@@ -291,6 +293,8 @@ def main():
             line["ranks"] = dist.get_world_size()
             line["gpus_arg"] = args.gpus
             line["bcast_s"] = bcast_s
+            line["bcast_image_s"] = bcast_image_s
+            line["rccl_forced_one_rank"] = bool(os.environ.get("UTREE_RCCL_FORCE")) and world == 1
             line["bcast"] = bcast_how
             line["scaling_note"] = ("value is the HBM-resident rate: every rank classifies its own batches, so it scales with the GPUs by construction (weak scaling, "
                                     "no data-path collective).  The file -> file rate (`e2e`) scales only while every rank writes its own output file; "

@@ -124,13 +124,32 @@ typedef struct {
 } utree_dev_info;
 int utree_dev_get_info(const utree_dev *dev, utree_dev_info *info);
 
-/* Replicate dev[0]'s image to the other devices with one ncclBroadcast (RCCL over xGMI) and attach it
- * there.  devices[0] must be dev0's device.  out[0] = dev0. */
+/* Replicate dev0's image to the other devices by ncclBroadcast (RCCL over xGMI; pieces of at most 1 GiB) and attach it
+ * there: what the reference's worker team gets by sharing one UTree in host memory (itree.c:1009-1018).  devices[0] must be
+ * dev0's device, no device twice.  out[0] = dev0; out[1..] own their replicas; on failure nothing is handed back.
+ * Rehearsal on one GPU: with UTREE_RCCL_FORCE=1 in the environment n_devices == 1 still builds the communicator and sends the
+ * image through ncclBroadcast into a second allocation on the same card, and out[0] is a NEW handle owning that replica
+ * (the caller still owns dev0). */
 int utree_dev_replicate(const utree_ctr *ctr, utree_dev *dev0, const int *devices, int n_devices, utree_dev **out);
+/* seconds the calling process's last utree_dev_replicate / utree_dev_replicate_rank spent between the first ncclBroadcast of
+ * the image and the drained streams (0 when it had nothing to send) */
+double utree_dev_replicate_seconds(void);
+/* What the command line does with n_devices > 1: utree_dev_replicate; if that fails, a warning on stderr and
+ * utree_dev_upload(ctr, devices[i], fine_bits) for every other device -- each GPU then reads the database from the host over
+ * PCIe.  *how (may be NULL) says which it was. */
+enum { UTREE_FANOUT_NONE = 0, UTREE_FANOUT_BROADCAST = 1, UTREE_FANOUT_UPLOAD = 2 };
+int utree_dev_fanout(const utree_ctr *ctr, utree_dev *dev0, const int *devices, int n_devices, int fine_bits, utree_dev **out, int *how);
+/* the same with the two steps passed in (utree_dev_fanout passes utree_dev_replicate and utree_dev_upload): the seam the
+ * fallback branch is tested through on a machine without a GPU */
+typedef int (*utree_replicate_fn)(const utree_ctr *, utree_dev *, const int *, int, utree_dev **);
+typedef int (*utree_upload_fn)(const utree_ctr *, int, int, utree_dev **);
+int utree_dev_fanout_with(const utree_ctr *ctr, utree_dev *dev0, const int *devices, int n_devices, int fine_bits, utree_dev **out, int *how,
+                          utree_replicate_fn replicate, utree_upload_fn upload);
 /* The same broadcast with one PROCESS per GPU: the root makes an id (utree_rccl_unique_id, UTREE_RCCL_ID_BYTES bytes) and hands
  * it to the other ranks over the launcher's control channel; every rank then calls utree_dev_replicate_rank with its own
  * device.  Root: dev0 = its image, *out = dev0.  Others: dev0 = NULL, `ctr` may describe the database (checked against the
- * image header) or be NULL; *out = a handle that owns the received copy. */
+ * image header) or be NULL; *out = a handle that owns the received copy.  UTREE_RCCL_FORCE=1: world == 1 runs the whole
+ * sequence on a communicator of one rank and *out owns a replica on the same card, as for utree_dev_replicate. */
 #define UTREE_RCCL_ID_BYTES 128
 int utree_rccl_unique_id(void *id_out, size_t cap);
 int utree_dev_replicate_rank(const utree_ctr *ctr, utree_dev *dev0, int device, int rank, int world, int root, const void *id_bytes,

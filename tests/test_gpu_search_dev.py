@@ -231,6 +231,93 @@ def test_replicate_rccl_over_all_visible_devices(torch_cuda, tmp_path):
         assert torch.equal(res, want), "replica on device %d differs" % g
 
 
+def test_rccl_on_a_communicator_of_one_rank(torch_cuda, tmp_path, monkeypatch):
+    """UTREE_RCCL_FORCE=1 (csrc/rccl_replicate.c): with one device / one rank the early returns are skipped, so ncclCommInitAll,
+    ncclCommInitRank, the 8-byte size broadcast and the image's ncclBroadcast pieces all execute on this lease's single card --
+    the image arrives in a second allocation, is attached like any received copy, and must answer like the one that was built:
+    the reference's golden lines through the whole-file search, and a batch's records."""
+    torch = torch_cuda
+    monkeypatch.setenv("UTREE_RCCL_FORCE", "1")
+    db = CtrDB.open(util.fixture_ctr("toy"))
+    t0 = DeviceTree.upload(db, 0)
+    # one process, all devices (the command line's shape): utree_dev_replicate
+    trees = DeviceTree.replicate(db, t0, [0])
+    assert len(trees) == 1 and trees[0] is not t0 and trees[0].image_ptr()[0] != t0.image_ptr()[0]
+    assert trees[0].image_ptr()[1] == t0.image_ptr()[1] and DeviceTree.replicate_seconds() > 0
+    # one process per GPU (bench.py's shape): utree_rccl_unique_id + utree_dev_replicate_rank
+    t_rank = DeviceTree.replicate_rank(db, t0, 0, 0, 1, 0, DeviceTree.rccl_unique_id())
+    assert t_rank is not t0 and t_rank.image_ptr()[0] not in (t0.image_ptr()[0], trees[0].image_ptr()[0])
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    for t in (trees[0], t_rank):
+        for rc in (False, True):
+            code, st, got = run(db, [t], data, tmp_path, rc=rc)
+            assert code == lib.OK and st.pipeline == 1
+            assert got == util.fixture_bytes("toy_out%s.txt.gz" % ("_rc" if rc else ""))
+    from utree_amd.search import frame_fasta
+    fr = frame_fasta(data)
+    buf = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    off, ln = torch.from_numpy(fr["seq_off"].astype(np.int64)).cuda(), torch.from_numpy(fr["seq_len"].astype(np.int32)).cuda()
+    want = t0.classify(buf, off, ln, rc=True).cpu()
+    for t in (trees[0], t_rank):
+        assert torch.equal(t.classify(buf, off, ln, rc=True).cpu(), want)
+        t.close()
+    # both handles of a forced two-"device" search on one card: the built image and its broadcast copy share the chunks
+    monkeypatch.setenv("UTREE_CHUNK_BYTES", "20000")
+    t2 = DeviceTree.replicate(db, t0, [0])[0]
+    code, st, got = run(db, [t0, t2], data, tmp_path, rc=True)
+    assert code == lib.OK and st.n_lanes >= 2 and got == util.fixture_bytes("toy_out_rc.txt.gz")
+    t2.close()
+    t0.close()
+
+
+def test_rccl_broadcast_in_pieces_of_a_gibibyte(torch_cuda, tmp_path, monkeypatch):
+    """An image beyond 1 GiB goes through ncclBroadcast in several pieces (the last one ragged); the copy is the image, byte for
+    byte, and classifies like it."""
+    torch = torch_cuda
+    from utree_amd import synth
+    monkeypatch.setenv("UTREE_RCCL_FORCE", "1")
+    sdb = synth.make_db(torch.device("cuda:0"), 120_000_000, W=8)
+    ptr, used = sdb.tree.image_ptr()
+    assert used > (2 << 30) + 4096, used
+    t2 = DeviceTree.replicate(sdb.ctr, sdb.tree, [0])[0]
+    p2, u2 = t2.image_ptr()
+    assert u2 == used and p2 != ptr
+
+    def view(p, n):
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (p, False), "version": 2}
+        return torch.as_tensor(_Raw(), device="cuda:0")
+    a, b = view(ptr, used), view(p2, used)
+    for lo in range(0, used, 1 << 28):
+        assert torch.equal(a[lo:lo + (1 << 28)], b[lo:lo + (1 << 28)]), "piece at %d differs" % lo
+    reads = synth.make_reads(sdb, 100_000, 150, seed=synth.READ_SEED + 5)
+    want = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=True).cpu()
+    assert torch.equal(t2.classify(reads.bases, reads.off, reads.length, rc=True).cpu(), want)
+    assert int((want[:, 2] > 0).sum()) > 90_000
+    print("broadcast of %.2f GiB on a one-rank communicator: %.4f s" % (used / 2**30, DeviceTree.replicate_seconds()))
+    t2.close()
+    sdb.tree.close()
+
+
+def test_cli_falls_back_to_uploads_when_the_broadcast_fails(torch_cuda, tmp_path):
+    """The command line with a broadcast that fails (UTREE_TEST_REPLICATE_FAIL under the one-rank rehearsal): a warning, every
+    GPU reads the tree from the host instead (SURVEY 8(e)'s fallback), same output, exit code 0 -- and without the failure the
+    same invocation reports the broadcast."""
+    import subprocess
+    fa, out = tmp_path / "r.fa", tmp_path / "o.txt"
+    fa.write_bytes(util.fixture_bytes("toy_reads.fa.gz"))
+    for fail in (0, 1):
+        env = dict(os.environ, UTREE_RCCL_FORCE="1", UTREE_GPUS="1")
+        if fail:
+            env["UTREE_TEST_REPLICATE_FAIL"] = "1"
+        p = subprocess.run([lib.CLI_PATH, util.fixture_ctr("toy"), str(fa), str(out), "4", "RC"], env=env, capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()
+        assert out.read_bytes() == util.fixture_bytes("toy_out_rc.txt.gz")
+        err = p.stderr.decode()
+        assert ("RCCL broadcast of the tree failed" in err) == bool(fail), err
+        assert ("replicated to 1 GPU(s) by RCCL broadcast" in err) == (not fail), err
+
+
 def test_output_that_cannot_seek_is_written_in_order(torch_cuda, tmp_path, monkeypatch):
     """`xtree-searchGG db reads.fa /dev/stdout | gzip`, a FIFO, process substitution: the reference writes with fprintf and works
     there; the device pipeline places chunks with pwrite, so on such an output it writes them in chunk order instead."""

@@ -294,3 +294,49 @@ def test_profile_entries_name_their_kernel_and_sources():
         assert key.startswith("nodes=") and ",k=" in key and ",rc=" in key
         assert "classify_" in e["kernel"] and len(e["kernel_source_sha256"]) == 64
         assert e["hbm_bytes_per_launch"] > 0 and e["avg_launch_ms"] > 0 and e["SQ_INSTS_VALU_per_launch"] > 0
+
+
+def test_fanout_falls_back_to_uploads_when_the_broadcast_fails(capfd):
+    """utree_dev_fanout (what the command line calls with more than one GPU): the RCCL broadcast, and when that
+    returns an error a warning and one utree_dev_upload per other device -- driven here, without a GPU, through the seam
+    utree_dev_fanout_with with the two steps passed in."""
+    L = lib.load()
+    n = 4
+    devs = (C.c_int * n)(0, 1, 2, 3)
+    calls = {"rep": 0, "up": []}
+    dev0 = C.c_void_p(0x1000)
+
+    def rep_fail(ctr, d0, devices, k, out):
+        calls["rep"] += 1
+        assert d0 == dev0.value and k == n and [devices[i] for i in range(k)] == [0, 1, 2, 3]
+        return lib.E_RCCL
+
+    def rep_ok(ctr, d0, devices, k, out):
+        calls["rep"] += 1
+        for i in range(1, k):
+            out[i] = 0x2000 + i
+        return lib.OK
+
+    def up(ctr, device, fine_bits, out):
+        calls["up"].append((device, fine_bits))
+        out[0] = 0x3000 + device
+        return lib.OK
+
+    out = (C.c_void_p * n)()
+    how = C.c_int(-1)
+    rc = L.utree_dev_fanout_with(None, dev0, devs, n, lib.FINE_AUTO, out, C.byref(how), C.cast(lib.REPLICATE_FN(rep_fail), C.c_void_p),
+                                 C.cast(lib.UPLOAD_FN(up), C.c_void_p))
+    assert rc == lib.OK and how.value == lib.FANOUT_UPLOAD and calls["rep"] == 1
+    assert calls["up"] == [(1, lib.FINE_AUTO), (2, lib.FINE_AUTO), (3, lib.FINE_AUTO)]
+    assert [out[i] for i in range(n)] == [0x1000, 0x3001, 0x3002, 0x3003]
+    assert "RCCL broadcast of the tree failed" in capfd.readouterr().err
+    calls["up"].clear()
+    rc = L.utree_dev_fanout_with(None, dev0, devs, n, lib.FINE_AUTO, out, C.byref(how), C.cast(lib.REPLICATE_FN(rep_ok), C.c_void_p),
+                                 C.cast(lib.UPLOAD_FN(up), C.c_void_p))
+    assert rc == lib.OK and how.value == lib.FANOUT_BROADCAST and calls["up"] == []
+    assert [out[i] for i in range(n)] == [0x1000, 0x2001, 0x2002, 0x2003]
+    assert "failed" not in capfd.readouterr().err
+    # a bad argument is not a transport failure: no fallback
+    rc = L.utree_dev_fanout_with(None, dev0, devs, n, lib.FINE_AUTO, out, C.byref(how),
+                                 C.cast(lib.REPLICATE_FN(lambda *a: lib.E_ARG), C.c_void_p), C.cast(lib.UPLOAD_FN(up), C.c_void_p))
+    assert rc == lib.E_ARG and calls["up"] == []

@@ -84,10 +84,12 @@ int main(int argc, char *argv[]) {
     printf("Read %llu nodes.\n", (unsigned long long)ci.n_nodes);                         /* itree.c:769 */
     if (ci.bin_total != ci.n_nodes)                                                       /* itree.c:792-793 */
         printf("Warning: detected nodes %u != %u\n", (unsigned)ci.bin_total, (unsigned)ci.n_nodes);
-    if (n_dev > 1) {
-        rc = utree_dev_replicate(ctr, devs[0], ids, n_dev, devs);
-        if (rc) { fprintf(stderr, "ERROR: RCCL broadcast of the tree: %s\n", utree_strerror(rc)); exit(3); }
-    }
+    utree_dev *built = devs[0];
+    int how = UTREE_FANOUT_NONE;
+    rc = utree_dev_fanout(ctr, built, ids, n_dev, UTREE_FINE_AUTO, devs, &how);           /* RCCL broadcast; on failure every GPU loads over PCIe */
+    if (rc) { fprintf(stderr, "ERROR: tree on %d GPUs: %s\n", n_dev, utree_strerror(rc)); exit(3); }
+    if (how == UTREE_FANOUT_BROADCAST)
+        fprintf(stderr, "[utree_amd] tree replicated to %d GPU(s) by RCCL broadcast in %.3f s\n", n_dev, utree_dev_replicate_seconds());
 #ifndef UTREE_RANK_SPECIFIC
     { int prc = utree_search_prepare(ctr, devs, n_dev, doRC);
       if (prc) fprintf(stderr, "[utree_amd] warning: the search buffers could not be allocated ahead (%s); the search allocates them itself\n", utree_strerror(prc)); }                                   /* the search's pinned / device buffers: part of "database resident" */
@@ -134,6 +136,7 @@ int main(int argc, char *argv[]) {
             st.seconds_total > 0 ? (double)st.n_reads / st.seconds_total : 0.0, st.seconds_kernels,
             st.pipeline ? " (lane-seconds; framing and formatting on the GPU)" : "");
     for (int i = n_dev - 1; i >= 0; --i) utree_dev_free(devs[i]);
+    if (devs[0] != built) utree_dev_free(built);                                          /* UTREE_RCCL_FORCE: devs[0] was a replica */
     utree_ctr_close(ctr);
     exit(0);
 }

@@ -20,6 +20,9 @@ _LIB = None
 OK, E_IO, E_FORMAT, E_UNSUPPORTED, E_NOMEM, E_HIP, E_ARG, E_NOLABELS, E_FASTA, E_RCCL, E_BUILD, E_DEVICE = range(12)
 BUILD_E_MAP_EMPTY, BUILD_E_MAP, BUILD_E_FASTA, BUILD_E_NO_KMERS, BUILD_E_NAME = range(1, 6)
 FINE_AUTO = -1
+FANOUT_NONE, FANOUT_BROADCAST, FANOUT_UPLOAD = range(3)
+REPLICATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p))
+UPLOAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p))
 INPUT_REFERENCE, INPUT_FASTQ, INPUT_FASTA_MULTILINE, INPUT_AUTO = range(4)
 
 
@@ -89,6 +92,10 @@ SYMBOLS = {
     "utree_dev_free": (None, [C.c_void_p]),
     "utree_dev_get_info": (C.c_int, [C.c_void_p, C.POINTER(DevInfo)]),
     "utree_dev_replicate": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "utree_dev_replicate_seconds": (C.c_double, []),
+    "utree_dev_fanout": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "utree_dev_fanout_with": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                        C.c_void_p, C.c_void_p]),
     "utree_rccl_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
     "utree_dev_replicate_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_void_p)]),

@@ -201,7 +201,23 @@ class DeviceTree:
         _lib.check(_lib.load().utree_dev_replicate_rank(db._h if db is not None else None, tree._h if tree is not None else None,
                                                         device, rank, world, root, uid, len(uid), C.byref(h)),
                    "utree_dev_replicate_rank")
-        return tree if tree is not None else cls(h.value, db)
+        if tree is not None and h.value == tree._h.value:
+            return tree
+        return cls(h.value, db if db is not None else (tree.db if tree is not None else None))   # a received copy (root: only under UTREE_RCCL_FORCE)
+
+    @classmethod
+    def replicate(cls, db: CtrDB, tree: "DeviceTree", devices) -> list:
+        """utree_dev_replicate: one process, the image broadcast to `devices` (devices[0] = the tree's own).  Returns the handles;
+        [0] is `tree` itself unless UTREE_RCCL_FORCE made it a replica on the same card."""
+        n = len(devices)
+        arr = (C.c_int * n)(*devices)
+        out = (C.c_void_p * n)()
+        _lib.check(_lib.load().utree_dev_replicate(db._h, tree._h, arr, n, out), "utree_dev_replicate")
+        return [tree if out[i] == tree._h.value else cls(out[i], db) for i in range(n)]
+
+    @staticmethod
+    def replicate_seconds() -> float:
+        return float(_lib.load().utree_dev_replicate_seconds())
 
     def image_tensor(self):
         """The flat image as a torch uint8 tensor view (for broadcast); only when torch owns the memory."""
