@@ -51,6 +51,8 @@ def test_150bp_reads_on_the_full_size_database(torch_cuda, W, nodes):
     sdb = synth.make_db(dev, nodes, W=W, keep_raw=True)
     n = 240_000
     reads = synth.make_reads(sdb, n, 150, seed=synth.READ_SEED + 77)
+    o = oracle_of(sdb)
+    host = reads.bases.cpu().numpy()
     for rc in (False, True):
         got = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
         again = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
@@ -63,16 +65,42 @@ def test_150bp_reads_on_the_full_size_database(torch_cuda, W, nodes):
             rcseq = comp[reads.bases.view(n, 150).long()].flip(1).contiguous().view(-1)
             other = sdb.tree.classify(rcseq, reads.off, reads.length, rc=True)
             assert torch.equal(got, other)
-        if not rc:
-            o = oracle_of(sdb)
-            host = reads.bases.cpu().numpy()
-            want = o.classify_batch(host, np.arange(n, dtype=np.uint64) * 150, np.full(n, 150, dtype=np.uint32), rc=False, threads=16)
-            hits, multi = assert_records_equal(got.cpu().numpy(), want, n)
-            assert hits > 0.9 * n and multi > 0.3 * n                                   # the sample exercises the vote
-            del o
+        # both strand modes against the oracle at the full database size
+        want = o.classify_batch(host, np.arange(n, dtype=np.uint64) * 150, np.full(n, 150, dtype=np.uint32), rc=rc, threads=16)
+        hits, multi = assert_records_equal(got.cpu().numpy(), want, n)
+        assert hits > 0.9 * n and multi > 0.3 * n                                       # the sample exercises the vote
+    del o
     perm = torch.randperm(n, device=dev)
     shuffled = sdb.tree.classify(reads.bases, reads.off[perm], reads.length[perm], rc=False)
     assert torch.equal(sdb.tree.classify(reads.bases, reads.off, reads.length, rc=False)[perm], shuffled)   # reads are independent
+    sdb.tree.close()
+
+
+@pytest.mark.parametrize("W,nodes", [(8, 150_000_000), (16, 100_000_000)], ids=["k32", "k64"])
+def test_the_automatic_choice_of_line_sized_buckets(torch_cuda, monkeypatch, W, nodes):
+    """Beyond 2.2 G 32-mer nodes (1.25 G 64-mer nodes) dev_image.c builds 128-byte buckets by itself (bucket_words_default).  The
+    threshold is lowered here (UTREE_BUCKET128_NODES) so that the AUTOMATIC branch -- no UTREE_BUCKET_BYTES -- is the one taken at a size the
+    suite can afford, and the image it builds is held to the oracle in both strand modes."""
+    torch = torch_cuda
+    monkeypatch.delenv("UTREE_BUCKET_BYTES", raising=False)
+    monkeypatch.setenv("UTREE_BUCKET128_NODES", str(nodes - 1))
+    sdb = synth.make_db(torch.device("cuda:0"), nodes, W=W, keep_raw=True)
+    assert sdb.tree.info.bucket_bytes == 128
+    monkeypatch.setenv("UTREE_BUCKET128_NODES", str(nodes))
+    small = synth.make_db(torch.device("cuda:0"), 2_000_000, W=W)
+    assert small.tree.info.bucket_bytes == 64                                           # at or below the threshold: 64-byte buckets
+    small.tree.close()
+    n = 120_000
+    reads = synth.make_reads(sdb, n, 150, seed=synth.READ_SEED + 78)
+    o = oracle_of(sdb)
+    host = reads.bases.cpu().numpy()
+    for rc in (False, True):
+        got = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
+        want = o.classify_batch(host, np.arange(n, dtype=np.uint64) * 150, np.full(n, 150, dtype=np.uint32), rc=rc, threads=16)
+        hits, multi = assert_records_equal(got.cpu().numpy(), want, n)
+        assert hits > 0.9 * n and multi > 0.3 * n
+    assert ", 2>" in sdb.tree.kernel_name() and sdb.tree.kernel_name().startswith("classify_lanes_k<%d, 2, 1," % W), sdb.tree.kernel_name()
+    sdb.tree.poll()
     sdb.tree.close()
 
 

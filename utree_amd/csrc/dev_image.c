@@ -53,7 +53,9 @@ static uint32_t bucket_words_default(uint64_t n_nodes, uint32_t W) {
     const char *e = getenv("UTREE_BUCKET_BYTES");
     if (e && atoi(e) == 128) return 16u;
     if (e && atoi(e) == 64) return 8u;
-    return n_nodes > (W == 16 ? 1250000000ull : 2200000000ull) ? 16u : 8u;
+    const char *t = getenv("UTREE_BUCKET128_NODES");                    /* test hook: the size from which the automatic choice is 128 bytes */
+    const uint64_t from = t && atoll(t) > 0 ? (uint64_t)atoll(t) : (W == 16 ? 1250000000ull : 2200000000ull);
+    return n_nodes > from ? 16u : 8u;
 }
 
 /* Buckets per hash region (utree_image_header.regions) for a tree of N nodes: a node's minimizer hash is the smallest of m = K-15
