@@ -80,7 +80,7 @@ int utree_ctr_get_info(const utree_ctr *ctr, utree_ctr_info *info);
 const char *utree_ctr_label(const utree_ctr *ctr, uint32_t ix, uint32_t *len);
 
 /* ------------------------------------------------------------------------------------------------
- * Device image: one flat HBM allocation holding the table of 64-byte buckets addressed by minimizer hash, the
+ * Device image: one flat HBM allocation holding the table of 64-byte buckets addressed by (canonical) minimizer hash and orientation, the
  * 8-byte-aligned records, the labels in strcmp order and the rank tables (layout: DESIGN.md §3).  It replaces UTree.Dump / UTree.BinIx
  * (itree.c:140-141) as seen by XT_getIX32.  Because it is flat and position independent, ONE RCCL
  * broadcast replicates a database to the other GPUs of a node.
@@ -120,7 +120,9 @@ typedef struct {
                                    wave-per-read kernels: k = 64 with 32-bit labels, many irregular bins)   */
     uint32_t bucket_bytes;      /* 64 (default) or 128 (UTREE_BUCKET_BYTES=128 when the image is built: a third
                                    less HBM, classify kernels 5-10 % slower)                               */
-    uint32_t reserved;
+    uint32_t strand_views;      /* 1: the image stores every k-mer under its mirrored minimizer view too (where that differs), so a
+                                   search with RC finds a window and its reverse complement in ONE pass over the read: both are
+                                   in the two buckets of one pair                     */
 } utree_dev_info;
 int utree_dev_get_info(const utree_dev *dev, utree_dev_info *info);
 

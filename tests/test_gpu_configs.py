@@ -99,7 +99,7 @@ def test_the_automatic_choice_of_line_sized_buckets(torch_cuda, monkeypatch, W, 
         want = o.classify_batch(host, np.arange(n, dtype=np.uint64) * 150, np.full(n, 150, dtype=np.uint32), rc=rc, threads=16)
         hits, multi = assert_records_equal(got.cpu().numpy(), want, n)
         assert hits > 0.9 * n and multi > 0.3 * n
-    assert ", 2>" in sdb.tree.kernel_name() and sdb.tree.kernel_name().startswith("classify_lanes_k<%d, 2, 1," % W), sdb.tree.kernel_name()
+    assert ", 2, " in sdb.tree.kernel_name() and sdb.tree.kernel_name().startswith("classify_lanes_k<%d, 2, 1," % W), sdb.tree.kernel_name()
     sdb.tree.poll()
     sdb.tree.close()
 

@@ -357,9 +357,122 @@ def test_line_sized_buckets_option(torch_cuda, name, rc, tmp_path, monkeypatch):
             assert classify_fasta_bytes(db, tree, data, rc=bool(rc)) == want
         assert classify_fasta_bytes(db, tree, more, rc=bool(rc)) == oracle_text(o, more, tmp_path, rc=bool(rc))
         if lane_pass == "1":
-            assert tree.kernel_name().startswith("classify_lanes_k<") and tree.kernel_name().endswith(", 2>")
+            assert tree.kernel_name().startswith("classify_lanes_k<") and tree.kernel_name().endswith(", 2, false>")
     tree.close()
     monkeypatch.delenv("UTREE_BUCKET_BYTES")
     t64 = DeviceTree.upload(db, 0)
     assert t64.info.bucket_bytes == 64 and t64.info.image_bytes != 0
     t64.close()
+
+
+def _rc16(x):
+    r = 0
+    for j in range(16):
+        r = (r << 2) | (3 - ((x >> (2 * j)) & 3))
+    return r
+
+
+def _mix32(x):
+    x = (x * 0x9E3779B1) & 0xFFFFFFFF
+    x ^= x >> 15
+    return (x * 0x85EBCA6B) & 0xFFFFFFFF
+
+
+def _mer(x):
+    return "".join("ACGT"[(x >> (30 - 2 * j)) & 3] for j in range(16))
+
+
+@pytest.mark.parametrize("k", [32, 64])
+def test_kmers_whose_two_minimizer_views_differ(torch_cuda, k, tmp_path, monkeypatch):
+    """Image version 11 finds the reverse complement of a window from the window's own minimizer run: under the MIRRORED view of the
+    database k-mer (device_common.hpp).  That view differs from the k-mer's own when two of its 16-mers tie in the 23 bits they are ranked
+    by, when the minimizer occurs twice (tandem repeats), or when it is its own reverse complement -- such k-mers are stored twice.  A
+    database made of exactly those, reads in both orientations, both strand modes, both kernel families and the one-pass / two-pass
+    lane kernels: the oracle's lines every time."""
+    rng = np.random.default_rng(100 + k)
+    rs = lambda n: "".join("ACGT"[int(c)] for c in rng.integers(0, 4, n))
+    comp = str.maketrans("ACGT", "TGCA")
+    kmers = set()
+    # (a) palindromic 16-mers with the smallest hashes: the minimizer wherever they occur
+    pals = []
+    for half in rng.integers(0, 1 << 16, 30000):
+        x = int(half) << 16
+        x |= _rc16(x) & 0xFFFF                                                         # second half = reverse complement of the first
+        assert _rc16(x) == x
+        pals.append(x)
+    pals = sorted(set(pals), key=_mix32)[:6]
+    for m in pals:
+        for _ in range(40):
+            p = int(rng.integers(0, k - 15))
+            s = rs(k)
+            kmers.add(s[:p] + _mer(m) + s[p + 16:])
+    # (b) two different 16-mers that tie in the top 23 bits of their (tiny) canonical hashes, both in one k-mer
+    cand = [int(c) for c in rng.integers(0, 1 << 32, 3_000_000, dtype=np.uint64)]
+    tiny = {}
+    for c in cand:
+        h = _mix32(min(c, _rc16(c)))
+        if h < (1 << 18):
+            tiny.setdefault(h >> 9, []).append(c)
+    pairs = [v[:2] for v in tiny.values() if len(v) >= 2 and min(v[0], _rc16(v[0])) != min(v[1], _rc16(v[1]))][:8]
+    assert len(pairs) >= 4
+    for a, b in pairs:
+        for _ in range(30):
+            s = rs(k)
+            pa = int(rng.integers(0, k - 31))
+            pb = int(rng.integers(pa + 16, k - 15))
+            ma = _mer(a) if rng.integers(0, 2) else _mer(_rc16(a))
+            mb = _mer(b) if rng.integers(0, 2) else _mer(_rc16(b))
+            s = s[:pa] + ma + s[pa + 16:]
+            kmers.add(s[:pb] + mb + s[pb + 16:])
+    # (c) tandem repeats: the same 16-mer at several positions of a k-mer
+    for period in (1, 2, 3, 4, 5, 7, 8, 11, 16):
+        for _ in range(25):
+            unit = rs(period)
+            s = (unit * (k // period + 2))[:k]
+            kmers.add(s)
+            kmers.add(rs(3) + s[:k - 6] + rs(3))
+    # (d) k-mers that hold a 16-mer AND its reverse complement (inverted repeats)
+    for _ in range(60):
+        m = rs(16)
+        s = rs(k)
+        pa = int(rng.integers(0, k - 31)); pb = int(rng.integers(pa + 16, k - 15))
+        s = s[:pa] + m + s[pa + 16:]
+        kmers.add(s[:pb] + m.translate(comp)[::-1] + s[pb + 16:])
+    kmers |= {rs(k) for _ in range(3000)}                                             # ... and ordinary ones
+    kmers = sorted(kmers)
+    hi, lo = ctrfile.encode_kmers(kmers)
+    labels = ["k__A;p__B;c__L%d" % i for i in range(12)]
+    ix = rng.integers(0, 12, len(kmers)).astype(np.uint32)
+    order = np.lexsort((lo, hi))
+    ctr = str(tmp_path / ("views%d.ctr" % k))
+    ctrfile.write_ctr(ctr, k // 4, 2, hi[order], lo[order], ix[order], labels)
+    db = CtrDB.open(ctr)
+    o = orc.OracleDB.load(ctr)
+    reads = []
+    for i, s in enumerate(kmers):
+        t = rs(int(rng.integers(0, 40))) + s + rs(int(rng.integers(0, 40)))
+        reads.append(("r%d" % i, t if i % 2 else t.translate(comp)[::-1]))
+    reads += [("j%d" % i, "".join(kmers[int(a)] if rng.integers(0, 2) else kmers[int(a)].translate(comp)[::-1] for a in rng.integers(0, len(kmers), 2)))
+              for i in range(600)]
+    data = fasta_bytes(reads)
+    want = {rc: oracle_text(o, data, tmp_path, rc=rc) for rc in (False, True)}
+    assert want[True].count(b"\n") >= len(kmers)
+    tree = DeviceTree.upload(db, 0)
+    assert tree.info.strand_views == 1
+    for lane_pass, bs in (("1", "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("UTREE_LANE_PASS", lane_pass)
+        monkeypatch.setenv("UTREE_LANES_BS", bs)
+        for rc in (False, True):
+            assert classify_fasta_bytes(db, tree, data, rc=rc) == want[rc], (lane_pass, bs, rc)
+            if lane_pass == "1":
+                assert tree.kernel_name().endswith(", 1, %s>" % ("true" if rc and bs == "1" else "false")), tree.kernel_name()
+    tree.close()
+    # without room for the second views the image says so, and both strands are walked as two sequences: same lines
+    monkeypatch.setenv("UTREE_DUP_CAP", "3")
+    monkeypatch.setenv("UTREE_LANE_PASS", "1")
+    monkeypatch.setenv("UTREE_LANES_BS", "1")
+    t2 = DeviceTree.upload(db, 0)
+    assert t2.info.strand_views == 0
+    assert classify_fasta_bytes(db, t2, data, rc=True) == want[True]
+    assert t2.kernel_name().endswith(", 1, false>")
+    t2.close()

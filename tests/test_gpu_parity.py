@@ -366,17 +366,21 @@ def test_overflowing_buckets(torch_cuda, tmp_path, run_max, monkeypatch):
     flagged and searched with the reference's probe sequence, and the database still loads and answers like the oracle."""
     if run_max:
         monkeypatch.setenv("UTREE_BUCKET_RUN_MAX", str(run_max))
-    def mix32(x):
-        x = np.uint32(x)
-        with np.errstate(over="ignore"):
-            x *= np.uint32(0x9E3779B1); x ^= x >> np.uint32(15); x *= np.uint32(0x85EBCA6B)
-        return int(x)
+    def rc16(x):                                                      # reverse complement of 16-mers packed first base first (A=0 .. T=3)
+        x = x.astype(np.uint32)
+        r = np.zeros_like(x)
+        for j in range(16):
+            r = (r << np.uint32(2)) | (np.uint32(3) - ((x >> np.uint32(2 * j)) & np.uint32(3)))
+        return r
     rng = np.random.default_rng(5)
     cand = rng.integers(0, 1 << 32, 6_000_000, dtype=np.uint64).astype(np.uint32)
+    canon = np.minimum(cand, rc16(cand))                              # image version 11: a 16-mer is ranked by the hash of its canonical form
     with np.errstate(over="ignore"):
-        h = cand.copy(); h *= np.uint32(0x9E3779B1); h ^= h >> np.uint32(15); h *= np.uint32(0x85EBCA6B)
-    minis = [int(c) for c in cand[np.argsort(h)[:3]]]                 # three 16-mers with tiny hashes: minimizers wherever they occur
-    assert all(mix32(m) < 5000 for m in minis)
+        h = canon.copy(); h *= np.uint32(0x9E3779B1); h ^= h >> np.uint32(15); h *= np.uint32(0x85EBCA6B)
+    best = np.argsort(h)[:3]
+    assert all(int(h[b]) < 5000 for b in best)
+    # three 16-mers with tiny hashes: minimizers wherever they occur; one as its canonical form, one reverse-complemented, one as drawn
+    minis = [int(canon[best[0]]), int(rc16(canon[best[1]:best[1] + 1])[0]), int(cand[best[2]])]
     for W in (8, 16):
         k = 4 * W
         kmers = set()
@@ -406,6 +410,13 @@ def test_overflowing_buckets(torch_cuda, tmp_path, run_max, monkeypatch):
         code, nr, good, err = o.search_file(str(fa), str(out), threads=4, rc=False)
         assert code == 0 and good >= len(kmers)
         assert classify_fasta_bytes(db, tree, data, rc=False) == out.read_bytes()
+        # both strands (one pass over canonical minimizer runs: the overflow runs of BOTH buckets of a pair), reads given as reverse complements too
+        comp = str.maketrans("ACGT", "TGCA")
+        data2 = "".join(">%s\n%s\n" % (n, sq if i % 2 else sq.translate(comp)[::-1]) for i, (n, sq) in enumerate(reads)).encode()
+        fa.write_bytes(data2)
+        code, nr, good2, err = o.search_file(str(fa), str(out), threads=4, rc=True)
+        assert code == 0 and good2 >= len(kmers)
+        assert classify_fasta_bytes(db, tree, data2, rc=True) == out.read_bytes()
         tree.close()
 
 

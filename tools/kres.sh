@@ -14,6 +14,6 @@ for ln in sys.stdin:
     elif cur is not None: cur[k]=v
 for r in rows:
     n=subprocess.run(["c++filt",r["name"]],capture_output=True,text=True).stdout.strip()
-    n=re.sub(r"\(.*","",n).replace("(anonymous namespace)::","")
+    n=re.sub(r"\(.*","",n.replace("(anonymous namespace)::",""))
     print("%-60s VGPR %3s AGPR %3s SGPR %3s spill %s/%s scratch %s occ %s LDS %s" % (n.replace("void ","")[:60], r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("VGPRs Spill","?"), r.get("SGPRs Spill","?"), r.get("ScratchSize [bytes/lane]"), r.get("Occupancy [waves/SIMD]"), r.get("LDS Size [bytes/block]")))
 '

@@ -71,18 +71,30 @@ static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32
     const uint32_t cap_entries = bucket_words / utree_rec_words(W, I);
     const char *te = getenv("UTREE_BUCKET_TARGET");                     /* nodes per bucket; experiments only */
     const double target = te && atof(te) > 0 ? atof(te) : (bucket_words == 16 ? 0.5625 : 0.375) * cap_entries;
+    /* (image version 11: the region table counts PAIRS of buckets -- the two orientations of a canonical 16-mer --, a pair is sized for
+     * 2 TARGET nodes.  Only half of the hash values are some canonical 16-mer's, so where a pair is one hash value -- the dense end of the
+     * range -- every other pair is empty: config 2's table grows by a third; the lookups pay nothing for it) */
     const uint64_t nb_max = 1ull << (16 + (F > 8 ? 8 : F)), nb_min = 1ull << 16;
     uint64_t base = 0;
     for (int r = 0; r < 256; ++r) {
         const double expect = (double)n_nodes * (pow(1.0 - r / 256.0, m) - pow(1.0 - (r + 1) / 256.0, m));
-        double want = ceil(expect / target);
+        double want = ceil(expect / (2.0 * target));
         uint64_t nb = want >= (double)nb_max ? nb_max : (uint64_t)want;
         if (nb < nb_min) nb = nb_min;
         if (nb > nb_max) nb = nb_max;
         if (regions) regions[r] = (base << UTREE_REGION_NB_BITS) | nb;
         base += nb;
     }
-    return base;
+    return 2 * base;
+}
+
+/* MIN records beyond one per node the build area holds: the second views of k-mers whose two views differ (ties in the 23-bit rank,
+ * palindromic minimizers: a few in a million on random sequence, a few per cent in repeats).  A database with more gets none and its
+ * image does not carry UTREE_F_STRAND_VIEWS (the lane pass then walks the reverse strand as a second sequence). */
+static uint64_t dup_capacity(uint64_t n_nodes) {
+    const char *e = getenv("UTREE_DUP_CAP");                            /* test hook */
+    if (e && atoll(e) >= 0) return (uint64_t)atoll(e);
+    return n_nodes / 8 + 65536;
 }
 
 int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
@@ -91,7 +103,7 @@ int utree_pick_fine_bits(const utree_ctr *ctr, int fine_bits) {
     if (fine_bits == UTREE_FINE_AUTO) {
         /* as fine as the density asks, within a memory cap for the table */
         const char *cap_env = getenv("UTREE_TABLE_MAX_GB");
-        double cap = (cap_env && atof(cap_env) > 0 ? atof(cap_env) : 48.0) * 1073741824.0;
+        double cap = (cap_env && atof(cap_env) > 0 ? atof(cap_env) : 96.0) * 1073741824.0;
         int F = 8;
         const uint32_t bw = bucket_words_default(ctr->info.n_nodes, ctr->info.W);
         while (F > 0 && (double)compute_regions(ctr->info.n_nodes, ctr->info.W, ctr->info.I, bw, (uint32_t)F, NULL) * 8.0 * bw > cap) --F;
@@ -114,7 +126,7 @@ static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     h->n_slots = compute_regions(h->n_nodes, h->W, h->I, h->bucket_words, F, h->regions);
     uint64_t off = UTREE_IMG_HEADER_BYTES;
     h->off_table = off; off = align_up(off + h->n_slots * 8 * h->bucket_words, 4096);
-    h->off_mrecs = off; off = align_up(off + (h->n_nodes + 8) * h->rec_words * 8, 4096);
+    h->off_mrecs = off; off = align_up(off + (h->n_nodes + dup_capacity(h->n_nodes) + 8) * h->rec_words * 8, 4096);
     h->off_coarse = off; off = align_up(off + (uint64_t)UTREE_NUMBINS * ((h->flags & UTREE_F_OFF64) ? 8 : 4), 256);
     h->off_irreg = off; off = align_up(off + (1u << 24) / 8, 256);
     h->off_label_off = off; off = align_up(off + ((uint64_t)h->n_labels + 1) * 4, 256);
@@ -371,9 +383,16 @@ static int build_finish(builder *b, const void *d_binix_raw) {
         d->hdr.n_min = cN - c0;
         HIPCHK(hipMemsetAsync(b->d_counters, 0, 16, st));
         HIPCHK(hipMemcpyAsync(img, &d->hdr, sizeof d->hdr, hipMemcpyHostToDevice, st));   /* the kernels read the region table there */
-        KCHK(utk_build_min(d->hdr.W, d->hdr.I, off64, coarse, recs, c0, d->hdr.n_min, (const uint64_t *)(img + offsetof(utree_image_header, regions)),
-                           d->hdr.regions, d->hdr.n_slots, d->hdr.bucket_words, (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs),
-                           (uint32_t *)(img + d->hdr.off_irreg), b->d_counters, st));
+        {
+            uint64_t n_min = 0;
+            int views = 0;
+            KCHK(utk_build_min(d->hdr.W, d->hdr.I, off64, coarse, recs, c0, d->hdr.n_min, dup_capacity(d->hdr.n_nodes), (const uint64_t *)(img + offsetof(utree_image_header, regions)),
+                               d->hdr.regions, d->hdr.n_slots, d->hdr.bucket_words, (uint64_t *)(img + d->hdr.off_table), (uint64_t *)(img + d->hdr.off_mrecs),
+                               (uint32_t *)(img + d->hdr.off_irreg), b->d_counters, &n_min, &views, st));
+            if (timing_on()) fprintf(stderr, "[utree_amd] image: %llu records for %llu nodes (second views%s)\n", (unsigned long long)n_min, (unsigned long long)d->hdr.n_min, views ? "" : ": too many, none stored");
+            d->hdr.n_min = n_min;
+            if (views) d->hdr.flags |= UTREE_F_STRAND_VIEWS;
+        }
         KCHK(utk_fill_recs_pad((uint64_t *)(img + d->hdr.off_mrecs) + d->hdr.n_min * d->hdr.rec_words, 8 * d->hdr.rec_words, st));
         HIPCHK(hipMemcpyAsync(counters, b->d_counters, 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -582,6 +601,7 @@ int utree_dev_get_info(const utree_dev *d, utree_dev_info *info) {
     info->vote_table = d->kimg.vote_tab != NULL;
     info->lane_pass = utk_lanes_image_ok(&d->kimg) != 0;
     info->bucket_bytes = 8u * d->hdr.bucket_words;
+    info->strand_views = (d->hdr.flags & UTREE_F_STRAND_VIEWS) ? 1u : 0u;
     return UTREE_OK;
 }
 
@@ -797,7 +817,6 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
         /* (the classes' launches go one after the other on `stream`: forked onto side streams with events they were 3-5 % slower,
          * profiles/r03/mixed_batches*.json) */
         else KCHK(utk_classify_lanes_mixed(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
-        if (e0 && !w.long_blocks) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
         if (w.long_blocks) {
             if (e0) HIPCHK(hipEventRecord(e0, st));
             HIPCHK(hipMemsetAsync(w.ltab_rank, 0xFF, (size_t)w.n_long_cap * UTREE_LONG_SLOTS * 4, st));
@@ -811,6 +830,9 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
             if (e0) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
         }
         KCHK(utk_classify_listed(&d->kimg, d_bases, d_off, d_len, n_reads, max_len, do_rc, d_out, &w, d->n_cu, st));
+        /* (the bracket of a batch without long reads ends behind the pass over what the lane pass left: on a workload that leaves many reads over
+         * that pass is part of the dominant work) */
+        if (e0 && !w.long_blocks) { HIPCHK(hipEventRecord(e1, st)); d->recorded[tslot] = 1; }
     } else {
         /* ---- the wave-per-read kernels: images the lane-per-read pass does not take (k = 64 with u32 labels, many irregular bins, a
          * non-monotone bin table), and batches it is not worth running on ---- */
@@ -864,12 +886,13 @@ const char *utree_classify_kernel_name(const utree_dev *dc) {
     if (!dc) return "";
     utree_dev *d = (utree_dev *)dc;                       /* the signature string lives in the handle */
     if (d->last_lanes && d->last_pieces) {
-        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, 16, %s, 2, %u>", d->hdr.W, d->hdr.I, d->kimg.irr_n ? "true" : "false", d->hdr.bucket_words / 8);
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, 16, %s, 2, %u, %s>", d->hdr.W, d->hdr.I, d->kimg.irr_n ? "true" : "false", d->hdr.bucket_words / 8,
+                 utk_lanes_both_strands(&d->kimg, d->last_rc) ? "true" : "false");
         return d->kernel_sig;
     }
     if (d->last_lanes) {      /* (a mixed batch: the instantiation its longest read takes) */
-        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, %d, %s, %d, %u>", d->hdr.W, d->hdr.I, d->last_lanes, d->kimg.irr_n ? "true" : "false",
-                 d->last_mixed ? 1 : 0, d->hdr.bucket_words / 8);
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, %d, %s, %d, %u, %s>", d->hdr.W, d->hdr.I, d->last_lanes, d->kimg.irr_n ? "true" : "false",
+                 d->last_mixed ? 1 : 0, d->hdr.bucket_words / 8, utk_lanes_both_strands(&d->kimg, d->last_rc) ? "true" : "false");
         return d->kernel_sig;
     }
     return d->last_long ? utk_classify_long_name(&d->kimg, d->kernel_sig, sizeof d->kernel_sig)

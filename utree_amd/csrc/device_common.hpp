@@ -116,9 +116,18 @@ template <int W, int I> __device__ uint32_t exact_probe(const uint64_t *recs, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// Minimizers.  m = 16 bases (32 bits); the minimizer of a k-mer is its 16-mer with the smallest mix32() >> MIN_LOW_BITS
-// (leftmost on ties).  mix32 is a bijection on 32 bits, so a table slot of B <= 32 hash bits plus the
-// remaining 32-B bits identify the minimizer exactly, and {position, the other k-16 bases} the k-mer.
+// Minimizers.  m = 16 bases (32 bits).  Since image version 11 the order among a k-mer's 16-mers is CANONICAL: a 16-mer is ranked by
+// mix32(the smaller of itself and its reverse complement) >> MIN_LOW_BITS, so a k-mer and its reverse complement choose the same
+// double-stranded 16-mer, and the minimizer of a k-mer is the LEFTMOST 16-mer of the smallest rank ("view f").  mix32 is a bijection on
+// 32 bits, so the hash h of the canonical 16-mer plus one ORIENTATION bit o (1: the k-mer holds the reverse complement of the canonical
+// 16-mer) identify the minimizer exactly, and {position, the other k-16 bases} the k-mer.  The table is made of PAIRS of buckets: pair =
+// what the hash addresses, bucket = 2 * pair + o -- the two orientations of one canonical 16-mer are the two halves of one (or two
+// adjacent) HBM line(s), so that ONE fetch serves a read's window (in bucket o) and the reverse complement of that window (itree.c:891-898
+// walks it as a second sequence) in bucket 1 - o: see lanes_core.hpp, BS.
+// The reverse complement of a window w with view f(w) = (h, o, pos) is looked for under the MIRRORED view (h, 1 - o, K-16-pos): that is the
+// view "g" of the k-mer x = rc(w) -- its RIGHTMOST 16-mer of the smallest rank, with o = 1 also when the 16-mer is its own reverse
+// complement.  g(x) differs from f(x) only when two 16-mers of x tie in the 23 bits of the rank or the minimizer is a palindrome; such
+// k-mers are stored under both views (image_build.hip: assign_k), and a lookup finds exactly one of them.
 // ------------------------------------------------------------------------------------------------
 // Multiply, fold the high half down, multiply: four instructions (the search kernels hash every 16-mer of every read) against the
 // eight of the murmur3 finaliser the images up to version 7 used; the bits that matter -- the top ones: order and bucket -- mix as
@@ -126,6 +135,18 @@ template <int W, int I> __device__ uint32_t exact_probe(const uint64_t *recs, ui
 __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA6Bu;
     return x;
+}
+// reverse complement of a 16-mer (first base in the top two bits; A=0 C=1 G=2 T=3: the complement is code ^ 3): v_bfrev, the two bits of
+// every base swapped back, all bits flipped
+__host__ __device__ __forceinline__ uint32_t rc16(uint32_t m) {
+    const uint32_t y = __builtin_bitreverse32(m);
+    return ~(((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1));
+}
+// hash of a 16-mer's canonical form and the orientation bit (0 also for a 16-mer that is its own reverse complement)
+__host__ __device__ __forceinline__ uint32_t canon_hash(uint32_t m, uint32_t &o) {
+    const uint32_t r = rc16(m);
+    o = m > r ? 1u : 0u;
+    return mix32(m > r ? r : m);
 }
 // 16-mers are ordered by their hash WITHOUT its MIN_LOW_BITS low bits (leftmost on ties): the search kernels then fit
 // { hash bits | position in the tile } into 32 bits and slide the minimum with one v_min_u32 per step.  The bucket is still
@@ -164,57 +185,60 @@ template <int W> __device__ __forceinline__ void min_rest(uint64_t khi, uint64_t
     }
 }
 
-// Minimizer of the word khi:klo by direct evaluation (load time; the search kernels get the same (h, pos)
-// from a sliding minimum over per-position hashes shared by the lanes of a wave).
-template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_t klo, uint32_t &h, uint32_t &pos,
-                                                          uint32_t &rest_hi32, uint64_t &rest_lo) {
-    if constexpr (W == 8) {
-        uint32_t best = mix32((uint32_t)(klo >> 32)), bj = 0;
-#pragma unroll
-        for (uint32_t j = 1; j <= 16; ++j) {
-            const uint32_t hh = mix32((uint32_t)(klo >> (32 - 2 * j)));
-            if ((hh >> MIN_LOW_BITS) < (best >> MIN_LOW_BITS)) { best = hh; bj = j; }
-        }
-        h = best; pos = bj;
-    } else {
-        const unsigned __int128 w = ((unsigned __int128)khi << 64) | klo;
-        uint32_t best = mix32((uint32_t)(w >> 96)), bj = 0;
-        for (uint32_t j = 1; j <= 48; ++j) {
-            const uint32_t hh = mix32((uint32_t)(w >> (96 - 2 * j)));
-            if ((hh >> MIN_LOW_BITS) < (best >> MIN_LOW_BITS)) { best = hh; bj = j; }
-        }
-        h = best; pos = bj;
+// 16-mer j of the word khi:klo
+template <int W> __device__ __forceinline__ uint32_t mer_at(uint64_t khi, uint64_t klo, uint32_t j) {
+    if constexpr (W == 8) return (uint32_t)(klo >> (32 - 2 * j));
+    else { const unsigned __int128 w = ((unsigned __int128)khi << 64) | klo; return (uint32_t)(w >> (96 - 2 * j)); }
+}
+// Both views of the word khi:klo by direct evaluation (load time; the search kernels get view f from a sliding minimum over
+// per-position hashes shared by the lanes of a wave): f = leftmost 16-mer of the smallest rank, g = rightmost, o_g = 1 for a palindrome.
+template <int W> __device__ __forceinline__ void minimizer_views(uint64_t khi, uint64_t klo, uint32_t &hf, uint32_t &of, uint32_t &pf,
+                                                                uint32_t &hg, uint32_t &og, uint32_t &pg) {
+    uint32_t best = 0xFFFFFFFFu;
+    hf = hg = of = og = pf = pg = 0;
+    for (uint32_t j = 0; j <= 4u * W - 16u; ++j) {
+        const uint32_t m = mer_at<W>(khi, klo, j), r = rc16(m);
+        const uint32_t hh = mix32(m > r ? r : m), key = hh >> MIN_LOW_BITS;
+        if (j == 0 || key < best) { best = key; hf = hh; of = m > r ? 1u : 0u; pf = j; }
+        if (j == 0 || key <= best) { hg = hh; og = m >= r ? 1u : 0u; pg = j; }
     }
+}
+// view f alone
+template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_t klo, uint32_t &h, uint32_t &o, uint32_t &pos,
+                                                          uint32_t &rest_hi32, uint64_t &rest_lo) {
+    uint32_t hg, og, pg;
+    minimizer_views<W>(khi, klo, h, o, pos, hg, og, pg);
     min_rest<W>(khi, klo, pos, rest_hi32, rest_lo);
 }
 
-// Bucket of a minimizer hash and the hash bits the bucket does not imply (utree_image_header.regions): region r = the hash's top 8
-// bits has nb_r buckets (any number from 2^16 to 2^24) over its 2^24 hash values, bucket = base_r + ((h24 * nb_r) >> 24) -- one
-// multiply-high of (h << 8) --, so that a bucket spans at most 256 consecutive hash values and the hash's low 8 bits tell them apart.
+// Bucket of a minimizer (hash of the canonical 16-mer, orientation) and the hash bits the bucket does not imply (utree_image_header.regions):
+// region r = the hash's top 8 bits has nb_r PAIRS of buckets (any number from 2^16 to 2^24) over its 2^24 hash values, pair = base_r +
+// ((h24 * nb_r) >> 24) -- one multiply-high of (h << 8) --, so that a pair spans at most 256 consecutive hash values and the hash's low 8
+// bits tell them apart; bucket = 2 * pair + o.
 __host__ __device__ __forceinline__ uint32_t bucket_in_region(uint32_t h, uint32_t nb) {
     return (uint32_t)(((uint64_t)(h << 8) * nb) >> 32);
 }
-__host__ __device__ __forceinline__ void bucket_of(const uint64_t *__restrict__ regions, uint32_t h, uint64_t &bucket, uint32_t &hlow) {
+__host__ __device__ __forceinline__ void bucket_of(const uint64_t *__restrict__ regions, uint32_t h, uint32_t o, uint64_t &bucket, uint32_t &hlow) {
     const uint64_t e = regions[h >> 24];
-    bucket = (e >> UTREE_REGION_NB_BITS) + bucket_in_region(h, (uint32_t)e & ((1u << UTREE_REGION_NB_BITS) - 1u));
+    bucket = 2u * ((e >> UTREE_REGION_NB_BITS) + bucket_in_region(h, (uint32_t)e & ((1u << UTREE_REGION_NB_BITS) - 1u))) + o;
     hlow = h & 0xFFu;
 }
 
-// bucket and MIN key from (h, pos)
-template <int W> __device__ __forceinline__ void min_finish(uint64_t khi, uint64_t klo, uint32_t h, uint32_t pos,
+// bucket and MIN key from (h, o, pos)
+template <int W> __device__ __forceinline__ void min_finish(uint64_t khi, uint64_t klo, uint32_t h, uint32_t o, uint32_t pos,
                                                            const uint64_t *__restrict__ regions, uint64_t &bucket, MinKey<W> &mk) {
     uint32_t rh, hl; uint64_t rl;
     min_rest<W>(khi, klo, pos, rh, rl);
-    bucket_of(regions, h, bucket, hl);
+    bucket_of(regions, h, o, bucket, hl);
     const uint64_t hlow = hl;
     if constexpr (W == 8) { mk.hi = 0; mk.lo = (hlow << 37) | ((uint64_t)pos << 32) | rl; }
     else { mk.lo = rl; mk.hi = (hlow << 38) | ((uint64_t)pos << 32) | rh; }
 }
 template <int W> __device__ __forceinline__ void min_split(uint64_t khi, uint64_t klo, const uint64_t *__restrict__ regions,
                                                           uint64_t &bucket, MinKey<W> &mk) {
-    uint32_t h, pos, rh; uint64_t rl;
-    minimizer<W>(khi, klo, h, pos, rh, rl);
-    min_finish<W>(khi, klo, h, pos, regions, bucket, mk);
+    uint32_t h, o, pos, rh; uint64_t rl;
+    minimizer<W>(khi, klo, h, o, pos, rh, rl);
+    min_finish<W>(khi, klo, h, o, pos, regions, bucket, mk);
 }
 
 // MIN records / bucket entries.  flag (top 2 bits of word KW): 0 record, 1 empty entry, 2 (a bucket's LAST entry only)

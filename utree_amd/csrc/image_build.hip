@@ -107,10 +107,15 @@ template <typename IDX, typename T> __global__ void gather_k(const T *__restrict
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
 }
 
-// minimizer pieces of every node the bin table reaches (nodes [c0, c0+m)); one thread per node, its bin by binary search
+// minimizer pieces of every node the bin table reaches (nodes [c0, c0+m)); one thread per 16 consecutive nodes, the first one's bin by
+// binary search.  Entry t < m is node t under its view f; a node whose view g differs (device_common.hpp) appends a second entry behind the
+// m first ones -- SRC[slot] = t, one atomic per such node -- as long as there is room (dup_cap); *ndup counts them all.
+// H carries the orientation with the hash: H[t] = h, O[t >> 5] bit t & 31 = o  (entries >= m: their own words, written whole by one thread
+// each would race -- so orientation bits are kept per entry in a byte array)
 template <int W, int I, typename OFF>
-__global__ void assign_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t c0, uint64_t m,
-                         uint32_t *__restrict__ H, uint64_t *__restrict__ K1, uint64_t *__restrict__ K2) {
+__global__ void assign_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t c0, uint64_t m, uint64_t dup_cap,
+                         uint32_t *__restrict__ H, uint8_t *__restrict__ O, uint64_t *__restrict__ K1, uint64_t *__restrict__ K2,
+                         uint64_t *__restrict__ SRC, unsigned long long *__restrict__ ndup) {
     for (uint64_t t0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * NODE_RUN; t0 < m; t0 += (uint64_t)gridDim.x * blockDim.x * NODE_RUN) {
         uint64_t p = bin_of<OFF>(coarse, c0 + t0);
         const uint64_t t1 = t0 + NODE_RUN < m ? t0 + NODE_RUN : m;
@@ -120,55 +125,61 @@ __global__ void assign_k(const OFF *__restrict__ coarse, const uint64_t *__restr
             const Key<W> k = file_key<W, I>(recs, j);
             uint64_t khi, klo;
             if constexpr (W == 16) { khi = (p << 40) | k.hi; klo = k.lo; } else { khi = 0; klo = (p << 40) | k.lo; }
-            uint32_t h, pos, rh; uint64_t rl;
-            minimizer<W>(khi, klo, h, pos, rh, rl);
-            H[t] = h;
-            if constexpr (W == 16) { K1[t] = rl; K2[t] = ((uint64_t)pos << 32) | rh; }
-            else K1[t] = ((uint64_t)pos << 32) | rl;
+            uint32_t hf, of, pf, hg, og, pg, rh; uint64_t rl;
+            minimizer_views<W>(khi, klo, hf, of, pf, hg, og, pg);
+            min_rest<W>(khi, klo, pf, rh, rl);
+            H[t] = hf; O[t] = (uint8_t)of;
+            if constexpr (W == 16) { K1[t] = rl; K2[t] = ((uint64_t)pf << 32) | rh; }
+            else K1[t] = ((uint64_t)pf << 32) | rl;
+            if (pg != pf || og != of) {
+                const unsigned long long slot = atomicAdd(ndup, 1ull);
+                if (slot < dup_cap) {
+                    const uint64_t u = m + slot;
+                    min_rest<W>(khi, klo, pg, rh, rl);
+                    H[u] = hg; O[u] = (uint8_t)og; SRC[slot] = t;
+                    if constexpr (W == 16) { K1[u] = rl; K2[u] = ((uint64_t)pg << 32) | rh; }
+                    else K1[u] = ((uint64_t)pg << 32) | rl;
+                }
+            }
         }
     }
 }
 
-// MIN record j = node idx[j] (relative to c0) in the final (hash, pos, rest) order
+// MIN record j = entry idx[j] in the final (bucket, hash bits, pos, rest) order; entry i is node i, or node SRC[i - m] under its second view
 template <int W, int I, typename IDX>
-__global__ void emit_k(const uint64_t *__restrict__ recs, uint64_t c0, const IDX *__restrict__ idx, const uint32_t *__restrict__ H,
-                       const uint64_t *__restrict__ K1, const uint64_t *__restrict__ K2, const uint64_t *__restrict__ regions, uint64_t m,
-                       uint64_t *__restrict__ out, uint32_t *__restrict__ Hs) {
+__global__ void emit_k(const uint64_t *__restrict__ recs, uint64_t c0, const IDX *__restrict__ idx, const uint32_t *__restrict__ H, const uint8_t *__restrict__ O,
+                       const uint64_t *__restrict__ K1, const uint64_t *__restrict__ K2, const uint64_t *__restrict__ SRC, uint64_t m_nodes,
+                       const uint64_t *__restrict__ regions, uint64_t m, uint64_t *__restrict__ out, uint64_t *__restrict__ Bs) {
     constexpr int EW = RecTraits<W, I>::EW;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = idx[j];
         const uint32_t h = H[i];
         uint64_t bucket; uint32_t hl;
-        bucket_of(regions, h, bucket, hl);
+        bucket_of(regions, h, O[i], bucket, hl);
         const uint64_t hlow = hl;
         MinKey<W> mk;
         if constexpr (W == 16) { mk.lo = K1[i]; mk.hi = (hlow << 38) | K2[i]; } else { mk.hi = 0; mk.lo = (hlow << 37) | K1[i]; }
-        const Entry<W, I> e = make_mrec<W, I>(mk, file_rank<W, I>(recs, c0 + i));
+        const uint64_t node = i < m_nodes ? i : SRC[i - m_nodes];
+        const Entry<W, I> e = make_mrec<W, I>(mk, file_rank<W, I>(recs, c0 + node));
 #pragma unroll
         for (int x = 0; x < EW; ++x) out[j * EW + x] = e.w[x];
-        Hs[j] = h;
+        Bs[j] = bucket;
     }
 }
 
 // Buckets from the sorted records: the first thread of every bucket's run copies up to CAP records into the bucket (the
 // rest of the bucket stays flagged empty); a longer run leaves CAP-1 records inline and an overflow descriptor last.
 template <int W, int I>
-__global__ void bucket_k(const uint32_t *__restrict__ Hs, const uint64_t *__restrict__ mrecs, uint64_t base, uint64_t m,
-                         const uint64_t *__restrict__ regions, uint64_t *__restrict__ table, uint32_t bw, uint64_t run_max, unsigned long long *overflow) {
-    // Hs / mrecs: this part's sorted hashes and records (a part = a range of whole buckets); base = MIN records in earlier parts
+__global__ void bucket_k(const uint64_t *__restrict__ Bs, const uint64_t *__restrict__ mrecs, uint64_t base, uint64_t m,
+                         uint64_t *__restrict__ table, uint32_t bw, uint64_t run_max, unsigned long long *overflow) {
+    // Bs / mrecs: this part's sorted bucket numbers and records (a part = a range of whole buckets); base = MIN records in earlier parts
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
     const int CAP = (int)bw / EW;                                                     // entries of a bucket (bw = its 8-byte words: 8 or 16)
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t b, bp; uint32_t hl;
-        bucket_of(regions, Hs[j], b, hl);
-        if (j) { bucket_of(regions, Hs[j - 1], bp, hl); if (bp == b) continue; }          // not the first node of its bucket
+        const uint64_t b = Bs[j];
+        if (j && Bs[j - 1] == b) continue;                                            // not the first record of its bucket
         uint64_t n = 1;
-        for (;;) {
-            if (j + n >= m) break;
-            bucket_of(regions, Hs[j + n], bp, hl);
-            if (bp != b) break;
-            ++n;
-        }
+        while (j + n < m && Bs[j + n] == b) ++n;
         uint64_t *o = table + b * bw;
         const uint64_t inl = n <= (uint64_t)CAP ? n : (uint64_t)CAP - 1;
         for (uint64_t q = 0; q < inl; ++q)
@@ -191,17 +202,17 @@ __global__ void bucket_k(const uint32_t *__restrict__ Hs, const uint64_t *__rest
 // count.  Only launched for a part in which bucket_k counted such a bucket (e.g. millions of k-mers that contain A^16, whose
 // hash is 0: all of them share the first bucket).
 template <int W, int I, typename OFF, typename IDX>
-__global__ void flag_saturated_k(const uint32_t *__restrict__ Hs, const IDX *__restrict__ idx, uint64_t m, uint64_t c0,
-                                 const OFF *__restrict__ coarse, const uint64_t *__restrict__ regions, const uint64_t *__restrict__ table, uint32_t bw,
+__global__ void flag_saturated_k(const uint64_t *__restrict__ Bs, const IDX *__restrict__ idx, uint64_t m, uint64_t c0, const uint64_t *__restrict__ SRC, uint64_t m_nodes,
+                                 const OFF *__restrict__ coarse, const uint64_t *__restrict__ table, uint32_t bw,
                                  uint32_t *irreg, unsigned long long *counters) {
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
     const int CAP = (int)bw / EW;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t b; uint32_t hl;
-        bucket_of(regions, Hs[j], b, hl);
+        const uint64_t b = Bs[j];
         const uint64_t d = table[b * bw + (uint64_t)(CAP - 1) * EW + KW];
         if ((d >> 62) != 2 || ((d >> 40) & 0x3FFFFFull) != 0x3FFFFFull) continue;
-        const uint32_t p = bin_of<OFF>(coarse, c0 + (uint64_t)idx[j]);
+        const uint64_t i = idx[j], node = i < m_nodes ? i : SRC[i - m_nodes];
+        const uint32_t p = bin_of<OFF>(coarse, c0 + node);
         const uint32_t bit = 1u << (p & 31);
         if (!(__atomic_load_n(&irreg[p >> 5], __ATOMIC_RELAXED) & bit) && !(atomicOr(&irreg[p >> 5], bit) & bit)) atomicAdd(&counters[1], 1ull);
     }
@@ -276,18 +287,18 @@ int sort_pass(const uint64_t *key_by_node, uint32_t nbits, IDX *&idx, IDX *&idx_
 // the last pass: by { bucket | the hash's low 8 bits } -- the bucket is monotone in the hash, but a bucket's up to 256 consecutive
 // hash values need not ascend in their low 8 bits, and inside a bucket (and its overflow run) records ascend by their KEY, whose top
 // field those 8 bits are
-template <typename IDX> __global__ void gather_bkey_k(const uint32_t *__restrict__ H, const IDX *__restrict__ idx, const uint64_t *__restrict__ regions,
+template <typename IDX> __global__ void gather_bkey_k(const uint32_t *__restrict__ H, const uint8_t *__restrict__ O, const IDX *__restrict__ idx, const uint64_t *__restrict__ regions,
                                                       uint64_t *__restrict__ dst, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t b; uint32_t hl;
-        bucket_of(regions, H[idx[i]], b, hl);
+        bucket_of(regions, H[idx[i]], O[idx[i]], b, hl);
         dst[i] = (b << 8) | hl;
     }
 }
 template <typename IDX>
-int sort_pass_bucket(const uint32_t *H, const uint64_t *regions, uint32_t nbits, IDX *&idx, IDX *&idx_alt, uint64_t *kg, uint64_t *kg_alt, uint64_t m,
+int sort_pass_bucket(const uint32_t *H, const uint8_t *O, const uint64_t *regions, uint32_t nbits, IDX *&idx, IDX *&idx_alt, uint64_t *kg, uint64_t *kg_alt, uint64_t m,
                      void *tmp, size_t tmp_bytes, hipStream_t st) {
-    gather_bkey_k<IDX><<<grid_for(m), 256, 0, st>>>(H, idx, regions, kg, m);
+    gather_bkey_k<IDX><<<grid_for(m), 256, 0, st>>>(H, O, idx, regions, kg, m);
     hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kg, kg_alt, idx, idx_alt, m, 0, nbits, st);
     if (e != hipSuccess) return (int)e;
     IDX *t = idx; idx = idx_alt; idx_alt = t;
@@ -325,14 +336,19 @@ struct in_part {
 // node on top of the 12-20 bytes of keys; when that does not fit beside the image (trees of billions of nodes) the
 // nodes are handled in 2^pb parts by the top bits of the hash -- parts are contiguous in the final order.
 template <int W, int I, typename OFF, typename IDX>
-int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, const uint64_t *regions, const uint64_t *h_regions, uint64_t n_buckets,
-              uint32_t bw, uint64_t *table, uint64_t *mrecs, uint32_t *irreg, unsigned long long *d_overflow, hipStream_t st) {
+int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, const uint64_t m_nodes, uint64_t dup_cap, const uint64_t *regions, const uint64_t *h_regions, uint64_t n_buckets,
+              uint32_t bw, uint64_t *table, uint64_t *mrecs, uint32_t *irreg, unsigned long long *d_overflow, uint64_t *n_min, int *views, hipStream_t st) {
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
     const uint64_t nslots = n_buckets * (bw / EW);                           // entries, all flagged empty to begin with
     for (int x = 0; x < EW; ++x) fill_u64_k<<<grid_for(nslots), 256, 0, st>>>(table, nslots, x == KW ? MFLAG_EMPTY : 0ull, EW, x);
-    if (!m) return (int)hipGetLastError();
-    uint32_t *H = nullptr, *Hg = nullptr, *Hg2 = nullptr; (void)Hg2;
-    uint64_t *K1 = nullptr, *K2 = nullptr, *kg = nullptr, *kg2 = nullptr;
+    *n_min = 0; *views = 1;
+    if (!m_nodes) return (int)hipGetLastError();
+    if (dup_cap > m_nodes) dup_cap = m_nodes;
+    uint64_t m = m_nodes;                                                    // entries: the nodes, then the second views (known after assign_k)
+    uint32_t *H = nullptr;
+    uint8_t *O = nullptr;
+    uint64_t *K1 = nullptr, *K2 = nullptr, *kg = nullptr, *kg2 = nullptr, *SRC = nullptr, *Bs = nullptr;
+    unsigned long long *d_ndup = nullptr;
     IDX *idx = nullptr, *idx2 = nullptr;
     unsigned long long *d_counts = nullptr;
     void *tmp = nullptr;
@@ -340,18 +356,28 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
     int rc = 0;
     uint32_t nparts = 1;
     part_bounds pbnd;
-    uint64_t cap = m, base = 0;
+    uint64_t cap = 0, base = 0;
     unsigned long long h_counts[65] = {0}, sat_seen = 0;
     // longest run an overflow descriptor may describe (22-bit count, all ones = saturated); UTREE_BUCKET_RUN_MAX lowers it (tests)
     uint64_t run_max = (1ull << 22) - 2;
     { const char *e = getenv("UTREE_BUCKET_RUN_MAX"); if (e && atoll(e) > 0 && (uint64_t)atoll(e) < run_max) run_max = (uint64_t)atoll(e); }
     const bool chat = getenv("UTREE_TIMING") != nullptr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto done; } } while (0)
-    CK(hipMalloc((void **)&H, m * 4)); CK(hipMalloc((void **)&K1, m * 8));
-    if (W == 16) CK(hipMalloc((void **)&K2, m * 8));
+    CK(hipMalloc((void **)&H, (m_nodes + dup_cap) * 4)); CK(hipMalloc((void **)&O, m_nodes + dup_cap)); CK(hipMalloc((void **)&K1, (m_nodes + dup_cap) * 8));
+    if (W == 16) CK(hipMalloc((void **)&K2, (m_nodes + dup_cap) * 8));
+    CK(hipMalloc((void **)&SRC, (dup_cap ? dup_cap : 1) * 8)); CK(hipMalloc((void **)&d_ndup, 8));
+    CK(hipMemsetAsync(d_ndup, 0, 8, st));
     if (chat) { CK(hipStreamSynchronize(st)); fprintf(stderr, "[utree_amd] image: table cleared, key buffers allocated\n"); }
-    assign_k<W, I, OFF><<<grid_for(m), 256, 0, st>>>(coarse, recs, c0, m, H, K1, K2);
-    if (chat) { CK(hipStreamSynchronize(st)); fprintf(stderr, "[utree_amd] image: minimizers of %llu nodes assigned\n", (unsigned long long)m); }
+    assign_k<W, I, OFF><<<grid_for((m_nodes + NODE_RUN - 1) / NODE_RUN), 256, 0, st>>>(coarse, recs, c0, m_nodes, dup_cap, H, O, K1, K2, SRC, d_ndup);
+    {
+        unsigned long long nd = 0;
+        CK(hipMemcpyAsync(&nd, d_ndup, 8, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        if (nd > dup_cap) { *views = 0; nd = 0; }                            // too many: none is used, and the image says so
+        m = m_nodes + nd;
+        if (chat) fprintf(stderr, "[utree_amd] image: minimizers of %llu nodes assigned, %llu second views%s\n", (unsigned long long)m_nodes, nd, *views ? "" : " (dropped: beyond the build area)");
+    }
+    cap = m;
     {
         // smallest number of parts whose sort buffers fit what is left of the HBM, each sort below 2^31 items
         size_t free_b = 0, total_b = 0;
@@ -443,19 +469,19 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
         {
             uint32_t bbits = 1;
             while (bbits < 56 && (n_buckets >> bbits)) ++bbits;
-            if ((rc = sort_pass_bucket<IDX>(H, regions, 8 + bbits, idx, idx2, kg, kg2, mq, tmp, t64, st))) goto done;   // bucket, low hash bits
+            if ((rc = sort_pass_bucket<IDX>(H, O, regions, 8 + bbits, idx, idx2, kg, kg2, mq, tmp, t64, st))) goto done;   // bucket (pair, orientation), low hash bits
         }
-        Hg = (uint32_t *)kg; Hg2 = (uint32_t *)kg2;
-        // emit_k recomputes the hashes from H[idx]: Hg becomes the array of hashes in the final order
-        emit_k<W, I, IDX><<<grid_for(mq), 256, 0, st>>>(recs, c0, idx, H, K1, K2, regions, mq, mrecs + base * EW, Hg);
-        bucket_k<W, I><<<grid_for(mq), 256, 0, st>>>(Hg, mrecs + base * EW, base, mq, regions, table, bw, run_max, d_overflow);
+        Bs = kg;
+        // emit_k recomputes the buckets from H[idx], O[idx]: Bs becomes the array of bucket numbers in the final order
+        emit_k<W, I, IDX><<<grid_for(mq), 256, 0, st>>>(recs, c0, idx, H, O, K1, K2, SRC, m_nodes, regions, mq, mrecs + base * EW, Bs);
+        bucket_k<W, I><<<grid_for(mq), 256, 0, st>>>(Bs, mrecs + base * EW, base, mq, table, bw, run_max, d_overflow);
         CK(hipGetLastError());
         {
             unsigned long long sat = 0;
             CK(hipMemcpyAsync(&sat, d_overflow, 8, hipMemcpyDeviceToHost, st));
             CK(hipStreamSynchronize(st));
             if (sat != sat_seen) {                  // this part has saturated buckets: their nodes' bins take the exact-probe path
-                flag_saturated_k<W, I, OFF, IDX><<<grid_for(mq), 256, 0, st>>>(Hg, idx, mq, c0, coarse, regions, table, bw, irreg, d_overflow);
+                flag_saturated_k<W, I, OFF, IDX><<<grid_for(mq), 256, 0, st>>>(Bs, idx, mq, c0, SRC, m_nodes, coarse, table, bw, irreg, d_overflow);
                 CK(hipGetLastError());
                 sat_seen = sat;
             }
@@ -465,10 +491,11 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, uint64_t m, 
     }
     CK(hipStreamSynchronize(st));
     if (base != m) rc = (int)hipErrorUnknown;
+    *n_min = m;
 done:
 #undef CK
     (void)hipFree(H); (void)hipFree(K1); (void)hipFree(K2); (void)hipFree(idx); (void)hipFree(idx2); (void)hipFree(kg);
-    (void)hipFree(kg2); (void)hipFree(tmp); (void)hipFree(d_counts);
+    (void)hipFree(kg2); (void)hipFree(tmp); (void)hipFree(d_counts); (void)hipFree(O); (void)hipFree(SRC); (void)hipFree(d_ndup);
     return rc;
 }
 
@@ -567,17 +594,17 @@ done:
 
 /* nodes [c0, c0+m) = what the (monotone) bin table reaches.  d_overflow[0] += buckets whose run saturates the descriptor,
  * d_overflow[1] += bins newly flagged in d_irreg because of them. */
-int utk_build_min(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
+int utk_build_min(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m, uint64_t dup_cap,
                   const uint64_t *d_regions, const uint64_t *h_regions, uint64_t n_buckets, uint32_t bw, uint64_t *d_table, uint64_t *d_mrecs, uint32_t *d_irreg,
-                  unsigned long long *d_overflow, void *stream) {
+                  unsigned long long *d_overflow, uint64_t *n_min, int *views, void *stream) {
     int rc = 0;
     int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
         constexpr int W = decltype(w)::value, I = decltype(i)::value;
         hipStream_t st = (hipStream_t)stream;
-        const bool idx64 = m >= 0xFFFFFFFFull;
-        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, bw, d_table, d_mrecs, d_irreg, d_overflow, st);
-        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, bw, d_table, d_mrecs, d_irreg, d_overflow, st);
-        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, d_regions, h_regions, n_buckets, bw, d_table, d_mrecs, d_irreg, d_overflow, st);
+        const bool idx64 = m + dup_cap >= 0xFFFFFFFFull;
+        if (off64 && idx64) rc = build_min<W, I, uint64_t, uint64_t>((const uint64_t *)d_coarse, d_recs, c0, m, dup_cap, d_regions, h_regions, n_buckets, bw, d_table, d_mrecs, d_irreg, d_overflow, n_min, views, st);
+        else if (off64) rc = build_min<W, I, uint64_t, uint32_t>((const uint64_t *)d_coarse, d_recs, c0, m, dup_cap, d_regions, h_regions, n_buckets, bw, d_table, d_mrecs, d_irreg, d_overflow, n_min, views, st);
+        else rc = build_min<W, I, uint32_t, uint32_t>((const uint32_t *)d_coarse, d_recs, c0, m, dup_cap, d_regions, h_regions, n_buckets, bw, d_table, d_mrecs, d_irreg, d_overflow, n_min, views, st);
     });
     return rc ? rc : drc;
 }

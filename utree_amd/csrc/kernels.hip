@@ -79,7 +79,7 @@ __device__ __forceinline__ uint32_t mmer_l(const uint32_t *s, uint32_t word, uin
 constexpr uint32_t MIN_POS_MASK = (1u << MIN_LOW_BITS) - 1u;       // a tile has < 2^MIN_LOW_BITS positions
 template <int W> struct MinWin { static constexpr uint32_t NEXT = (W == 16) ? 17u : 1u; };   // [t,t+16)+[t+1,t+17) / [t,t+32)+[t+17,t+49)
 template <int W, uint32_t NCH>
-__device__ __forceinline__ void build_minkeys_n(const uint32_t *s, uint32_t sh, uint32_t *Kl, uint32_t *Hl, uint32_t lane) {
+__device__ __forceinline__ void build_minkeys_n(const uint32_t *s, uint32_t sh, uint32_t *Kl, uint32_t *Hl, uint64_t *Ob, uint32_t lane) {
     uint32_t x[NCH];
 #pragma unroll
     for (uint32_t c = 0; c < NCH; ++c) x[c] = mmer_l(s, 4 * c, sh);          // all chunks' words are requested before the first is hashed
@@ -89,9 +89,14 @@ __device__ __forceinline__ void build_minkeys_n(const uint32_t *s, uint32_t sh, 
     asm volatile("" : "+v"(lo));
 #pragma unroll
     for (uint32_t c = 0; c < NCH; ++c) {
-        const uint32_t h = mix32(x[c]);
+        // (image version 11: a 16-mer is ranked and addressed by the hash of its canonical form; which orientation the read holds picks the
+        // bucket of the pair -- one bit per position, kept as the chunk's ballot)
+        const uint32_t r = rc16(x[c]);
+        const bool o = x[c] > r;
+        const uint32_t h = mix32(o ? r : x[c]);
         Kl[c * 64] = ((h & ~MIN_POS_MASK) | lo) + c * 64;
         Hl[c * 64] = h;
+        Ob[c] = __builtin_amdgcn_ballot_w64(o);
     }
     Kl[NCH * 64] = ~0u;
     wave_lds_fence();
@@ -108,15 +113,15 @@ __device__ __forceinline__ void build_minkeys_n(const uint32_t *s, uint32_t sh, 
     }
 }
 template <int W, uint32_t TILE>
-__device__ __forceinline__ void build_minkeys(const uint32_t *s, uint32_t sh, uint32_t *Kl, uint32_t *Hl, uint32_t npos, uint32_t lane) {
+__device__ __forceinline__ void build_minkeys(const uint32_t *s, uint32_t sh, uint32_t *Kl, uint32_t *Hl, uint64_t *Ob, uint32_t npos, uint32_t lane) {
     constexpr uint32_t MAXCH = (TILE + 4 * W - 16 + 63) / 64;
     static_assert(MAXCH <= 5, "tile too large");
     const uint32_t nch = (npos + 63) >> 6;                 // wave-uniform
-    if (nch <= 1) build_minkeys_n<W, 1>(s, sh, Kl, Hl, lane);
-    else if (nch == 2) build_minkeys_n<W, 2>(s, sh, Kl, Hl, lane);
-    else if (nch == 3 || MAXCH == 3) build_minkeys_n<W, 3>(s, sh, Kl, Hl, lane);
-    else if (nch == 4) build_minkeys_n<W, MAXCH >= 4 ? 4 : 3>(s, sh, Kl, Hl, lane);
-    else build_minkeys_n<W, MAXCH >= 5 ? 5 : 3>(s, sh, Kl, Hl, lane);
+    if (nch <= 1) build_minkeys_n<W, 1>(s, sh, Kl, Hl, Ob, lane);
+    else if (nch == 2) build_minkeys_n<W, 2>(s, sh, Kl, Hl, Ob, lane);
+    else if (nch == 3 || MAXCH == 3) build_minkeys_n<W, 3>(s, sh, Kl, Hl, Ob, lane);
+    else if (nch == 4) build_minkeys_n<W, MAXCH >= 4 ? 4 : 3>(s, sh, Kl, Hl, Ob, lane);
+    else build_minkeys_n<W, MAXCH >= 5 ? 5 : 3>(s, sh, Kl, Hl, Ob, lane);
 }
 
 // The block's copy of the image's region table in the form the window loop wants it (stage_regions):
@@ -136,11 +141,13 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const Lan
     uint32_t *Kp = (uint32_t *)Kk;                                          // the wave's 8 * (TILE + 128) bytes: keys, then hashes
     uint32_t *Kl = Kp + lane, *Hl = Kp + (TILE + 128) + lane;
     const uint32_t *Hh = Kp + (TILE + 128);
+    uint64_t *Ob = Kk + (TILE + 128) - 8;                                   // orientation ballots of the tile's (at most five) chunks: the hash area's unused tail
+    static_assert(((TILE + 4 * W - 16 + 63) / 64) * 64 + 16 <= TILE + 128, "the ballots share the hash area");
     const uint32_t nlane = 0u - lane;
     for (uint32_t wb = 0; wb < n; wb += TILE) {
         const uint32_t tn = n - wb < TILE ? n - wb : TILE;
         const uint32_t *st = lb.swl + ((w0 + wb) >> 4);                      // the tile's first word, per lane
-        build_minkeys<W, TILE>(st, lb.sh, Kl, Hl, tn + K - 16, lane);       // 16-mers of windows w0+wb .. w0+wb+tn-1
+        build_minkeys<W, TILE>(st, lb.sh, Kl, Hl, Ob, tn + K - 16, lane);   // 16-mers of windows w0+wb .. w0+wb+tn-1
         TICK(2);
 #if defined(UTREE_ABLATE) && UTREE_ABLATE == 2
         continue;
@@ -152,13 +159,14 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const Lan
             const uint32_t ka = Kr[0], kb = Kr[MinWin<W>::NEXT];
             const uint32_t p = (kb < ka ? kb : ka) & MIN_POS_MASK;
             const uint32_t h = Hh[p];
+            const uint32_t o = (uint32_t)(Ob[p >> 6] >> (p & 63u)) & 1u;    // the read holds the canonical 16-mer (0) or its reverse complement
             const uint32_t pos = p + nlane - it * 64;                       // minimizer position inside the window
             const uint64_t re = rg.reg[h >> 24];
             const uint32_t bl = __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u));
 #ifdef UTREE_ABLATE_L2
             baddr = rg.table + ((uint64_t)(bl & 0x1FFFu) << rg.bshift);     // timing experiment: every bucket inside 1 MB (L2 hits), answers wrong
 #else
-            baddr = rg.table + (((re >> UTREE_REGION_NB_BITS) + bl) << rg.bshift);
+            baddr = rg.table + ((2u * ((re >> UTREE_REGION_NB_BITS) + bl) + o) << rg.bshift);
 #endif
             tag = ((h & 0xFFu) << 6) | pos;                                 // hash bits the bucket does not imply | position (< 64)
         };

@@ -17,7 +17,11 @@
 //                          record, longer ones searched per window
 //   phase C  lane = read   tally of the read's hits (itree.c:1028-1040): distinct labels ascending with counts, result record
 //
-// With RC the read's reverse complement takes phases A and B a second time in the same slot.  The hits a read gets are the same
+// With RC (BS instantiations: an image with 64-byte buckets that carries UTREE_F_STRAND_VIEWS) both strands are served by ONE pass: minimizers
+// are canonical (device_common.hpp), so the reverse complement of a window has the window's own minimizer run, mirrored -- the other bucket
+// of the same pair (the other half of the line the quad fetches anyway), positions K-16-p, the outer bases reversed and complemented -- and
+// every run's scan tests the entries of bucket o against its windows and those of bucket 1-o against their reverse complements.  Without BS
+// the read's reverse complement takes phases A and B a second time in the same slot.  The hits a read gets are the same
 // (window, record) pairs classify_short_k finds: it asks, per window, which entry of the minimizer's bucket carries the window's
 // key {hash bits, position, outer bases}; this kernel asks, per entry, which window of the run has that key.  Reads this kernel
 // does not finish -- two or more bases other than ACGTacgt, more distinct labels than LANES_TSLOTS, a wave whose run list is full -- go on the
@@ -118,11 +122,14 @@ __device__ __forceinline__ void rest96(const uint32_t (&A)[3], const uint32_t (&
 // an image -- utk_lanes_image_ok)
 // NL: 16-byte loads a lane makes per bucket -- 1: the image has 64-byte buckets (a quad of lanes fetches one with one request), 2: 128-byte
 // buckets (two requests, the two halves of one line)
-template <int W, int I, int SEGS, bool IRR, int MODE, int NL>
+// BS: both strands from one pass (NL = 1 only; do_rc is set): a quad fetches both buckets of a run's pair -- two requests, the two halves of one line
+template <int W, int I, int SEGS, bool IRR, int MODE, int NL, bool BS>
 __global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
 void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
                       uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws, uint32_t cls) {
     constexpr bool PIECE = MODE == 2, LISTED = MODE == 1;
+    static_assert(!BS || NL == 1, "both strands in one pass: 64-byte buckets");
+    constexpr int NLX = BS ? 2 : NL;                                 // 16-byte loads per lane and run: the pipeline is that of the 128-byte buckets
     using G = Geo<W>;
     constexpr uint32_t K = G::K, NB = G::NB, NA = G::NA, STRIDE = G::STRIDE, FRONT = G::FRONT, RUNS_CAP = G::RUNS;
     constexpr uint32_t SW = LCAP - K + 1, RPW = 64 / SEGS;            // windows per lane; reads per wavefront
@@ -146,10 +153,10 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     __shared__ uint64_t s_reg[256];
     for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) s_reg[x] = im.regions[x];   // {first bucket << 25 | buckets} of every hash region
     const uint64_t tbl = (uint64_t)(uintptr_t)im.table;
-    // the 128-byte bucket of a minimizer hash (device_common.hpp: bucket_of)
-    auto bucket_addr = [&](uint32_t h) -> uint64_t {
+    // the bucket of a minimizer: the hash of its canonical form picks the pair, the orientation the bucket (device_common.hpp: bucket_of)
+    auto bucket_addr = [&](uint32_t h, uint32_t o) -> uint64_t {
         const uint64_t re = s_reg[h >> 24];
-        return tbl + (((re >> UTREE_REGION_NB_BITS) + __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u))) << (NL == 2 ? 7 : 6));
+        return tbl + ((2u * ((re >> UTREE_REGION_NB_BITS) + __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u))) + o) << (NL == 2 ? 7 : 6));
     };
     const uint32_t lane = lane_id();
     const uint32_t wv = uni32(threadIdx.x >> 6);
@@ -280,7 +287,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         bool wave_full = false;
         // With RC the read's reverse complement is a second pass over the same slot (itree.c:891-898 appends it behind a separator
         // that no window spans: two independent sequences, one list of hits).
-        for (int strand = 0; strand < (do_rc ? 2 : 1); ++strand) {
+        for (int strand = 0; strand < (do_rc && !BS ? 2 : 1); ++strand) {
         if (strand) {
             // the slot's bases 0 .. 16 NWORD - 1 reversed and complemented word by word, then moved up by the 16 NWORD - L bases that
             // now lead; the bad base moves with them
@@ -310,7 +317,11 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         uint32_t nruns = 0;
         if (maxnwin) {
             uint32_t A[NB];
-            uint32_t m16 = sl[0];
+            uint32_t m16 = sl[0], r16 = rc16(sl[0]);                        // the 16-mer at the walk's position and its reverse complement
+            // (a 16-mer's rank is the hash of its canonical form, the smaller of the two: one xor, one funnel shift and one minimum per
+            // position on top of the forward walk)
+#define ROLL16(p_) { const uint32_t b_ = (sl[(p_) >> 4] >> (30u - 2u * ((p_) & 15u))) & 3u; m16 = (m16 << 2) | b_; r16 = __builtin_amdgcn_alignbit(b_ ^ 3u, r16, 2u); }
+#define CKEY() (mix32(umin(m16, r16)) & ~0x1FFu)
             // (a window's bin is its first 12 bases: the top 24 bits of the 16-mer it starts with -- every 16-mer passes here)
             auto irregular = [&](uint32_t m, uint32_t u) {                  // u: the 16-mer's first base = the window it starts
                 if constexpr (IRR) {
@@ -319,12 +330,12 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
                 }
             };
             irregular(m16, 0u);
-            A[0] = mix32(m16) & ~0x1FFu;
+            A[0] = CKEY();
 #pragma unroll
             for (uint32_t p = 16; p < K; ++p) {
-                m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u);
+                ROLL16(p)
                 irregular(m16, p - 15u);
-                A[p - 15] = (mix32(m16) & ~0x1FFu) | (p - 15u);
+                A[p - 15] = CKEY() | (p - 15u);
             }
             // A window that does not exist (beyond the read's last) or holds the bad base (itree.c:919-927) carries the key ~0 -- no
             // 16-mer's -- instead of its minimizer's: the run before it ends there like at any change of minimizer, and a "run" of
@@ -347,9 +358,9 @@ _Pragma("unroll") \
                     if (rr == 0) wmin = A[0]; \
                     else { \
                         const uint32_t p = s + (K - 1u); \
-                        m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u); \
+                        ROLL16(p) \
                         irregular(m16, s + (NB - 1u)); \
-                        const uint32_t k = (mix32(m16) & ~0x1FFu) | (s + (NB - 1u)); \
+                        const uint32_t k = CKEY() | (s + (NB - 1u)); \
                         const uint32_t Sr = A[rr]; \
                         A[rr - 1] = k; \
                         P = rr == 1 ? k : umin(P, k); \
@@ -373,9 +384,9 @@ _Pragma("unroll") \
                 } \
                 if (done) break; \
                 const uint32_t p = NB * (b + 1u) + (K - 1u); \
-                m16 = (m16 << 2) | ((sl[p >> 4] >> (30u - 2u * (p & 15u))) & 3u); \
+                ROLL16(p) \
                 irregular(m16, NB * (b + 1u) + (NB - 1u)); \
-                A[NB - 1] = (mix32(m16) & ~0x1FFu) | (NB * (b + 1u) + (NB - 1u)); \
+                A[NB - 1] = CKEY() | (NB * (b + 1u) + (NB - 1u)); \
             }
 #ifdef UTREE_LANES_NOCLEAN
             const bool clean = false;
@@ -384,6 +395,8 @@ _Pragma("unroll") \
 #endif
             if (clean) { PHASE_A_BLOCKS(true) } else { PHASE_A_BLOCKS(false) }
 #undef PHASE_A_BLOCKS
+#undef ROLL16
+#undef CKEY
             nruns = uni32(nruns);
         }
         if (nruns > RUNS_CAP) { wave_full = true; nruns = 0; }                         // every read of the grab goes on the list
@@ -403,8 +416,16 @@ _Pragma("unroll") \
         // An entry's tag is {flag2 | hash low bits | minimizer position in the k-mer} (its high half-word; k = 32: times two, the zero bit
         // below the position included): the run's windows have the tags tlo .. tlo + span -- hash bits of the run's minimizer, positions
         // d - (windows - 1) .. d -- so that "a record of this run's minimizer, for one of its windows" is one subtract and one compare.
-        struct RunRegs { uint32_t h, pk, t, A[NA], B[NA]; };
+        // (pk bit 31: the orientation o of the run's minimizer in the read -- the bucket of the pair its windows' records are in.  BS: tr, RA, RB
+        // are the same for the windows' reverse complements: they have the mirrored positions K-16-p in bucket 1-o, and their outer bases are
+        // the reverse complement of the 2 (K-16) bases around the minimizer, read the same way)
+        struct RunRegs { uint32_t h, pk, t, A[NA], B[NA], tr, RA[NA], RB[NA]; };
         constexpr uint32_t TSH = W == 8 ? 1u : 0u, PB = W == 8 ? 5u : 6u;             // tag scale; bits of the position field
+        constexpr uint32_t KM = K - 16u;                                              // the largest minimizer position
+        auto rev_context = [&](const uint32_t (&A)[NA], const uint32_t (&B)[NA], uint32_t (&RA)[NA], uint32_t (&RB)[NA]) {
+#pragma unroll
+            for (uint32_t i = 0; i < NA; ++i) { RA[i] = rc16(B[NA - 1u - i]); RB[i] = rc16(A[NA - 1u - i]); }
+        };
         // a run's context from its record: the words around the minimizer come from the slot of the run's read
         auto context = [&](uint32_t q, uint32_t ustar, uint32_t &m, uint32_t (&A)[NA], uint32_t (&B)[NA]) {
             const uint32_t *sq = stream + q * STRIDE + FRONT + (ustar >> 4);
@@ -426,14 +447,18 @@ _Pragma("unroll") \
             const uint32_t rec = runs[act ? idx : nruns - 1u];
             const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu;
             const uint32_t end = (rec >> 16) & 0xFFu;
-            uint32_t m;
+            uint32_t m, o;
             context(q, ustar, m, c.A, c.B);
-            c.h = mix32(m);
+            c.h = canon_hash(m, o);
             // (beyond the list: an offset no run has -- no entry's position field names a window of that run)
             const uint32_t dl = act ? ((ustar - first) << 8) | ((end - 1u - first) << 14) : (G::DNONE << 8);
-            c.pk = first | dl | (q << 20);
+            c.pk = first | dl | (q << 20) | (o << 31);
             // (beyond the list: a range no entry's tag lies in)
             c.t = act ? (((((c.h & 0xFFu) << PB) | (ustar - (end - 1u))) << TSH) | (((end - 1u - first) << TSH) << 16)) : 0xFFFFu;
+            if constexpr (BS) {
+                rev_context(c.A, c.B, c.RA, c.RB);
+                c.tr = act ? (((((c.h & 0xFFu) << PB) | (KM - (ustar - first))) << TSH) | (((end - 1u - first) << TSH) << 16)) : 0xFFFFu;
+            }
         };
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef const __attribute__((address_space(1))) u32x4 *gptr128;
@@ -444,12 +469,13 @@ _Pragma("unroll") \
         // time (runs 2 half, 2 half + 1); lane j fetches bytes 16 j .. 16 j + 15 of both 64-byte halves of each of the two buckets: P[0],
         // P[1] of the first run, P[2], P[3] of the second; the two requests of a quad for one bucket are the two halves of one line --,
         // three half-batches deep.  Either way 16 registers per unit in flight, 8 KB of buckets in flight while one unit is scanned.
+        // BS: the two loads are the run's own bucket (o) and the other one of its pair -- the other half of the same line
 #define ISSUE_K(k, at) { const uint64_t b_ = ((uint64_t)QUAD_BCAST(ahi, k) << 32) | (QUAD_BCAST(alo, k) | mine); \
-                         P[at] = *(gptr128)b_; if constexpr (NL == 2) P[at + 1] = *(gptr128)(b_ | 64u); }
+                         P[at] = *(gptr128)b_; if constexpr (NL == 2) P[at + 1] = *(gptr128)(b_ | 64u); if constexpr (BS) P[at + 1] = *(gptr128)(b_ ^ 64u); }
         auto issue = [&](const RunRegs &c, const uint32_t half, u32x4 (&P)[4]) {
-            const uint64_t a = bucket_addr(c.h);                                                       // aligned to the bucket's size
+            const uint64_t a = bucket_addr(c.h, c.pk >> 31);                                           // aligned to the bucket's size
             const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32), mine = 16u * (lane & 3u);
-            if constexpr (NL == 1) { ISSUE_K(0, 0) ISSUE_K(1, 1) ISSUE_K(2, 2) ISSUE_K(3, 3) }
+            if constexpr (NLX == 1) { ISSUE_K(0, 0) ISSUE_K(1, 1) ISSUE_K(2, 2) ISSUE_K(3, 3) }
             else if (half == 0u) { ISSUE_K(0, 0) ISSUE_K(1, 2) } else { ISSUE_K(2, 0) ISSUE_K(3, 2) }
         };
 #undef ISSUE_K
@@ -470,7 +496,8 @@ _Pragma("unroll") \
         // hits of a batch wait in two registers per lane (lane of the read << QS | rank, the later one in `p0`) and go to the reads' lists
         // once per batch.  `last`: these 16 bytes are the bucket's last in this lane's share (the second load); the quad's fourth lane
         // then holds the bucket's last entry, which says whether the bucket continues in an overflow run
-        auto scan1 = [&](uint32_t ct, uint32_t cpk, const uint32_t (&cA)[NA], const uint32_t (&cB)[NA], const u32x4 &Pk, const bool last,
+        // `rev`: the entries are tested against the reverse complements of the run's windows (ct, cA, cB: the mirrored tags and bases)
+        auto scan1 = [&](uint32_t ct, uint32_t cpk, const uint32_t (&cA)[NA], const uint32_t (&cB)[NA], const u32x4 &Pk, const bool last, const bool rev,
                          uint32_t &p0, uint32_t &p1, uint32_t &np) {
             const uint32_t tlo = ct & 0xFFFFu, span = ct >> 16;
             const uint32_t qs = I == 2 ? ((cpk >> 4) & 0x3F0000u) : (cpk & 0x3F00000u);  // read << QS
@@ -522,7 +549,7 @@ _Pragma("unroll") \
                     const uint32_t first = cpk & 0xFFu, q = (cpk >> 20) & 63u;
                     if ((om >> lane) & 1ull) {
                         const uint32_t at = n_ovf + lanes_below(om);
-                        runs[at] = (first + d) | (first << 8) | ((first + lenm1 + 1u) << 16) | (q << 24);
+                        runs[at] = (first + d) | (first << 8) | ((first + lenm1 + 1u) << 16) | (q << 24) | (rev ? 0x80000000u : 0u);   // (bit 31: the strand)
 #ifndef UTREE_LANES_REFETCH_DESC
                         // (the descriptor is in this lane's registers: the first 64 of a grab's overflowing runs keep it, and the
                         // overflow stage's first round starts without the trip that fetches it again)
@@ -538,8 +565,11 @@ _Pragma("unroll") \
 #define SCAN_K(k, at) { uint32_t bA[NA], bB[NA]; \
                         _Pragma("unroll") for (uint32_t i = 0; i < NA; ++i) { bA[i] = QUAD_BCAST(c.A[i], k); bB[i] = QUAD_BCAST(c.B[i], k); } \
                         const uint32_t bt = QUAD_BCAST(c.t, k), bpk = QUAD_BCAST(c.pk, k); \
-                        scan1(bt, bpk, bA, bB, P[at], NL == 1, p0, p1, np); if constexpr (NL == 2) scan1(bt, bpk, bA, bB, P[at + 1], true, p0, p1, np); }
-            if constexpr (NL == 1) { SCAN_K(0, 0) SCAN_K(1, 1) SCAN_K(2, 2) SCAN_K(3, 3) }
+                        scan1(bt, bpk, bA, bB, P[at], NL == 1, false, p0, p1, np); if constexpr (NL == 2) scan1(bt, bpk, bA, bB, P[at + 1], true, false, p0, p1, np); \
+                        if constexpr (BS) { \
+                            _Pragma("unroll") for (uint32_t i = 0; i < NA; ++i) { bA[i] = QUAD_BCAST(c.RA[i], k); bB[i] = QUAD_BCAST(c.RB[i], k); } \
+                            scan1(QUAD_BCAST(c.tr, k), bpk, bA, bB, P[at + 1], true, true, p0, p1, np); } }
+            if constexpr (NLX == 1) { SCAN_K(0, 0) SCAN_K(1, 1) SCAN_K(2, 2) SCAN_K(3, 3) }
             else if (half == 0u) { SCAN_K(0, 0) SCAN_K(1, 2) } else { SCAN_K(2, 0) SCAN_K(3, 2) }
 #undef SCAN_K
             if (ballot64(np != 0u)) {
@@ -553,7 +583,7 @@ _Pragma("unroll") \
             const uint32_t nit = (nruns + 63u) >> 6;
             RunRegs R0, R1, R2;
             u32x4 P0[4], P1[4], P2[4];
-            if constexpr (NL == 1) {
+            if constexpr (NLX == 1) {
                 // three batches deep: two (8 KB of buckets) in flight while one is scanned
                 prepare(0u, R0); issue(R0, 0u, P0);
                 prepare(1u, R1); issue(R1, 0u, P1);
@@ -605,9 +635,10 @@ _Pragma("unroll") \
             uint64_t dsc = 0;
             if (i < n_ovf) {
                 const uint32_t rec = runs[i];
-                uint32_t m, A[NA], B[NA];
-                context(rec >> 24, rec & 0xFFu, m, A, B);
-                const uint64_t baddr = bucket_addr(mix32(m));
+                uint32_t m, o, A[NA], B[NA];
+                context((rec >> 24) & 63u, rec & 0xFFu, m, A, B);
+                const uint32_t h = canon_hash(m, o);
+                const uint64_t baddr = bucket_addr(h, o ^ (rec >> 31));                 // (the reverse strand's records: the other bucket of the pair)
                 dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + (64u * NL - 8u * EW + 8u * KW));
             }
             return dsc;
@@ -674,22 +705,27 @@ _Pragma("unroll") \
                     const uint32_t t = t0 + 64u * u + lane;
                     if (t < total_rec) {
                         const uint32_t rec = recs[u];
-                        const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu, lenm1 = ((rec >> 16) & 0xFFu) - 1u - first;
-                        uint32_t m, A[NA], B[NA];
+                        const uint32_t q = (rec >> 24) & 63u, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu, lenm1 = ((rec >> 16) & 0xFFu) - 1u - first;
+                        const bool rev = BS && (rec >> 31) != 0u;
+                        uint32_t m, o, A[NA], B[NA];
                         context(q, ustar, m, A, B);
-                        const uint32_t h = mix32(m);
+                        if constexpr (BS) { if (rev) { uint32_t RA[NA], RB[NA]; rev_context(A, B, RA, RB);
+_Pragma("unroll") for (uint32_t x = 0; x < NA; ++x) { A[x] = RA[x]; B[x] = RB[x]; } } }
+                        const uint32_t h = canon_hash(m, o);
                         const uint32_t hlow = h & 0xFFu;
+                        // the window an entry of position `pos` is the record of starts at ustar - pos; on the reverse strand at ustar - (K-16 - pos)
+                        const uint32_t wbase = rev ? ustar - first - KM : ustar - first;
                         bool hit;
                         uint32_t rank;
                         if constexpr (W == 8) {
                             const uint32_t lo = (uint32_t)e[u].w[0], hi = (uint32_t)(e[u].w[0] >> 32), pos = (hi >> 17) & 31u;
-                            hit = (hi >> 22) == hlow && (ustar - first - pos) <= lenm1 && (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos)) == lo;
+                            hit = (hi >> 22) == hlow && (rev ? wbase + pos : wbase - pos) <= lenm1 && (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos)) == lo;
                             if constexpr (I == 2) rank = hi & 0xFFFFu; else { rank = (uint32_t)e[u].w[1]; hit = hit && rank != INVALID; }
                         } else {
                             const uint32_t z = (uint32_t)e[u].w[1], wq = (uint32_t)(e[u].w[1] >> 32), pos = (wq >> 16) & 63u;
                             uint32_t r0, r1, r2;
                             rest96(A, B, pos, r0, r1, r2);
-                            hit = (wq >> 22) == hlow && (ustar - first - pos) <= lenm1 && r0 == __builtin_amdgcn_alignbit(wq, z, 16u) &&
+                            hit = (wq >> 22) == hlow && (rev ? wbase + pos : wbase - pos) <= lenm1 && r0 == __builtin_amdgcn_alignbit(wq, z, 16u) &&
                                   r1 == (uint32_t)(e[u].w[0] >> 32) && r2 == (uint32_t)e[u].w[0];
                             rank = z & 0xFFFFu;
                         }
@@ -710,11 +746,15 @@ _Pragma("unroll") \
                         uint32_t j;
                         const uint32_t it_ = item_of(t, j);
                         const uint32_t rec = runs[ib + it_];
-                        const uint32_t q = rec >> 24, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu;
-                        const uint32_t pos = ustar - (first + j);                  // the window's minimizer position, 0..K-16
-                        uint32_t m, A[NA], B[NA];
+                        const uint32_t q = (rec >> 24) & 63u, ustar = rec & 0xFFu, first = (rec >> 8) & 0xFFu;
+                        const bool rev = BS && (rec >> 31) != 0u;
+                        // the window's minimizer position, 0..K-16 (its reverse complement's: mirrored)
+                        const uint32_t pos = rev ? KM - (ustar - (first + j)) : ustar - (first + j);
+                        uint32_t m, o, A[NA], B[NA];
                         context(q, ustar, m, A, B);
-                        const uint32_t h = mix32(m);
+                        if constexpr (BS) { if (rev) { uint32_t RA[NA], RB[NA]; rev_context(A, B, RA, RB);
+_Pragma("unroll") for (uint32_t x = 0; x < NA; ++x) { A[x] = RA[x]; B[x] = RB[x]; } } }
+                        const uint32_t h = canon_hash(m, o);
                         const uint32_t hlow = h & 0xFFu;
                         const uint64_t dsc = ost[it_];
                         lo[u] = dsc & M40; hi[u] = lo[u] + ((dsc >> 40) & 0x3FFFFFull); qs[u] = q;
@@ -845,7 +885,7 @@ _Pragma("unroll") \
 #endif
 }
 
-template <int W, int I, int SEGS, bool IRR, int MODE, int NL>
+template <int W, int I, int SEGS, bool IRR, int MODE, int NL, bool BS = false>
 static int launch_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                         int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream, uint32_t cls = 0) {
     static_assert(NL == 1 || NL == 2, "bucket size");
@@ -853,7 +893,7 @@ static int launch_lanes(const utk_image *im, const uint8_t *d_bases, const uint6
     const uint32_t wps = W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS;
     const uint32_t cap = (uint32_t)n_cu * (4u * wps / LANES_WAVES > 0 ? 4u * wps / LANES_WAVES : 1u);
     if (blocks > cap) blocks = cap;
-    classify_lanes_k<W, I, SEGS, IRR, MODE, NL><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws, cls);
+    classify_lanes_k<W, I, SEGS, IRR, MODE, NL, BS><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws, cls);
     return (int)hipGetLastError();
 }
 

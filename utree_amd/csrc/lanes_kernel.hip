@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "device_common.hpp"
 #include "wave_common.hpp"
@@ -15,7 +16,7 @@ using namespace utk;
 #endif
 
 extern "C" {
-#define PART_DECL(W_, I_, NL_) int utk_lanes_part_##W_##_##I_##_##NL_(int segs, int irr, int mode, const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, \
+#define PART_DECL(W_, I_, NL_) int utk_lanes_part_##W_##_##I_##_##NL_(int segs, int irr, int mode, int bs, const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, \
                                                                    const uint32_t *d_len, uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws,     \
                                                                    int n_cu, void *stream, uint32_t cls);
 PART_DECL(8, 2, 1) PART_DECL(8, 2, 2) PART_DECL(8, 4, 1) PART_DECL(8, 4, 2) PART_DECL(16, 2, 1) PART_DECL(16, 2, 2)
@@ -32,11 +33,23 @@ __device__ __forceinline__ void store_result(utree_result *out, uint32_t label, 
     o[0] = label; o[1] = (uint32_t)cut; o[2] = found; o[3] = uix; o[4] = sl; o[5] = ol;
 }
 
+}  // namespace
+
+// both strands in one pass: 64-byte buckets whose image stores every k-mer under its mirrored view too (UTREE_LANES_BS=0: the reverse strand
+// as a second sequence, as for the other images)
+extern "C" int utk_lanes_both_strands(const utk_image *im, int do_rc) {
+    const char *e = getenv("UTREE_LANES_BS");
+    return do_rc && im->bucket_words == 8u && (im->flags & UTREE_F_STRAND_VIEWS) && !(e && atoi(e) == 0);
+}
+
+namespace {
+
 // one instantiation of classify_lanes_k (lanes_part.hip), chosen by the image: k, label width, bucket size
 int lanes_launch(const utk_image *im, int segs, int mode, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads, int do_rc,
                  utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream, uint32_t cls) {
     const int irr = im->irr_n != 0, nl = im->bucket_words == 16u ? 2 : 1;
-#define PART(W_, I_, NL_) return utk_lanes_part_##W_##_##I_##_##NL_(segs, irr, mode, im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
+    const int bs = utk_lanes_both_strands(im, do_rc);
+#define PART(W_, I_, NL_) return utk_lanes_part_##W_##_##I_##_##NL_(segs, irr, mode, bs, im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
     if (im->W == 16) { if (nl == 2) PART(16, 2, 2); PART(16, 2, 1); }
     if (im->I == 4) { if (nl == 2) PART(8, 4, 2); PART(8, 4, 1); }
     if (nl == 2) PART(8, 2, 2);

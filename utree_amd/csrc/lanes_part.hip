@@ -5,21 +5,28 @@
 #define CAT_(a, b, c, d) a##b##_##c##_##d
 #define CAT(a, b, c, d) CAT_(a, b, c, d)
 
-extern "C" int CAT(utk_lanes_part_, LANES_W, LANES_I, LANES_NL)(int segs, int irr, int mode, const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off,
+// bs: both strands in one pass (64-byte buckets, an image with UTREE_F_STRAND_VIEWS, do_rc set)
+extern "C" int CAT(utk_lanes_part_, LANES_W, LANES_I, LANES_NL)(int segs, int irr, int mode, int bs, const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off,
                                                                 const uint32_t *d_len, uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws,
                                                                 int n_cu, void *stream, uint32_t cls) {
-#define GO(S_, M_) return irr ? launch_lanes<LANES_W, LANES_I, S_, true, M_, LANES_NL>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls) \
-                              : launch_lanes<LANES_W, LANES_I, S_, false, M_, LANES_NL>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
-    if (mode == 0 && segs == 1) GO(1, 0);                      // a batch of reads of up to 160 bases, whole
-    if (mode == 2 && segs == 16) GO(16, 2);                    // pieces of long reads
+#define GO2(S_, M_, B_) return irr ? launch_lanes<LANES_W, LANES_I, S_, true, M_, LANES_NL, B_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls) \
+                                   : launch_lanes<LANES_W, LANES_I, S_, false, M_, LANES_NL, B_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
+#if LANES_NL == 1
+#define GO(S_, M_) { if (bs && do_rc) { GO2(S_, M_, true); } GO2(S_, M_, false); }
+#else
+#define GO(S_, M_) { if (bs) return (int)hipErrorInvalidValue; GO2(S_, M_, false); }
+#endif
+    if (mode == 0 && segs == 1) GO(1, 0)                       // a batch of reads of up to 160 bases, whole
+    if (mode == 2 && segs == 16) GO(16, 2)                     // pieces of long reads
     if (mode == 1) {                                           // one length class of a mixed batch
-        if (segs == 1) GO(1, 1);
-        if (segs == 2) GO(2, 1);
-        if (segs == 4) GO(4, 1);
-        if (segs == 8) GO(8, 1);
-        if (segs == 16) GO(16, 1);
+        if (segs == 1) GO(1, 1)
+        if (segs == 2) GO(2, 1)
+        if (segs == 4) GO(4, 1)
+        if (segs == 8) GO(8, 1)
+        if (segs == 16) GO(16, 1)
     }
 #undef GO
+#undef GO2
     return (int)hipErrorInvalidValue;
 }
 

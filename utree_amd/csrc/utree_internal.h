@@ -13,7 +13,7 @@ extern "C" {
 #define UTREE_INVALID 0xFFFFFFFFu
 #define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
 #define UTREE_IMG_HEADER_BYTES 4096u
-#define UTREE_IMG_VERSION 10u                    /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region; 10: the vote records carry the file-order index */
+#define UTREE_IMG_VERSION 11u                    /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region; 10: the vote records carry the file-order index; 11: canonical minimizers, strand-paired buckets */
 #define UTREE_REGION_NB_BITS 25                  /* regions[r] = base_r << 25 | nb_r (nb_r <= 2^24)                    */
 #define UTREE_TALLY_CHUNK 8192u                  /* tally entries a wave reserves with one atomic              */
 #define UTREE_CUR_LONG 32                        /* cursors[] index of the long-read counter (own 256-B line)   */
@@ -48,6 +48,8 @@ extern "C" {
 #define UTREE_F_GENERIC   2u   /* bin table not monotone: fine_bits = 0, every lookup takes the exact path  */
 #define UTREE_F_OFF64     4u   /* bin-table offsets are 64-bit (n_nodes >= UINT32_MAX)                       */
 #define UTREE_F_VOTE_TABLE 16u /* labels are short and token-structured: vote_k takes its decisions from the table at off_vote */
+#define UTREE_F_STRAND_VIEWS 32u /* every k-mer is also stored under its mirrored view where that differs (device_common.hpp): a window's reverse
+                                    complement is found from the window's own minimizer run, in the other bucket of the pair */
 #define UTREE_F_INVALID_RANKS 8u   /* some node's label index is >= the number of labels (itree.c:929: never a hit): wave-per-read kernels only */
 
 /* At offset 0 of the flat device image (position independent: offsets, never pointers). */
@@ -56,7 +58,7 @@ typedef struct {
     uint32_t version, W, I, k;
     uint32_t fine_bits, rec_words, n_labels, flags;
     uint64_t n_nodes;
-    uint64_t n_slots;                /* buckets in the table (sum over the 256 hash regions)                */
+    uint64_t n_slots;                /* buckets in the table: two (the orientations) per pair, pairs summed over the 256 hash regions */
     uint64_t n_min;                  /* MIN records = nodes the bin table reaches                          */
     uint64_t off_table, off_mrecs, off_recs, off_coarse, off_irreg, off_label_off, off_label_blob, off_rank2ix;
     uint64_t label_blob_bytes;
@@ -64,10 +66,10 @@ typedef struct {
     uint64_t total_bytes;
     uint64_t off_vote;               /* 32 bytes per label, rank order (UTREE_F_VOTE_TABLE): see utk_vote_rec                    */
     uint32_t bucket_words, pad0;     /* 8-byte words of a bucket: 8 (64 bytes: the faster kernels) or 16 (a whole 128-byte line: the smaller image) */
-    /* Bucket addressing: region r = top 8 bits of the minimizer hash h; regions[r] = base_r << 25 | nb_r and
-     * bucket = base_r + (((h & 0xFFFFFF) * nb_r) >> 24) with 2^16 <= nb_r <= 2^24 buckets in the region, so a bucket spans at most
-     * 256 consecutive hash values and the low 8 bits of h go into the record key.  The hash is a MINIMUM of K-15 hashes, so
-     * nodes crowd towards h = 0: every region gets the number of buckets its expected share of the nodes asks for. */
+    /* Bucket addressing: region r = top 8 bits of the minimizer hash h (of the canonical 16-mer); regions[r] = base_r << 25 | nb_r and
+     * pair = base_r + (((h & 0xFFFFFF) * nb_r) >> 24) with 2^16 <= nb_r <= 2^24 PAIRS of buckets in the region, bucket = 2 pair + orientation,
+     * so a pair spans at most 256 consecutive hash values and the low 8 bits of h go into the record key.  The hash is a MINIMUM of K-15
+     * hashes, so nodes crowd towards h = 0: every region gets the number of pairs its expected share of the nodes asks for. */
     uint64_t regions[256];
 } utree_image_header;
 
@@ -115,9 +117,11 @@ int utk_widen_binix(const void *d_raw_binix, uint32_t width, int off64, void *d_
 /* counters[0] += irregular bins, counters[1] = 1 if the table is not monotone / exceeds n_nodes */
 int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes,
                  uint32_t *d_irreg, unsigned long long *d_counters, void *stream);
-int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m,
+/* dup_cap: MIN records the area at d_mrecs holds beyond the m nodes' own (second views, UTREE_F_STRAND_VIEWS); *n_min = records written,
+ * *views = 1 when every node that has a second view got it (else none did and the image must not claim the flag) */
+int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m, uint64_t dup_cap,
                   const uint64_t *d_regions, const uint64_t *h_regions, uint64_t n_buckets, uint32_t bucket_words, uint64_t *d_table, uint64_t *d_mrecs,
-                  uint32_t *d_irreg, unsigned long long *d_overflow, void *stream);
+                  uint32_t *d_irreg, unsigned long long *d_overflow, uint64_t *n_min, int *views, void *stream);
 int utk_compact_overflow(uint32_t W, uint32_t I, uint64_t *d_table, uint64_t n_buckets, uint32_t bucket_words, uint64_t *d_mrecs, uint64_t *n_kept, void *stream);
 int utk_compress_chunk(uint32_t W, uint32_t I, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
                        void *d_out, void *stream);
@@ -158,6 +162,7 @@ int utk_lanes_segs(const utk_image *im, uint32_t max_len);      /* lanes per rea
 /* long reads (ws->long_list) in pieces through the lane-per-read pass; what it cannot finish ends up on ws->long_left with its
  * count in cursors[UTREE_CUR_LONG], for utk_classify_long with long_list = long_left */
 int utk_lanes_image_ok(const utk_image *im);
+int utk_lanes_both_strands(const utk_image *im, int do_rc);      /* the BS instantiations take this batch: both strands from one pass */
 int utk_classify_long_pieces(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, int do_rc,
                              utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream);
 int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
