@@ -69,7 +69,7 @@ def resolve_defaults(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=0, help="GPUs = ranks (default: WORLD_SIZE under a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--nodes", type=int, default=1_217_000_000, help="synthetic CTR nodes (config 2: 1.217e9 = 8 GB)")
@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo --replicate torch)")
     ap.add_argument("--e2e-reads-per-rank", type=int, default=8_000_000, help="N>1: reads of each rank's shard in the file -> file leg")
     args = resolve_defaults(ap.parse_args())
+    if args.gpus <= 0:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("UTREE_BENCH_FORCE_DIST"):
         raise SystemExit(self_launch(args))
@@ -287,6 +289,7 @@ def main():
                        "parallelism": "reads sharded over %d GPU(s), CTR image replicated%s; batches alternate over %d HIP stream(s) per GPU" %
                                       (world, " by %s (%.2f s)" % (bcast_how, bcast_s) if dist_on else "", ns)},
             "roofline": roof,
+            "batch_reads": args.batch_reads, "reads_per_gpu": args.batch_reads * args.steps,
             "db_build_seconds": db_s, "classified_fraction_last_batch": nfound / args.batch_reads,
         }
         if dist_on:
@@ -536,8 +539,11 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
                 roof["random_line_ceiling_GBs"] = RANDOM_LINE_GBS
                 roof["random_line_frac"] = e["hbm_bytes_per_launch"] / t_prof / 1e9 / RANDOM_LINE_GBS
                 if "classify_lanes_k" in kernel_sig:
-                    roof["limiter_note"] = ("lane-per-read pass: one bucket fetch per minimizer run, each a random 128-byte HBM line (the bucket IS the line); the measured "
-                                            "traffic runs at random_line_frac of the rate at which this chip serves random lines -- DESIGN.md section 5c")
+                    what = ("the bucket IS the line" if tree.info.bucket_bytes == 128 else
+                            "a 64-byte bucket is half of the line it drags in; the other half is the bucket of the same minimizer in the other orientation -- "
+                            + ("with both strands in one pass (this run) both halves are used" if args.rc and kernel_sig.endswith("true>") else "used only by a search with RC"))
+                    roof["limiter_note"] = ("lane-per-read pass: one fetch per minimizer run, each a random 128-byte HBM line (%s); the measured "
+                                            "traffic runs at random_line_frac of the rate at which this chip serves random lines -- the lever is lines per read, not bytes per line" % what)
                 else:
                     roof["limiter_note"] = ("no unit is saturated: the kernel is bound by each wavefront's chain of dependent steps (LDS round trips, two bucket "
                                             "fetches, the tally) at the hardware's limit of 8 wavefronts per SIMD -- DESIGN.md section 5 has the experiments")
@@ -750,7 +756,44 @@ def e2e_leg(args, sdb, tree, files, cpu):
         out["parity_ok"] = bool(out["runs_identical"] and out.get("parity_head_vs_reference", True))
     except Exception as e:
         out["error"] = repr(e)
+    try:
+        out["db_load"] = db_load_leg(args, sdb, tree, files)
+        out["db_load_seconds"] = out["db_load"].get("seconds")
+    except Exception as e:
+        out["db_load"] = {"error": repr(e)}
     return out
+
+
+def db_load_leg(args, sdb, tree, files):
+    """"reported beside it: DB load + upload".  What XT_read32 (itree.c:733-828) is to the reference: the `.ctr` FILE of the
+    bench's database (in /dev/shm, as the reference baseline reads it) -> utree_ctr_open (header, bin table, labels) -> utree_dev_upload
+    (node dump file -> pinned -> HBM, repack, minimizer sort, buckets).  The image so built must answer like the one the steps ran on."""
+    import ctypes as C
+    import torch
+    from utree_amd import lib as ulib
+    from utree_amd.search import CtrDB, DeviceTree
+    path = files.ctr()
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    db2 = CtrDB.open(path)
+    t1 = time.time()
+    t2_tree = DeviceTree.upload(db2, tree.info.device)
+    torch.cuda.synchronize()
+    t2 = time.time()
+    ph = (C.c_double * 4)()
+    ulib.load().utree_dev_upload_seconds(ph)
+    from utree_amd import synth
+    chk = synth.make_reads(sdb, 200_000, args.read_len, seed=synth.READ_SEED + 4242, device=tree_device(tree))
+    same = bool(torch.equal(tree.classify(chk.bases, chk.off, chk.length, rc=bool(args.rc)), t2_tree.classify(chk.bases, chk.off, chk.length, rc=bool(args.rc))))
+    img = t2_tree.info.image_bytes
+    t2_tree.close()
+    db2.close()
+    return {"seconds": t2 - t0, "file_bytes": os.path.getsize(path), "image_bytes": int(img),
+            "phases_seconds": {"utree_ctr_open (header, bin table, labels)": t1 - t0, "device + image allocation, labels": ph[0],
+                               "node dump: file -> pinned -> HBM, repacked as it arrives": ph[1], "bin-table check, minimizer sort, buckets, packing": ph[2]},
+            "file_GBps": os.path.getsize(path) / max(1e-9, ph[1]) / 1e9,
+            "note": "the .ctr file is in /dev/shm (page cache): a cold file adds its storage's read time",
+            "classifies_like_the_benchmarked_image": same}
 
 
 def tree_device(tree):

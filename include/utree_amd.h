@@ -95,6 +95,9 @@ size_t utree_dev_image_bytes(const utree_ctr *ctr, int fine_bits);
 /* Stream the node dump (from the .ctr file or the host copy given to utree_ctr_from_memory) to `device`
  * and build the image there. */
 int utree_dev_upload(const utree_ctr *ctr, int device, int fine_bits, utree_dev **out);
+/* seconds of the calling process's last utree_dev_upload: {device + image allocation and labels, node dump file -> pinned memory -> HBM
+ * (repacked as it arrives), bin-table check + minimizer sort + buckets, all of it} -- XT_read32's time (itree.c:733-828) has no such split */
+int utree_dev_upload_seconds(double *h_out4);
 /* Build from raw on-disk pieces that already sit in HBM on `device`: `d_binix` = (2^24+1) entries of
  * ctr's binix_width, `d_records` = n_nodes*SZ packed bytes.  If `d_image` is non-NULL it must have
  * utree_dev_image_bytes() bytes and the image is built in place (caller-owned, e.g. a torch tensor). */

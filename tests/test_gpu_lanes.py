@@ -336,6 +336,32 @@ def test_a_workspace_too_small_is_reported_not_overrun(torch_cuda, tmp_path, mon
     tree.close()
 
 
+@pytest.mark.parametrize("hook,value", [("UTREE_TEST_LONG_CAP", "256"), ("UTREE_TEST_LONG_CAP", "100"), ("UTREE_TEST_PIECES_CAP", "300"), ("UTREE_TEST_PIECES_CAP", "7")])
+def test_more_long_reads_or_pieces_than_the_tables_hold_is_reported(torch_cuda, hook, value, tmp_path, monkeypatch):
+    """The tables of the pieces pass (long reads through the lane kernels) are sized from the batch's total_bases / max_len.  With the
+    test hooks that shrink the capacities -- 256: a multiple of pieces_k's workgroup, where only a check that does not depend on the
+    thread index fires -- the batch is reported (UTREE_E_DEVICE), every consumer of the lists stops at the capacity (the lists' areas
+    keep their size, so a kernel that ran on would read unwritten entries: the results of the next batch would show it), and the next
+    batch, hook off, equals the oracle."""
+    from utree_amd import lib
+    d = OwnDB(tmp_path, seed=5)
+    db = CtrDB.open(d.ctr)
+    tree = DeviceTree.upload(db, 0)
+    o = orc.OracleDB.load(d.ctr)
+    rng = np.random.default_rng(8)
+    data = fasta_bytes(random_reads(rng, d, 400, 2200, 9000, hit_frac=0.8) + random_reads(rng, d, 3000, 100, 160, hit_frac=0.8))
+    want = oracle_text(o, data, tmp_path, rc=True)
+    monkeypatch.setenv("UTREE_LANE_PASS", "1")
+    monkeypatch.setenv(hook, value)
+    with pytest.raises(lib.UtreeError) as ei:
+        classify_fasta_bytes(db, tree, data, rc=True)
+    assert ei.value.code == lib.E_DEVICE
+    monkeypatch.delenv(hook)
+    assert classify_fasta_bytes(db, tree, data, rc=True) == want
+    assert tree.kernel_name().startswith("classify_lanes_k<8, 2, 16, false, 2,")
+    tree.close()
+
+
 @pytest.mark.parametrize("name,rc", [("toy", 1), ("k64", 1), ("ix32", 0), ("vote", 0), ("katq2", 0)])
 def test_line_sized_buckets_option(torch_cuda, name, rc, tmp_path, monkeypatch):
     """UTREE_BUCKET_BYTES=128 builds the image with one bucket per 128-byte HBM line (a third smaller; the kernels' NL = 2

@@ -341,6 +341,43 @@ def test_output_that_cannot_seek_is_written_in_order(torch_cuda, tmp_path, monke
     assert got["bytes"] == util.fixture_bytes("toy_out_rc.txt.gz")
 
 
+@pytest.mark.parametrize("where", [0.02, 0.55, 0.97])
+def test_fifo_output_and_a_record_the_device_pipeline_hands_over(torch_cuda, where, tmp_path, monkeypatch):
+    """Output that cannot seek AND a late chunk the device pipeline does not take (a NUL byte in a sequence line: fgets / strlen
+    semantics, the host framing's business): the chunks in front of it are already in the pipe, so the host pipeline continues from
+    that chunk on the same descriptor -- the reader sees every line once, in order: the oracle's file.  (Starting over, as for a
+    regular file, would send the first chunks twice: O_TRUNC does nothing to a pipe.)"""
+    import threading
+    monkeypatch.setenv("UTREE_CHUNK_BYTES", "20000")
+    db, tree = tree_for("toy")
+    o = orc.OracleDB.load(util.fixture_ctr("toy"))
+    data = bytearray(util.fixture_bytes("toy_reads.fa.gz")[:600_000])
+    data = data[: data.rfind(b"\n>") + 1]
+    at = data.index(b"\n", data.index(b"\n>", int(where * len(data))) + 1) + 30          # inside a sequence line
+    assert data[at] in b"ACGTacgtN"
+    data[at] = 0
+    fa, fifo, want = tmp_path / "in.fa", tmp_path / "out.fifo", tmp_path / "want.txt"
+    fa.write_bytes(bytes(data))
+    ocode, nr, good, err = o.search_file(str(fa), str(want), threads=4, rc=True)
+    assert ocode == 0
+    os.mkfifo(fifo)
+    got = {}
+
+    def reader():
+        with open(fifo, "rb") as f:
+            got["bytes"] = f.read()
+    th = threading.Thread(target=reader)
+    th.start()
+    code, st = search_gg(db, [tree], str(fa), str(fifo), rc=True, threads=4)
+    th.join(60)
+    assert code == lib.OK and st.pipeline == 0                      # the host pipeline finished the file ...
+    assert got["bytes"] == want.read_bytes()                        # ... and nothing came twice
+    assert st.n_reads == nr and st.good_finds == good
+    # the same file into a regular output: started over by the host pipeline, same bytes
+    code, st, out = run(db, [tree], bytes(data), tmp_path, rc=True)
+    assert code == lib.OK and out == want.read_bytes() and st.n_reads == nr
+
+
 def test_three_byte_records_fill_a_chunk(torch_cuda, tmp_path):
     """A record can be ">\\n\\n" (the reference reads it as a sequence of length 0 and prints nothing): a chunk of them holds
     more reads than bytes / 4.  Every read must be framed, and the real reads among them classified."""

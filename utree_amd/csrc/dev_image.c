@@ -66,14 +66,46 @@ static uint32_t bucket_words_default(uint64_t n_nodes, uint32_t W) {
  * 2: 9 of 16 entries, image 17.6 GiB, 0.3 overflowing buckets per 150 bp read), 64-byte buckets to 37.5 % (3 of 8, 22.9 GiB, 0.28).  The
  * dense end of the hash range has several nodes per hash VALUE, so a bucket there holds the nodes of one, two or three values: a
  * mixture, not one Poisson mean -- which is why the small buckets want the lower load (DESIGN.md section 3 has the sweeps). */
+/* share of a bucket's NODES that sit in a bucket of more than `cap` of them, the bucket's load being Poisson(lam): sum_{k > cap} k P(k) / lam */
+static double pois_tail_nodes(double lam, uint32_t cap) {
+    if (lam <= 0) return 0;
+    double p = exp(-lam), s = 0;
+    for (uint32_t k = 1; k <= cap; ++k) { p *= lam / k; s += k * p; }
+    s = 1.0 - s / lam;
+    return s < 0 ? 0 : s;
+}
+/* UTREE_CANON_MODE 1: only every other hash value is some canonical 16-mer's, so a pair of `v` = 2^24 / nb hash values holds Binomial(v, 1/2)
+ * occupied ones, each with Poisson(lam1) nodes per bucket -- lumps: the share of the region's nodes in overflowing buckets */
+static double lumpy_overflow(double nb, double expect, uint32_t cap) {
+    const double v = 16777216.0 / nb, lam1 = expect / 16777216.0;
+    if (v > 48.0) return pois_tail_nodes(expect / (2.0 * nb), cap);    /* dozens of values per pair: no lumps to speak of */
+    const int lo = (int)floor(v);
+    const double fr = v - lo;
+    double tot = 0, totw = 0;
+    for (int which = 0; which < 2; ++which) {
+        const int V = lo + which;
+        const double w = which ? fr : 1.0 - fr;
+        if (!V || w <= 0) continue;
+        double pn = pow(0.5, V);                                        /* Binomial(V, 1/2): n = 0 */
+        for (int n = 0; n <= V && n <= 64; ++n) {
+            const double mean = n * lam1;
+            tot += w * pn * mean * pois_tail_nodes(mean, cap); totw += w * pn * mean;
+            pn = pn * (double)(V - n) / (double)(n + 1);
+        }
+    }
+    return totw > 0 ? tot / totw : 0;
+}
+
 static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32_t bucket_words, uint32_t F, uint64_t regions[256]) {
-    const double m = 4.0 * W - 15.0;
+    /* (image version 11: the region table counts PAIRS of buckets -- the two orientations of a canonical 16-mer --, a pair is sized for
+     * 2 TARGET nodes) */
+    const double m = (UTREE_CANON_MODE == 2 ? 2.0 : 1.0) * (4.0 * W - 15.0);   /* mode 2: the smallest of 2 (K - 15) hashes */
     const uint32_t cap_entries = bucket_words / utree_rec_words(W, I);
     const char *te = getenv("UTREE_BUCKET_TARGET");                     /* nodes per bucket; experiments only */
     const double target = te && atof(te) > 0 ? atof(te) : (bucket_words == 16 ? 0.5625 : 0.375) * cap_entries;
-    /* (image version 11: the region table counts PAIRS of buckets -- the two orientations of a canonical 16-mer --, a pair is sized for
-     * 2 TARGET nodes.  Only half of the hash values are some canonical 16-mer's, so where a pair is one hash value -- the dense end of the
-     * range -- every other pair is empty: config 2's table grows by a third; the lookups pay nothing for it) */
+    const char *se = getenv("UTREE_LUMP_SLACK");                        /* experiments only */
+    const double slack = se ? atof(se) : 1.5;
+    const double p0 = pois_tail_nodes(target, cap_entries);
     const uint64_t nb_max = 1ull << (16 + (F > 8 ? 8 : F)), nb_min = 1ull << 16;
     uint64_t base = 0;
     for (int r = 0; r < 256; ++r) {
@@ -82,6 +114,10 @@ static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32
         uint64_t nb = want >= (double)nb_max ? nb_max : (uint64_t)want;
         if (nb < nb_min) nb = nb_min;
         if (nb > nb_max) nb = nb_max;
+        /* mode 1: more pairs where a pair holds so few hash values that the occupied ones make lumps: up to the overflow share the design
+         * load has without them (times `slack`), at most one pair per value */
+        if (UTREE_CANON_MODE != 2 && slack > 0)
+            while (nb < nb_max && lumpy_overflow((double)nb, expect, cap_entries) > slack * p0 + 1e-4) { nb += nb / 20 + 1; if (nb > nb_max) nb = nb_max; }
         if (regions) regions[r] = (base << UTREE_REGION_NB_BITS) | nb;
         base += nb;
     }
@@ -474,6 +510,14 @@ int utree_dev_build(const utree_ctr *ctr, int device, int fine_bits, const void 
     return UTREE_OK;
 }
 
+/* where the calling process's last utree_dev_upload spent its time (bench.py's database-load figure) */
+static double g_upload_s[4];
+int utree_dev_upload_seconds(double *h_out4) {
+    if (!h_out4) return UTREE_E_ARG;
+    for (int i = 0; i < 4; ++i) h_out4[i] = g_upload_s[i];
+    return UTREE_OK;
+}
+
 int utree_dev_upload(const utree_ctr *ctr, int device, int fine_bits, utree_dev **out) {
     if (!ctr || !out) return UTREE_E_ARG;
     *out = NULL;
@@ -484,7 +528,9 @@ int utree_dev_upload(const utree_ctr *ctr, int device, int fine_bits, utree_dev 
     if (rc) return rc;
     double t1 = now_s(), t2 = t1, t3 = t1;
     const size_t SZ = ctr->info.SZ;
-    const size_t chunk_recs = ((size_t)48 << 20) / SZ;
+    /* (the node dump goes file -> pinned memory -> HBM in 128 MiB pieces, two in flight; the page-cache copy is the cost -- one thread moves
+     * ~5 GB/s -- so a small team reads each piece: 8.6 GB in 0.6 s instead of 1.7) */
+    const size_t chunk_recs = ((size_t)128 << 20) / SZ;
     const size_t chunk_bytes = chunk_recs * SZ;
     void *h_pin[2] = {NULL, NULL}, *d_raw[2] = {NULL, NULL}, *d_binix = NULL;
     hipEvent_t ev[2] = {NULL, NULL};
@@ -504,12 +550,18 @@ int utree_dev_upload(const utree_ctr *ctr, int device, int fine_bits, utree_dev 
         size_t bytes = (size_t)cnt * SZ;
         HIPCHK(hipEventSynchronize(ev[slot]));                 /* the pinned buffer is free again */
         if (fd >= 0) {
-            size_t got = 0;
-            while (got < bytes) {
-                ssize_t r = pread(fd, (char *)h_pin[slot] + got, bytes - got, (off_t)(ctr->records_file_off + done * SZ + got));
-                if (r <= 0) { rc = UTREE_E_FORMAT; goto fail; }            /* "Error in reading tree." itree.c:768 */
-                got += (size_t)r;
+            int T = 8, bad = 0;
+            if ((size_t)T > bytes / ((size_t)4 << 20) + 1) T = (int)(bytes / ((size_t)4 << 20) + 1);
+#pragma omp parallel for num_threads(T) schedule(static, 1) reduction(| : bad)
+            for (int t = 0; t < T; ++t) {
+                size_t a = bytes * (size_t)t / (size_t)T, e = bytes * (size_t)(t + 1) / (size_t)T;
+                while (a < e) {
+                    ssize_t r = pread(fd, (char *)h_pin[slot] + a, e - a, (off_t)(ctr->records_file_off + done * SZ + a));
+                    if (r <= 0) { bad |= 1; break; }
+                    a += (size_t)r;
+                }
             }
+            if (bad) { rc = UTREE_E_FORMAT; goto fail; }                   /* "Error in reading tree." itree.c:768 */
         } else memcpy(h_pin[slot], ctr->h_records + done * SZ, bytes);
         HIPCHK(hipMemcpyAsync(d_raw[slot], h_pin[slot], bytes, hipMemcpyHostToDevice, NULL));
         rc = build_chunk(&b, d_raw[slot], done, cnt);
@@ -525,6 +577,7 @@ int utree_dev_upload(const utree_ctr *ctr, int device, int fine_bits, utree_dev 
     rc = build_finish(&b, d_binix);
     t3 = now_s();
     if (timing_on()) fprintf(stderr, "[utree_amd] image: alloc+labels %.3f s, stream+repack nodes %.3f s, validate+sort+table %.3f s\n", t1 - t0, t2 - t1, t3 - t2);
+    g_upload_s[0] = t1 - t0; g_upload_s[1] = t2 - t1; g_upload_s[2] = t3 - t2; g_upload_s[3] = t3 - t0;
     if (!rc) *out = b.d;
     b.d = NULL;
 fail:
@@ -763,6 +816,9 @@ static void carve(const utree_dev *d, void *ws, uint32_t n_reads, uint64_t total
         w->long_left = (uint32_t *)(b + off); off = align_up(off + cap * 4, 256);
         /* the long reads' tally lists at fixed places behind everything the other passes reserve (no reservation traffic) */
         w->ltally_base = (uint64_t)((uint64_t *)(b + off) - w->tally); off = align_up(off + cap * UTREE_LONG_SLOTS * 8, 256);
+        /* test hooks: capacities too small on purpose (the areas keep their size): the kernels must report, not overrun */
+        { const char *e = getenv("UTREE_TEST_LONG_CAP"); if (e && atoll(e) > 0 && (uint64_t)atoll(e) < w->n_long_cap) w->n_long_cap = (uint32_t)atoll(e); }
+        { const char *e = getenv("UTREE_TEST_PIECES_CAP"); if (e && atoll(e) > 0 && (uint64_t)atoll(e) < w->n_pieces_cap) w->n_pieces_cap = (uint64_t)atoll(e); }
     }
     *bytes = (size_t)off;
 }

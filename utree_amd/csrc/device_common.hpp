@@ -142,11 +142,30 @@ __host__ __device__ __forceinline__ uint32_t rc16(uint32_t m) {
     const uint32_t y = __builtin_bitreverse32(m);
     return ~(((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1));
 }
-// hash of a 16-mer's canonical form and the orientation bit (0 also for a 16-mer that is its own reverse complement)
-__host__ __device__ __forceinline__ uint32_t canon_hash(uint32_t m, uint32_t &o) {
-    const uint32_t r = rc16(m);
-    o = m > r ? 1u : 0u;
+// The strand-independent hash of a 16-mer m with reverse complement r (UTREE_CANON_MODE, utree_internal.h) and its orientation bit: 1 when the
+// hash is the reverse complement's.  of: as view f has it (0 for a 16-mer that is its own reverse complement), og: as view g has it (1).
+__host__ __device__ __forceinline__ uint32_t canon_of(uint32_t m, uint32_t r, uint32_t &of, uint32_t &og) {
+#if UTREE_CANON_MODE == 2
+    const uint32_t hf = mix32(m), hr = mix32(r);
+    of = hr < hf ? 1u : 0u; og = hr <= hf ? 1u : 0u;
+    return hr < hf ? hr : hf;
+#else
+    of = m > r ? 1u : 0u; og = m >= r ? 1u : 0u;
     return mix32(m > r ? r : m);
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t canon_hash(uint32_t m, uint32_t &o) {
+    uint32_t og;
+    return canon_of(m, rc16(m), o, og);
+}
+// the hash alone (the search kernels' walk has m and r rolling)
+__host__ __device__ __forceinline__ uint32_t canon_key(uint32_t m, uint32_t r) {
+#if UTREE_CANON_MODE == 2
+    const uint32_t hf = mix32(m), hr = mix32(r);
+    return hr < hf ? hr : hf;
+#else
+    return mix32(m > r ? r : m);
+#endif
 }
 // 16-mers are ordered by their hash WITHOUT its MIN_LOW_BITS low bits (leftmost on ties): the search kernels then fit
 // { hash bits | position in the tile } into 32 bits and slide the minimum with one v_min_u32 per step.  The bucket is still
@@ -197,10 +216,11 @@ template <int W> __device__ __forceinline__ void minimizer_views(uint64_t khi, u
     uint32_t best = 0xFFFFFFFFu;
     hf = hg = of = og = pf = pg = 0;
     for (uint32_t j = 0; j <= 4u * W - 16u; ++j) {
-        const uint32_t m = mer_at<W>(khi, klo, j), r = rc16(m);
-        const uint32_t hh = mix32(m > r ? r : m), key = hh >> MIN_LOW_BITS;
-        if (j == 0 || key < best) { best = key; hf = hh; of = m > r ? 1u : 0u; pf = j; }
-        if (j == 0 || key <= best) { hg = hh; og = m >= r ? 1u : 0u; pg = j; }
+        const uint32_t m = mer_at<W>(khi, klo, j);
+        uint32_t o1, o2;
+        const uint32_t hh = canon_of(m, rc16(m), o1, o2), key = hh >> MIN_LOW_BITS;
+        if (j == 0 || key < best) { best = key; hf = hh; of = o1; pf = j; }
+        if (j == 0 || key <= best) { hg = hh; og = o2; pg = j; }
     }
 }
 // view f alone

@@ -91,12 +91,11 @@ __device__ __forceinline__ void build_minkeys_n(const uint32_t *s, uint32_t sh, 
     for (uint32_t c = 0; c < NCH; ++c) {
         // (image version 11: a 16-mer is ranked and addressed by the hash of its canonical form; which orientation the read holds picks the
         // bucket of the pair -- one bit per position, kept as the chunk's ballot)
-        const uint32_t r = rc16(x[c]);
-        const bool o = x[c] > r;
-        const uint32_t h = mix32(o ? r : x[c]);
+        uint32_t o;
+        const uint32_t h = canon_hash(x[c], o);
         Kl[c * 64] = ((h & ~MIN_POS_MASK) | lo) + c * 64;
         Hl[c * 64] = h;
-        Ob[c] = __builtin_amdgcn_ballot_w64(o);
+        Ob[c] = __builtin_amdgcn_ballot_w64(o != 0u);
     }
     Kl[NCH * 64] = ~0u;
     wave_lds_fence();

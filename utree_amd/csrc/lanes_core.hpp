@@ -175,7 +175,10 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     unsigned long long chunk_base = 0;
     uint32_t chunk_left = 0;
     const uint32_t wave_gid = blockIdx.x * LANES_WAVES + wv;
-    if constexpr (PIECE) n_reads = (uint32_t)ws.cursors[UTREE_CUR_PIECES];    // (the items: pieces)
+    if constexpr (PIECE) {                                              // (the items: pieces -- as many as were listed: pieces_k stops, and reports, at the capacity)
+        const unsigned long long np = ws.cursors[UTREE_CUR_PIECES];
+        n_reads = (uint32_t)(np < ws.n_pieces_cap ? np : ws.n_pieces_cap);
+    }
     if constexpr (LISTED) n_reads = (uint32_t)ws.cursors[UTREE_CUR_CLASS + cls];
     if constexpr (MODE != 0) { if (!n_reads) return; }                  // (a length class no read of the batch fell into, no long read: nothing to set up)
     if constexpr (MODE == 0) { if (cls && !ws.cursors[UTREE_CUR_CLASS]) return; }   // (a mixed batch without a read of one lane)
@@ -321,7 +324,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
             // (a 16-mer's rank is the hash of its canonical form, the smaller of the two: one xor, one funnel shift and one minimum per
             // position on top of the forward walk)
 #define ROLL16(p_) { const uint32_t b_ = (sl[(p_) >> 4] >> (30u - 2u * ((p_) & 15u))) & 3u; m16 = (m16 << 2) | b_; r16 = __builtin_amdgcn_alignbit(b_ ^ 3u, r16, 2u); }
-#define CKEY() (mix32(umin(m16, r16)) & ~0x1FFu)
+#define CKEY() (canon_key(m16, r16) & ~0x1FFu)
             // (a window's bin is its first 12 bases: the top 24 bits of the 16-mer it starts with -- every 16-mer passes here)
             auto irregular = [&](uint32_t m, uint32_t u) {                  // u: the 16-mer's first base = the window it starts
                 if constexpr (IRR) {

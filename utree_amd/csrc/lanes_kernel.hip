@@ -61,16 +61,18 @@ int lanes_launch(const utk_image *im, int segs, int mode, const uint8_t *d_bases
 // pieces_k: every entry of ws.long_list is cut into pieces of PW windows; one atomic per read reserves its places on ws.pieces
 __global__ __launch_bounds__(256) void pieces_k(const uint32_t *__restrict__ len, uint32_t K, uint32_t PW, utk_workspace ws) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
+    uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
+    // (the capacities are bounds on what a batch of the stated total_bases / max_len can hold; a batch beyond them is reported, and every
+    // consumer of the lists stops at the capacity: no kernel reads an entry that was not written or writes past a table)
+    if (n_long > ws.n_long_cap) { if (i == 0) ws.cursors[UTREE_CUR_ERROR] = UTREE_DEVERR_LONG_CAP; n_long = ws.n_long_cap; }
     if (i >= n_long) return;
-    if (i >= ws.n_long_cap) { ws.cursors[UTREE_CUR_ERROR] = UTREE_DEVERR_LONG_CAP; return; }   // (the capacity is the bound on such reads: a caller's total_bases was too small)
     const uint64_t L = len[ws.long_list[i]];
     const uint64_t nwin = L >= K ? L - K + 1 : 0;
     const uint32_t np = (uint32_t)((nwin + PW - 1) / PW);
     if (!np) return;
     const unsigned long long at = atomicAdd(&ws.cursors[UTREE_CUR_PIECES], (unsigned long long)np);
-    if (at + np > ws.n_pieces_cap) { ws.cursors[UTREE_CUR_ERROR] = UTREE_DEVERR_PIECES_CAP; return; }
-    for (uint32_t p = 0; p < np; ++p) ws.pieces[at + p] = ((uint64_t)i << 32) | p;
+    if (at + np > ws.n_pieces_cap) ws.cursors[UTREE_CUR_ERROR] = UTREE_DEVERR_PIECES_CAP;
+    for (uint32_t p = 0; p < np && at + p < ws.n_pieces_cap; ++p) ws.pieces[at + p] = ((uint64_t)i << 32) | p;   // (every entry below the capacity is some read's)
 }
 
 // finish_long_k: one wavefront per long read, a lane per slot of its table: the distinct labels in strcmp order (= ascending rank) with
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(256) void pieces_k(const uint32_t *__restrict__ len
 // on ws.long_left for classify_long_k
 __global__ __launch_bounds__(256) void finish_long_k(utree_result *__restrict__ out, utk_workspace ws) {
     const uint32_t lane = lane_id();
-    const uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
+    uint32_t n_long = (uint32_t)ws.cursors[UTREE_CUR_LONG];
+    if (n_long > ws.n_long_cap) n_long = ws.n_long_cap;                  // (pieces_k has reported it)
     // (a resident grid walking the entries: a workgroup per four reads is bound by the rate at which workgroups are dispatched)
     for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n_long; i += gridDim.x * 4u) {
     const uint32_t r = ws.long_list[i];

@@ -80,7 +80,7 @@ typedef struct {
     const utree_ctr *ctr;
     gpu_ctx *G; int n_dev;
     int fd, fo;                                 /* input, output                                            */
-    off_t out_pos;
+    off_t out_pos, start_off;                   /* start_off: where the input begins for this pipeline (behind what the device pipeline wrote to a pipe) */
     int do_rc, host_threads;
     const utree_rank_params *rank;              /* non-NULL: the rank-specific `xtree-search` (rank.c), one device  */
     int input_format;                           /* UTREE_INPUT_*: opt-in FASTQ / multi-line FASTA (+ gzip via zlib)   */
@@ -120,7 +120,7 @@ static void set_state(pipe_t *P, slot_t *s, int state) {
 /* ---- stage 1: read + frame ------------------------------------------------------------------- */
 static void *reader_main(void *arg) {
     pipe_t *P = (pipe_t *)arg;
-    off_t file_pos = 0;
+    off_t file_pos = P->start_off;
     size_t carry = 0;                           /* bytes of an incomplete read carried into the next chunk */
     const uint8_t *carry_src = NULL;
     int eof = 0;
@@ -339,20 +339,27 @@ static int search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const 
     if (!ctr || !devs || n_dev < 1 || !fasta_path || !out_path || input_format < 0 || input_format > UTREE_INPUT_AUTO) return UTREE_E_ARG;
     int rc = UTREE_OK;
     uint64_t dev_printed = 0;
+    utree_search_resume resume;
+    memset(&resume, 0, sizeof resume); resume.fo = -1;
     /* The GG search on the reference's input format takes the device text pipeline (search_dev.c); it hands back input it
      * does not take -- malformed records, NUL bytes, lines fgets would split -- and the host framing below then reproduces
      * the reference on it case by case.  UTREE_HOST_TEXT=1 forces the host pipeline (tests, A/B). */
     if (!rank && input_format == UTREE_INPUT_REFERENCE && !getenv("UTREE_HOST_TEXT")) {
-        rc = utree_search_file_device(ctr, devs, n_dev, fasta_path, out_path, do_rc, host_threads, stats, &dev_printed);
+        rc = utree_search_file_device(ctr, devs, n_dev, fasta_path, out_path, do_rc, host_threads, stats, &dev_printed, &resume);
         if (rc != UTREE_RETRY_HOST) return rc;
         rc = UTREE_OK;
     }
     double t_start = now_s();
     pipe_t *P = (pipe_t *)calloc(1, sizeof *P);
-    if (!P) return UTREE_E_NOMEM;
+    if (!P) { if (resume.fo >= 0) close(resume.fo); return UTREE_E_NOMEM; }
     P->ctr = ctr; P->n_dev = n_dev; P->do_rc = do_rc; P->rank = rank; P->input_format = input_format;
     P->progress_printed = dev_printed;
     P->fd = open(fasta_path, O_RDONLY);
+    if (resume.fo >= 0) {
+        /* the output is a pipe and the device pipeline has written the chunks in front of `in_off`: go on from there, on the same descriptor */
+        P->fo = resume.fo; P->start_off = (off_t)resume.in_off;
+        P->st.n_reads = resume.n_reads; P->st.good_finds = resume.good_finds; P->st.bytes_in = resume.bytes_in; P->st.bytes_out = resume.bytes_out;
+    } else
     P->fo = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);                   /* fopen(outfile, "wb"), itree.c:834 */
     if (P->fd < 0 || P->fo < 0) {                                                 /* itree.c:835 */
         if (P->fd >= 0) close(P->fd);

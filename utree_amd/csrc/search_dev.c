@@ -182,6 +182,9 @@ struct dpipe {
     uint64_t printed;                           /* progress lines already on stdout (a host re-run must not repeat them) */
     uint64_t n_reads, good, next_progress, bytes_in;
     int rc, stop;                               /* first error; UTREE_RETRY_HOST = input for the host path          */
+    /* seq_out: a chunk that needs the host framing does not stop the chunks in front of it -- they are written, in order, and the host
+     * pipeline continues from that chunk's first byte (search_dev.h: utree_search_resume); the chunks behind it are dropped */
+    int retry_set; uint64_t retry_at; off_t retry_off;
     uint8_t tail[(64 << 10) + 8];
 };
 
@@ -192,6 +195,16 @@ static void dfail(dpipe *P, int rc) {
     pthread_cond_broadcast(&P->cv);
     pthread_mutex_unlock(&P->mu);
 }
+
+/* chunk `c`, which starts at byte `off` of the input, is not for this pipeline (called with or without the lock: `locked`) */
+static void dretry(dpipe *P, uint64_t c, off_t off, int locked) {
+    if (!locked) pthread_mutex_lock(&P->mu);
+    if (!P->seq_out) { if (!P->rc) P->rc = UTREE_RETRY_HOST; P->stop = 1; }
+    else if (!P->retry_set || c < P->retry_at) { P->retry_set = 1; P->retry_at = c; P->retry_off = off; }
+    pthread_cond_broadcast(&P->cv);
+    if (!locked) pthread_mutex_unlock(&P->mu);
+}
+#define DROPPED(P, c) ((P)->retry_set && (c) > (P)->retry_at)      /* a chunk behind the one the host pipeline continues from */
 
 /* Next chunk [off, off+len): ends after a '\n' that a '>' follows, or at the end of the file.  Called with the lock held.
  * Returns 0 = none left, 1 = chunk, -1 = no record boundary inside a chunk's worth of bytes. */
@@ -234,10 +247,10 @@ static void *lane_main(void *arg) {
     for (;;) {
         off_t off = 0; size_t len = 0; int final = 0; uint64_t c = 0;
         pthread_mutex_lock(&P->mu);
-        int got = P->stop ? 0 : take_chunk(P, &off, &len, &final, &c);
+        int got = (P->stop || P->retry_set) ? 0 : take_chunk(P, &off, &len, &final, &c);
+        if (got < 0) dretry(P, P->n_taken, P->next_off, 1);                    /* no record boundary within a chunk's bytes */
         pthread_mutex_unlock(&P->mu);
-        if (got < 0) { dfail(P, UTREE_RETRY_HOST); return NULL; }
-        if (!got) return NULL;
+        if (got <= 0) return NULL;
         if (!b->stream || b->ws_rc < P->do_rc) {                  /* first chunk of this lane: its buffers */
             int arc = lane_alloc(L->dev, b, P->do_rc);
             if (arc) { dfail(P, arc); return NULL; }
@@ -274,7 +287,7 @@ static void *lane_main(void *arg) {
         double t2 = now_s();
         L->t_frame += t2 - t1;
         const utk_text_meta m1 = *b->h_meta;
-        if (m1.flags || (m1.n_lines & 1u) || m1.n_lines > 2 * DMAX_READS || m1.n_lines / 2 > grid_reads) { dfail(P, UTREE_RETRY_HOST); return NULL; }
+        if (m1.flags || (m1.n_lines & 1u) || m1.n_lines > 2 * DMAX_READS || m1.n_lines / 2 > grid_reads) { dretry(P, c, off, 0); return NULL; }
         const uint32_t nr = m1.n_lines / 2;
         /* ---- classify (kernels.hip), then the output text ---- */
         if (nr) {
@@ -291,7 +304,7 @@ static void *lane_main(void *arg) {
         L->t_classify += t3 - t2;
         const utk_text_meta m2 = *b->h_meta;
         if (nr) { int pe = utree_classify_poll(L->dev); if (pe) { dfail(P, pe); return NULL; } }   /* the batch's error word came back with it */
-        if (m2.flags || m2.out_bytes > DOUT_BYTES) { dfail(P, UTREE_RETRY_HOST); return NULL; }
+        if (m2.flags || m2.out_bytes > DOUT_BYTES) { dretry(P, c, off, 0); return NULL; }
         if (nr && m2.out_bytes) {
             LK(utk_text_format(&L->dev->kimg, ((struct utree_search_ctx *)L->dev->search_ctx)->d_ix2rank, b->d_in, b->d_res, b->d_name_off,
                                b->d_name_len, nr, b->d_line_len, b->d_line_off, b->d_scan, b->scan_bytes, b->d_out, DOUT_BYTES, b->d_meta, 1,
@@ -301,8 +314,8 @@ static void *lane_main(void *arg) {
         /* ---- the chunk's place in the output: after the text of every earlier chunk (input order, like one thread) ---- */
         off_t base;
         pthread_mutex_lock(&P->mu);
-        while (P->published != c && !P->stop) pthread_cond_wait(&P->cv, &P->mu);
-        if (P->stop) { pthread_mutex_unlock(&P->mu); hipStreamSynchronize(b->stream); return NULL; }
+        while (P->published != c && !P->stop && !DROPPED(P, c)) pthread_cond_wait(&P->cv, &P->mu);
+        if (P->stop || DROPPED(P, c)) { pthread_mutex_unlock(&P->mu); hipStreamSynchronize(b->stream); return NULL; }
         base = P->cum_out;
         P->cum_out += (off_t)m2.out_bytes;
         P->n_reads += nr; P->good += nr ? m2.good_finds : 0; P->bytes_in += len;
@@ -322,8 +335,8 @@ static void *lane_main(void *arg) {
         size_t done = 0;
         if (P->seq_out) {                                           /* wait for every earlier chunk's text to be out */
             pthread_mutex_lock(&P->mu);
-            while (P->written != c && !P->stop) pthread_cond_wait(&P->cv, &P->mu);
-            const int stop = P->stop;
+            while (P->written != c && !P->stop && !DROPPED(P, c)) pthread_cond_wait(&P->cv, &P->mu);
+            const int stop = P->stop || DROPPED(P, c);
             pthread_mutex_unlock(&P->mu);
             if (stop) return NULL;
         }
@@ -367,9 +380,10 @@ int utree_search_prepare(const utree_ctr *ctr, utree_dev **devs, int n_dev, int 
 }
 
 int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
-                             int do_rc, int host_threads, utree_search_stats *stats, uint64_t *progress_printed) {
+                             int do_rc, int host_threads, utree_search_stats *stats, uint64_t *progress_printed, utree_search_resume *resume) {
     const double t_start = now_s();
     if (progress_printed) *progress_printed = 0;
+    if (resume) { memset(resume, 0, sizeof *resume); resume->fo = -1; }
     dpipe *P = (dpipe *)calloc(1, sizeof *P);
     if (!P) return UTREE_E_NOMEM;
     P->ctr = ctr; P->do_rc = do_rc; P->next_progress = 1048576;
@@ -382,10 +396,14 @@ int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, 
         free(P);
         return UTREE_E_IO;
     }
-    if (!S_ISREG(sb.st_mode)) { close(P->fd); close(P->fo); free(P); return UTREE_RETRY_HOST; }   /* a pipe: no pread */
+    P->seq_out = lseek(P->fo, 0, SEEK_CUR) == (off_t)-1;                          /* `out` is a pipe, a FIFO, a tty: no pwrite there */
+    if (!S_ISREG(sb.st_mode)) {                                                   /* the input is a pipe: no pread */
+        if (P->seq_out && resume) resume->fo = P->fo; else close(P->fo);          /* (an output that is a pipe too stays open for the host pipeline) */
+        close(P->fd); free(P);
+        return UTREE_RETRY_HOST;
+    }
     P->file_size = sb.st_size;
     P->chunk_bytes = chunk_bytes();
-    P->seq_out = lseek(P->fo, 0, SEEK_CUR) == (off_t)-1;                          /* `out` is a pipe, a FIFO, a tty: no pwrite there */
     const int K = lanes_per_device(n_dev), n_lanes = K * n_dev;
     int rc = UTREE_OK;
     for (int g = 0; g < n_dev && !rc; ++g) { struct utree_search_ctx *c = NULL; rc = ctx_get(ctr, devs[g], K, &c); }
@@ -415,8 +433,16 @@ int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, 
         for (int i = 0; i < started; ++i) pthread_join(lanes[i].th, NULL);
         rc = P->rc;
     }
+    if (!rc && P->retry_set) {
+        /* every chunk in front of `retry_at` is written; the host pipeline takes the rest of the input and the open descriptor */
+        rc = UTREE_RETRY_HOST;
+        if (resume) {
+            resume->fo = P->fo; resume->in_off = (long long)P->retry_off;
+            resume->n_reads = P->n_reads; resume->good_finds = P->good; resume->bytes_in = P->bytes_in; resume->bytes_out = (uint64_t)P->cum_out;
+        }
+    }
     close(P->fd);
-    close(P->fo);
+    if (!(resume && resume->fo == P->fo)) close(P->fo);
     if (progress_printed) *progress_printed = P->printed;
     if (stats) {
         memset(stats, 0, sizeof *stats);

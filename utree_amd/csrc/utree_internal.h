@@ -14,6 +14,14 @@ extern "C" {
 #define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
 #define UTREE_IMG_HEADER_BYTES 4096u
 #define UTREE_IMG_VERSION 11u                    /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region; 10: the vote records carry the file-order index; 11: canonical minimizers, strand-paired buckets */
+/* How a 16-mer gets its strand-independent rank and address (image version 11, device_common.hpp):
+ *   1: the hash of its canonical form, the smaller of the 16-mer and its reverse complement -- three vector instructions per base of a read
+ *      on top of the forward walk, but only every other hash value is some canonical 16-mer's: where the table has a pair of buckets per
+ *      hash value (the dense end of the range) every other pair stays empty, and regions of a few values per pair must be sized for the lumps
+ *   2: the smaller of the two hashes -- a second hash per base (seven instructions), every value in use, the table as small as before */
+#ifndef UTREE_CANON_MODE
+#define UTREE_CANON_MODE 1
+#endif
 #define UTREE_REGION_NB_BITS 25                  /* regions[r] = base_r << 25 | nb_r (nb_r <= 2^24)                    */
 #define UTREE_TALLY_CHUNK 8192u                  /* tally entries a wave reserves with one atomic              */
 #define UTREE_CUR_LONG 32                        /* cursors[] index of the long-read counter (own 256-B line)   */

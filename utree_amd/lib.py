@@ -85,6 +85,7 @@ SYMBOLS = {
     "utree_ctr_label": (C.c_void_p, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "utree_dev_image_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "utree_dev_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "utree_dev_upload_seconds": (C.c_int, [C.POINTER(C.c_double)]),
     "utree_dev_build": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                   C.c_void_p, C.POINTER(C.c_void_p)]),
     "utree_dev_image": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
