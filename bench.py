@@ -103,12 +103,26 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only to rehearse on one GPU")
     ap.add_argument("--share-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo --replicate torch)")
     ap.add_argument("--e2e-reads-per-rank", type=int, default=8_000_000, help="N>1: reads of each rank's shard in the file -> file leg")
+    ap.add_argument("--no-cli-leg", action="store_true", help="N>1: skip the command-line leg (one process, all GPUs, one input, one output)")
+    ap.add_argument("--make-files", default="", help="(internal) write the bench database as DIR/db.ctr and --e2e-reads reads as DIR/reads.fa, then exit")
     args = resolve_defaults(ap.parse_args())
     if args.gpus <= 0:
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("UTREE_BENCH_FORCE_DIST"):
         raise SystemExit(self_launch(args))
+    if args.make_files:
+        raise SystemExit(make_files(args))
+    # The product's own multi-GPU shape -- ONE process, utree_dev_fanout (RCCL broadcast) + utree_search_file over all the GPUs, one input,
+    # one output -- is the command line's: rank 0 times it as a child BEFORE this process touches a GPU (the other ranks wait in the
+    # rendezvous meanwhile, holding nothing).  UTREE_BENCH_CLI_LEG=1 rehearses it at N = 1.
+    cli_leg_result = None
+    if ((int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0 and not args.no_cli_leg) or os.environ.get("UTREE_BENCH_CLI_LEG")) \
+            and args.workload == "config" and args.len_dist == "fixed":
+        try:
+            cli_leg_result = cli_leg(args)
+        except Exception as ex:                                   # the leg must never take the benchmark line down
+            cli_leg_result = {"error": repr(ex)}
 
     # stdout carries ONE JSON line: libraries that chat on fd 1 (RCCL prints a version banner there when its
     # communicator is created) are sent to stderr until that line is written
@@ -292,6 +306,8 @@ def main():
             "batch_reads": args.batch_reads, "reads_per_gpu": args.batch_reads * args.steps,
             "db_build_seconds": db_s, "classified_fraction_last_batch": nfound / args.batch_reads,
         }
+        if cli_leg_result is not None:
+            line["cli"] = cli_leg_result
         if dist_on:
             line["ranks"] = dist.get_world_size()
             line["gpus_arg"] = args.gpus
@@ -431,6 +447,84 @@ def e2e_leg_dist(args, sdb, tree, rank, world, dev, udist):
             out["error"] = repr(e)
     dist.barrier()
     if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+def make_files(args):
+    """(child of cli_leg) the bench's synthetic database as a real `.ctr` file and the file leg's reads as FASTA, in --make-files DIR."""
+    import numpy as np
+    import torch
+    from utree_amd import synth
+    dev = torch.device("cuda", 0)
+    d = args.make_files
+    sdb = synth.make_db(dev, args.nodes, W=args.kmer // 4, fine_bits=args.fine_bits, keep_raw=True)
+    records = sdb.records.cpu().numpy()
+    with open(os.path.join(d, "db.ctr"), "wb") as f:
+        f.write(np.array([sdb.W, 0, 2, sdb.n_nodes], dtype="<u8").tobytes())
+        f.write(sdb.binix.cpu().numpy().view(np.uint32).tobytes())
+        for lo in range(0, records.size, 1 << 30):
+            f.write(records[lo:lo + (1 << 30)].tobytes())
+        f.write(sdb.label_text)
+    n_total, done, b = args.e2e_reads, 0, 0
+    with open(os.path.join(d, "reads.fa"), "wb") as f:
+        while done < n_total:
+            n = min(4_000_000, n_total - done)
+            r = synth.make_reads(sdb, n, args.read_len, seed=synth.READ_SEED + 7000 + b, device=dev)
+            synth.fasta_tensor(r, done).cpu().numpy().tofile(f)
+            done += n
+            b += 1
+    return 0
+
+
+def cli_leg(args):
+    """One invocation of the command line over all the GPUs of the run: `UTREE_GPUS=N utree_amd/xtree-searchGG db.ctr reads.fa out.txt [RC]`
+    -- utree_ctr_open + utree_dev_upload on GPU 0, utree_dev_fanout (the RCCL broadcast; per-device uploads if it fails), utree_search_file
+    over the N handles: one input file, one output file.  Children only: this process has not touched a GPU yet."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    n = int(os.environ.get("WORLD_SIZE", "1"))
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 40 * 2**30 else None
+    d = tempfile.mkdtemp(prefix="utree_bench_cli_", dir=base)
+    out = {"what": "one process, %d GPU(s): xtree-searchGG db.ctr reads.fa out.txt (database load, RCCL fan-out, file -> file search)" % n, "n_gpus": n}
+    try:
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "UTREE_BENCH_CLI_LEG", "UTREE_BENCH_FORCE_DIST", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                  "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+            env.pop(k, None)
+        t0 = time.time()
+        gen = [sys.executable, os.path.abspath(__file__), "--make-files", d, "--nodes", str(args.nodes), "--kmer", str(args.kmer), "--read-len", str(args.read_len),
+               "--e2e-reads", str(args.e2e_reads), "--fine-bits", str(args.fine_bits)]
+        subprocess.run(gen, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+        out["make_files_seconds"] = time.time() - t0
+        time.sleep(15)                                             # (the generator has just freed ~100 GB of HBM: see db_load_leg)
+        cli = os.path.join(ROOT, "utree_amd", "xtree-searchGG")
+        env["UTREE_GPUS"] = str(n)
+        env["UTREE_TIMING"] = "1"                                  # the loader's and the pipeline's phase lines on stderr
+        cmd = [cli, os.path.join(d, "db.ctr"), os.path.join(d, "reads.fa"), os.path.join(d, "out.txt"), "16"] + (["RC"] if args.rc else [])
+        t0 = time.time()
+        p = subprocess.run(cmd, env=env, capture_output=True, timeout=900)
+        wall = time.time() - t0
+        err = p.stderr.decode(errors="replace")
+        out.update(exit_code=p.returncode, wall_seconds=wall, reads=args.e2e_reads, output_bytes=os.path.getsize(os.path.join(d, "out.txt")) if p.returncode == 0 else 0)
+        m = re.search(r"search ([0-9.]+) s \(([0-9.]+) reads/s\)", err)
+        if m:
+            out["search_seconds"] = float(m.group(1))
+            out["value"] = float(m.group(2))
+            out["unit"] = "reads/s, file -> file, ONE output file, all GPUs"
+            out["load_and_fanout_seconds"] = wall - float(m.group(1))
+        m = re.search(r"replicated to (\d+) GPU\(s\) by RCCL broadcast in ([0-9.]+) s", err)
+        if m:
+            out["fanout"] = "RCCL broadcast"
+            out["broadcast_seconds"] = float(m.group(2))
+        elif "every GPU reads it from the host" in err:
+            out["fanout"] = "per-device upload over PCIe (the broadcast failed)"
+        out["bound"] = ("one output file fills at the host's page-allocation rate (~6 GB/s: DESIGN.md, file -> file): beyond ~80 M reads/s more GPUs do not "
+                        "show in THIS number; they show in `value` (HBM-resident) and in a search whose output goes to several files")
+        out["stderr_tail"] = err[-2500:]
+    finally:
         shutil.rmtree(d, ignore_errors=True)
     return out
 
@@ -774,6 +868,11 @@ def db_load_leg(args, sdb, tree, files):
     from utree_amd.search import CtrDB, DeviceTree
     path = files.ctr()
     torch.cuda.empty_cache()
+    # (the driver scrubs freed device memory in the background, and a large allocation that follows a large free waits for it -- seconds,
+    # erratically: tools/alloc_probe.c, profiles/r04/alloc_probe.txt.  A command line started on an idle GPU does not meet that; this process
+    # has just freed tens of GB, so it idles first)
+    idle = float(os.environ.get("UTREE_BENCH_IDLE_BEFORE_LOAD", "15"))
+    time.sleep(idle)
     t0 = time.time()
     db2 = CtrDB.open(path)
     t1 = time.time()
@@ -788,7 +887,7 @@ def db_load_leg(args, sdb, tree, files):
     img = t2_tree.info.image_bytes
     t2_tree.close()
     db2.close()
-    return {"seconds": t2 - t0, "file_bytes": os.path.getsize(path), "image_bytes": int(img),
+    return {"seconds": t2 - t0, "idle_seconds_before": idle, "file_bytes": os.path.getsize(path), "image_bytes": int(img),
             "phases_seconds": {"utree_ctr_open (header, bin table, labels)": t1 - t0, "device + image allocation, labels": ph[0],
                                "node dump: file -> pinned -> HBM, repacked as it arrives": ph[1], "bin-table check, minimizer sort, buckets, packing": ph[2]},
             "file_GBps": os.path.getsize(path) / max(1e-9, ph[1]) / 1e9,
