@@ -13,8 +13,9 @@
  *   - nothing calls exit(): functions return UTREE_OK or an error code; the CLI (xtree-searchGG) maps the
  *     codes to the reference's exit codes and messages;
  *   - `.ctr` files are consumed unchanged (layout: itree.c:1301-1313 writer, 736-775 reader);
- *   - PACKSIZE / IXTYPE are compile-time in the reference (itree.c:35-70) and run-time here: W in {8,16}
- *     (k = 32, 64) and I in {2,4} are dispatched from the file header;
+ *   - PACKSIZE / IXTYPE are compile-time in the reference (itree.c:35-70) and run-time here: W in {4,8,16}
+ *     (k = 16, 32, 64: every PACKSIZE the reference compiles with, README.md:87-88) and I in {2,4} are dispatched from the file
+ *     header; PACKSIZE=16 trees are searched (GG) and compressed, not built or searched rank-specifically;
  *   - there is no CPU fallback: every compute entry point needs a gfx950 device and fails with
  *     UTREE_E_HIP otherwise.
  */
@@ -57,7 +58,7 @@ int utree_abi_version(void);
 typedef struct utree_ctr utree_ctr;
 
 typedef struct {
-    uint32_t W;            /* bytes per packed k-mer word: header[0] (8 => k=32, 16 => k=64)            */
+    uint32_t W;            /* bytes per packed k-mer word: header[0] (4 => k=16, 8 => k=32, 16 => k=64)  */
     uint32_t I;            /* bytes per label index:       header[2]                                     */
     uint32_t k;            /* 4*W                                                                        */
     uint32_t SZ;           /* bytes per stored record = W + I - 3 (itree.c:691)                           */
@@ -122,7 +123,8 @@ typedef struct {
     uint32_t lane_pass;         /* 1: the lane-per-read classify kernels take this image (else the
                                    wave-per-read kernels: k = 64 with 32-bit labels, many irregular bins)   */
     uint32_t bucket_bytes;      /* 64 (default) or 128 (UTREE_BUCKET_BYTES=128 when the image is built: a third
-                                   less HBM, classify kernels 5-10 % slower)                               */
+                                   less HBM, classify kernels 5-10 % slower); 0: a PACKSIZE=16 tree, whose image is a
+                                   direct-address table of all 2^32 words' answers                         */
     uint32_t strand_views;      /* 1: the image stores every k-mer under its mirrored minimizer view too (where that differs), so a
                                    search with RC finds a window and its reverse complement in ONE pass over the read: both are
                                    in the two buckets of one pair                     */

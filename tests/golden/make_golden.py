@@ -744,6 +744,11 @@ def main():
         gen_build(manifest)
         json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "k16":            # add the PACKSIZE=16 fixture (reference built with -D PACKSIZE=16: oracle/_ref/*-k16)
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+        gen_toy(manifest, "k16", "-k16", "xtree-searchGG-k16", 120, 900, 3000, 100, seed=16, complevel=0)
+        json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "irregular":      # add the irregular-bin fixtures to an existing golden set
         manifest = json.load(open(os.path.join(HERE, "manifest.json")))
         gen_irregular(manifest)
@@ -753,6 +758,7 @@ def main():
     gen_toy(manifest, "toy", "", "xtree-searchGG", 1000, 1000, 10000, 100, seed=20240807)
     gen_toy(manifest, "k64", "-k64", "xtree-searchGG-k64", 150, 1200, 3000, 150, seed=64)
     gen_toy(manifest, "ix32", "-ix32", "xtree-searchGG-ix32", 150, 1200, 3000, 120, seed=32)
+    gen_toy(manifest, "k16", "-k16", "xtree-searchGG-k16", 120, 900, 3000, 100, seed=16, complevel=0)
     gen_vote(manifest)
     gen_kat(manifest)
     gen_irregular(manifest)

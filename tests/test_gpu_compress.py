@@ -21,7 +21,7 @@ def _ubt_from_db_fixture(name, path):
     return d
 
 
-@pytest.mark.parametrize("name", ["toy", "k64", "ix32"])
+@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "k16"])
 def test_compress_reference_built_databases(name, tmp_path):
     """The toy databases went through the reference's BUILD_GG + COMPRESS; re-compressing their `.ubt` must give the
     same `.ctr` bytes."""
@@ -67,5 +67,5 @@ def test_compress_errors(tmp_path):
     p = tmp_path / "bad.ubt"
     p.write_bytes(np.array([8, 0, 2, 0], dtype="<u8").tobytes())
     assert compress(str(p), str(tmp_path / "o.ctr"))[0] == lib.E_FORMAT
-    p.write_bytes(np.array([4, 0, 2, 3], dtype="<u8").tobytes() + b"\0" * 64)
+    p.write_bytes(np.array([2, 0, 2, 3], dtype="<u8").tobytes() + b"\0" * 64)            # PACKSIZE=8: no build of the reference reads it either
     assert compress(str(p), str(tmp_path / "o.ctr"))[0] == lib.E_UNSUPPORTED

@@ -38,7 +38,7 @@ def tree_for(name, fine_bits=lib.FINE_AUTO):
 
 
 GOLDEN = [("toy", 0), ("toy", 1), ("k64", 0), ("k64", 1), ("ix32", 0), ("ix32", 1), ("vote", 0), ("kat", 0), ("katq", 0),
-          ("katq2", 0), ("generic", 0)]
+          ("katq2", 0), ("generic", 0), ("k16", 0), ("k16", 1)]
 
 
 @pytest.mark.parametrize("name,rc", GOLDEN)
@@ -71,7 +71,7 @@ def test_irregular_bins_and_generic_mode_are_detected(torch_cuda):
 
 def test_lookup_operator_matches_oracle(torch_cuda):
     torch = torch_cuda
-    for name in ("kat", "katq", "toy", "k64", "ix32"):
+    for name in ("kat", "katq", "toy", "k64", "ix32", "k16"):
         db, tree = tree_for(name, 4)
         o = orc.OracleDB.load(util.fixture_ctr(name))
         d = util.load_db_fixture(name)
@@ -86,7 +86,10 @@ def test_lookup_operator_matches_oracle(torch_cuda):
             lo = sl | (pref << np.uint64(40))
             hi = np.zeros_like(lo)
         # hits, near misses, random words
-        qlo = np.concatenate([lo, lo ^ np.uint64(1), lo + np.uint64(1 << 40), rng.integers(0, 1 << 63, 5000).astype(np.uint64)])
+        far = np.uint64(1 << 8) if d.W == 4 else np.uint64(1 << 40)                       # the same suffix in the next bin
+        qlo = np.concatenate([lo, lo ^ np.uint64(1), lo + far, rng.integers(0, 1 << 63, 5000).astype(np.uint64)])
+        if d.W == 4:
+            qlo &= np.uint64(0xFFFFFFFF)                                                 # PACKSIZE=16: a word is 32 bits
         qhi = np.concatenate([hi, hi, hi, rng.integers(0, 1 << 63, 5000).astype(np.uint64) if d.W == 16 else np.zeros(5000, np.uint64)])
         t_lo = torch.from_numpy(qlo.view(np.int64)).cuda()
         t_hi = torch.from_numpy(qhi.view(np.int64)).cuda()
@@ -131,7 +134,7 @@ def fasta_bytes(reads):
     return b"".join(b">" + n.encode() + b"\n" + s.encode() + b"\n" for n, s in reads)
 
 
-@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "vote"])
+@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "vote", "k16"])
 @pytest.mark.parametrize("rc", [0, 1])
 def test_random_reads_vs_oracle_short_and_long(torch_cuda, name, rc, tmp_path):
     """Seeded reads from 1 bp to 40 kb (short wave-per-read path, long workgroup-per-read path, both strands)."""
@@ -210,7 +213,7 @@ def test_edge_case_files_through_search_file(torch_cuda, tmp_path):
         assert out.read_bytes() == bytes.fromhex(c["output_hex"]), nm
 
 
-@pytest.mark.parametrize("name,rc", [("toy", 0), ("toy", 1), ("k64", 1), ("ix32", 0)])
+@pytest.mark.parametrize("name,rc", [("toy", 0), ("toy", 1), ("k64", 1), ("ix32", 0), ("k16", 1)])
 def test_cli_drop_in(torch_cuda, name, rc, tmp_path):
     """The xtree-searchGG command line: same arguments, same output file, same banners, exit code 0."""
     out = tmp_path / "cls.txt"
@@ -225,9 +228,16 @@ def test_cli_drop_in(torch_cuda, name, rc, tmp_path):
     assert "Tree read." in so and ("Good finds: %d" % want.count(b"\n")) in so
     m = util.manifest()
     assert ("Nodes in input tree: %d" % m[name + "_nodes"]) in so
+    if name == "k16":
+        assert "(PACKSIZE=16, CNTTYPE=NA, IXTYPE=uint16_t, SZ=3)" in so
 
 
 def test_cli_usage_and_bad_db(tmp_path):
+    # a tree no build of the reference reads (PACKSIZE=8 does not compile there): its own refusal text and exit code (itree.c:746-751)
+    p = tmp_path / "p8.ctr"
+    p.write_bytes(np.array([2, 0, 2, 5], dtype="<u8").tobytes() + b"\0" * 64)
+    r = subprocess.run([lib.CLI_PATH, str(p), "a", "b"], stdout=subprocess.PIPE)
+    assert r.returncode == 0 and b"ERROR. Input tree requires PACKSIZE=8, CNTTYPE=NA, IXTYPE=uint16_t" in r.stdout
     r = subprocess.run([lib.CLI_PATH], stdout=subprocess.PIPE)
     assert r.returncode == 1 and b"usage: xtree-searchGG compTree.ctr fastaToSearch.fa output.txt [threads] [SPEED <X>] [RC]" in r.stdout
     r = subprocess.run([lib.CLI_PATH, str(tmp_path / "none.ctr"), "a", "b"], stdout=subprocess.PIPE)
@@ -520,3 +530,36 @@ def test_tally_workspace_under_label_diversity_and_mixed_lengths(torch_cuda):
     assert np.array_equal(g32[multi, 4], want["sl"][multi]) and np.array_equal(g32[multi, 5], want["ol"][multi])
     assert float(want["uix"].mean()) > 3.5                                                     # nearly every hit a label of its own
     sdb.tree.close()
+
+
+@pytest.mark.parametrize("case", ["quirk", "dups", "generic", "ix32"])
+def test_packsize16_direct_table_on_irregular_trees(torch_cuda, case, tmp_path):
+    """PACKSIZE=16 (README.md:88): a k-mer is a 32-bit word and the image holds XT_getIX32's answer for every word.  Where a bin is not
+    strictly ascending -- COMPRESS' first-bin quirk, repeated or unsorted suffixes -- or the bin table is not monotone, the table is
+    filled by the reference's own probe order: the oracle's lines (itself held to the genuine -D PACKSIZE=16 build on these very
+    files, tests/test_oracle_golden.py), both strands, and the word operator on every probe."""
+    torch = torch_cuda
+    ctr, data = util.k16_table_cases(str(tmp_path))[case]
+    db = CtrDB.open(ctr)
+    tree = DeviceTree.upload(db, 0)
+    o = orc.OracleDB.load(ctr)
+    assert tree.info.bucket_bytes == 0 and tree.info.lane_pass == 0
+    if case in ("quirk", "dups"):
+        assert tree.info.irregular_bins >= 1
+    if case == "generic":
+        assert tree.info.generic_mode == 1
+    fa = tmp_path / "r.fa"
+    fa.write_bytes(data)
+    for rc in (False, True):
+        out = tmp_path / "o.txt"
+        code, nr, good, err = o.search_file(str(fa), str(out), threads=4, rc=rc)
+        assert code == 0 and good > 100
+        assert classify_fasta_bytes(db, tree, data, rc=rc) == out.read_bytes()
+    rng = np.random.default_rng(2)
+    q = np.concatenate([rng.integers(0, 1 << 32, 20000, dtype=np.uint64), np.arange(0x10 << 8, (0x12 << 8), dtype=np.uint64)])
+    got = tree.get_ix(None, torch.from_numpy(q.view(np.int64)).cuda()).cpu().numpy().view(np.uint32)
+    nl = o.n_labels
+    for j in range(len(q)):
+        w = o.lookup(0, int(q[j]))
+        assert int(got[j]) == (w if w < nl else 0xFFFFFFFF), (case, hex(int(q[j])))
+    tree.close()

@@ -40,7 +40,7 @@ def test_product_does_not_reference_oracle():
                 assert "orc_" not in txt, f
 
 
-@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "vote", "kat", "katq"])
+@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "k16", "vote", "kat", "katq"])
 def test_loader_matches_oracle_and_fixture(name):
     p = util.fixture_ctr(name)
     db = CtrDB.open(p)

@@ -87,7 +87,7 @@ int utree_compress_file(const char *ubt_path, const char *ctr_path, int device, 
     uint64_t meta[4] = {0, 0, 0, 0};
     if (pread(fd, meta, 32, 0) != 32 || !meta[3]) { close(fd); return UTREE_E_FORMAT; }      /* itree.c:1239 */
     const uint64_t W = meta[0], I = meta[2], N = meta[3];
-    if (meta[1] != 0 || !(W == 8 || W == 16) || !(I == 2 || I == 4)) { close(fd); return UTREE_E_UNSUPPORTED; }
+    if (meta[1] != 0 || !(W == 4 || W == 8 || W == 16) || !(I == 2 || I == 4)) { close(fd); return UTREE_E_UNSUPPORTED; }   /* PACKSIZE 16, 32, 64 */
     const size_t DR = (size_t)(W + I), SZ = (size_t)(W + I - 3);
     off_t fsize = lseek(fd, 0, SEEK_END);
     if ((uint64_t)fsize < 32 + N * DR) { close(fd); return UTREE_E_FORMAT; }

@@ -93,7 +93,7 @@ static int parse_labels(utree_ctr *c, const char *text, size_t len) {
 static int check_header(uint64_t W, uint64_t cnt, uint64_t I, uint64_t N) {
     if (!N) return UTREE_E_FORMAT;                                     /* itree.c:738 */
     if (cnt != 0) return UTREE_E_UNSUPPORTED;                          /* NO_COUNT builds only (itree.c:34) */
-    if (!(W == 8 || W == 16) || !(I == 2 || I == 4)) return UTREE_E_UNSUPPORTED;
+    if (!(W == 4 || W == 8 || W == 16) || !(I == 2 || I == 4)) return UTREE_E_UNSUPPORTED;   /* PACKSIZE 16, 32, 64 (README.md:87-88; 4 and 8 do not compile in the reference) */
     return UTREE_OK;
 }
 

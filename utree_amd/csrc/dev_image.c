@@ -159,10 +159,19 @@ static void layout(const utree_ctr *ctr, uint32_t F, utree_image_header *h) {
     /* UTREE_FORCE_OFF64: test hook that runs the 64-bit-offset instantiations (N >= 2^32-1 databases) on small files */
     h->flags = (ctr->info.binix_width == 8 || getenv("UTREE_FORCE_OFF64")) ? UTREE_F_OFF64 : 0;
     h->bucket_words = bucket_words_default(h->n_nodes, h->W);
-    h->n_slots = compute_regions(h->n_nodes, h->W, h->I, h->bucket_words, F, h->regions);
     uint64_t off = UTREE_IMG_HEADER_BYTES;
+    if (h->W == 4) {
+        /* PACKSIZE=16: a k-mer is a 32-bit word, so the image holds XT_getIX32's answer for every word: 2^32 ranks of I bytes (8 or 16 GiB whatever
+         * the database's size), one load per window.  No buckets, no MIN records; the FILE records only while the table is built. */
+        h->flags |= UTREE_F_DIRECT;
+        h->bucket_words = 8; h->n_slots = 0; h->fine_bits = 0;
+        h->off_table = off; off = align_up(off + ((uint64_t)1 << 32) * h->I, 4096);
+        h->off_mrecs = off; off = align_up(off + 64, 4096);
+    } else {
+    h->n_slots = compute_regions(h->n_nodes, h->W, h->I, h->bucket_words, F, h->regions);
     h->off_table = off; off = align_up(off + h->n_slots * 8 * h->bucket_words, 4096);
     h->off_mrecs = off; off = align_up(off + (h->n_nodes + dup_capacity(h->n_nodes) + 8) * h->rec_words * 8, 4096);
+    }
     h->off_coarse = off; off = align_up(off + (uint64_t)UTREE_NUMBINS * ((h->flags & UTREE_F_OFF64) ? 8 : 4), 256);
     h->off_irreg = off; off = align_up(off + (1u << 24) / 8, 256);
     h->off_label_off = off; off = align_up(off + ((uint64_t)h->n_labels + 1) * 4, 256);
@@ -403,6 +412,22 @@ static int build_finish(builder *b, const void *d_binix_raw) {
     d->hdr.n_irregular = counters[0];
     if (invalid) d->hdr.flags |= UTREE_F_INVALID_RANKS;
     uint64_t full_bytes = d->hdr.total_bytes;
+    if (d->hdr.W == 4) {
+        /* PACKSIZE=16: the direct-address table from the FILE records (image_build.hip: direct_*_k); the records then leave the image */
+        uint64_t c0 = 0, cN = 0;
+        if (!counters[1]) {
+            if (ctr->info.binix_width == 4) { uint32_t a, z; memcpy(&a, ctr->binix_raw, 4); memcpy(&z, (const char *)ctr->binix_raw + 4 * (size_t)(UTREE_NUMBINS - 1), 4); c0 = a; cN = z; }
+            else { memcpy(&c0, ctr->binix_raw, 8); memcpy(&cN, (const char *)ctr->binix_raw + 8 * (size_t)(UTREE_NUMBINS - 1), 8); }
+        } else HIPCHK(hipMemsetAsync(img + d->hdr.off_irreg, 0xFF, (1u << 24) / 8, st));
+        KCHK(utk_build_direct(d->hdr.I, off64, counters[1] != 0, coarse, recs, d->hdr.n_nodes, c0, cN - c0, (const uint32_t *)(img + d->hdr.off_irreg), counters[0],
+                              img + d->hdr.off_table, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (counters[1]) d->hdr.flags |= UTREE_F_GENERIC; else if (counters[0]) d->hdr.flags |= UTREE_F_IRREGULAR;   /* (what the table was built from: informational) */
+        d->hdr.n_min = 0;
+        d->hdr.total_bytes = d->hdr.off_recs;                    /* (off_recs is the last area: the image ends in front of it) */
+        if (timing_on()) fprintf(stderr, "[utree_amd] image: direct-address table of 2^32 x %u bytes built (%llu irregular bins%s answered by the reference's probe order)\n",
+                                 d->hdr.I, counters[0], counters[1] ? ", bin table not monotone: every bin" : "");
+    } else
     if (counters[1]) {
         /* bin table not monotone (never written by the reference's COMPRESS): trust it verbatim like the
          * reference does -- every bin takes the exact probe path over [BinIx[p], BinIx[p+1]) */
@@ -655,6 +680,7 @@ int utree_dev_get_info(const utree_dev *d, utree_dev_info *info) {
     info->lane_pass = utk_lanes_image_ok(&d->kimg) != 0;
     info->bucket_bytes = 8u * d->hdr.bucket_words;
     info->strand_views = (d->hdr.flags & UTREE_F_STRAND_VIEWS) ? 1u : 0u;
+    if (d->hdr.flags & UTREE_F_DIRECT) info->bucket_bytes = 0;
     return UTREE_OK;
 }
 

@@ -93,11 +93,12 @@ template <int W, int I> __device__ __forceinline__ uint32_t file_rank(const uint
 }
 // split of the 2k-bit word khi:klo into 24-bit prefix (itree.c:684) and suffix key (itree.c:685)
 template <int W> __device__ __forceinline__ uint32_t word_prefix(uint64_t khi, uint64_t klo) {
-    return (uint32_t)(((W == 16) ? khi : klo) >> 40);
+    if constexpr (W == 4) return (uint32_t)(klo >> 8);                  // PACKSIZE=16: a 32-bit word, 24 prefix + 8 suffix bits
+    else return (uint32_t)(((W == 16) ? khi : klo) >> 40);
 }
 template <int W> __device__ __forceinline__ Key<W> word_suffix(uint64_t khi, uint64_t klo) {
     Key<W> q;
-    if constexpr (W == 16) { q.hi = khi & M40; q.lo = klo; } else { q.hi = 0; q.lo = klo & M40; }
+    if constexpr (W == 16) { q.hi = khi & M40; q.lo = klo; } else if constexpr (W == 4) { q.hi = 0; q.lo = klo & 0xFFull; } else { q.hi = 0; q.lo = klo & M40; }
     return q;
 }
 
@@ -312,6 +313,14 @@ template <typename Fn> int dispatch_wi(uint32_t W, uint32_t I, Fn &&fn) {
     return (int)hipGetLastError();
 }
 
+// ... and W = 4 (PACKSIZE=16) for the code that exists for it: repacking, the bin-table check, COMPRESS
+template <typename Fn> int dispatch_wi_all(uint32_t W, uint32_t I, Fn &&fn) {
+    if (W == 4 && I == 2) fn(IC<4>{}, IC<2>{});
+    else if (W == 4 && I == 4) fn(IC<4>{}, IC<4>{});
+    else return dispatch_wi(W, I, fn);
+    return (int)hipGetLastError();
+}
+
 template <typename Fn> int dispatch_img(const utk_image *im, Fn &&fn) {
     const bool exc = (im->flags & (UTREE_F_IRREGULAR | UTREE_F_GENERIC)) != 0;
     const bool o64 = (im->flags & UTREE_F_OFF64) != 0;
@@ -321,6 +330,18 @@ template <typename Fn> int dispatch_img(const utk_image *im, Fn &&fn) {
         else if (o64) fn(w, i, std::false_type{}, uint64_t{});
         else fn(w, i, std::false_type{}, uint32_t{});
     });
+}
+
+// the GG search kernels also exist for W = 4 (PACKSIZE=16): a direct-address table holds every word's answer, the irregular bins'
+// included (image_build.hip: direct_*_k), so neither the exact-probe path nor 64-bit offsets are instantiated for it
+template <typename Fn> int dispatch_img_all(const utk_image *im, Fn &&fn) {
+    if (im->W == 4) {
+        if (im->I == 2) fn(IC<4>{}, IC<2>{}, std::false_type{}, uint32_t{});
+        else if (im->I == 4) fn(IC<4>{}, IC<4>{}, std::false_type{}, uint32_t{});
+        else return (int)hipErrorInvalidValue;
+        return (int)hipGetLastError();
+    }
+    return dispatch_img(im, fn);
 }
 
 }  // namespace utk

@@ -41,8 +41,8 @@ __global__ void repack_k(const uint8_t *__restrict__ raw, uint64_t count, const 
         if (rank == INVALID) atomicAdd(invalid, 1ull);               // (no well-formed database has such a node)
         uint64_t *o = recs + i * EW;
         const uint64_t r16 = rank == INVALID ? 0xFFFFull : (uint64_t)rank;
-        if constexpr (W == 8 && I == 2) { o[0] = lo | (r16 << 40); }
-        else if constexpr (W == 8 && I == 4) { o[0] = lo; o[1] = rank; }
+        if constexpr (W <= 8 && I == 2) { o[0] = lo | (r16 << 40); }             // (W = 4, PACKSIZE=16: a suffix of 8 bits in the same place)
+        else if constexpr (W <= 8 && I == 4) { o[0] = lo; o[1] = rank; }
         else if constexpr (W == 16 && I == 2) { o[0] = lo; o[1] = hi | (r16 << 40); }
         else { o[0] = lo; o[1] = hi; o[2] = rank; o[3] = 0; }
     }
@@ -499,14 +499,69 @@ done:
     return rc;
 }
 
+// ---- PACKSIZE=16 (W = 4): the direct-address table.  A k-mer is a 32-bit word = 24-bit prefix (its bin) + 8-bit suffix, so every word's
+// answer fits a table of 2^32 ranks.  direct_fill_k: one thread per 16 consecutive nodes -- the node of bin p with suffix s answers word
+// p << 8 | s.  That IS the reference's answer wherever a bin is strictly ascending (any exact-match search finds the one record); a bin that
+// is not (COMPRESS' first-bin quirk, duplicates, unsorted input) is flagged by validate_k, and direct_exact_k asks the reference's own probe
+// sequence (exact_probe: itree.c:699-707) for each of the bin's 256 possible suffixes -- every bin of a table that is not monotone. ----
+template <int I> __device__ __forceinline__ void direct_store(void *table, uint32_t word, uint32_t rank) {
+    if constexpr (I == 2) ((uint16_t *)table)[word] = rank == INVALID ? (uint16_t)0xFFFFu : (uint16_t)rank;
+    else ((uint32_t *)table)[word] = rank;
+}
+template <int I, typename OFF>
+__global__ void direct_fill_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t c0, uint64_t m, void *__restrict__ table) {
+    for (uint64_t t0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * NODE_RUN; t0 < m; t0 += (uint64_t)gridDim.x * blockDim.x * NODE_RUN) {
+        uint64_t p = bin_of<OFF>(coarse, c0 + t0);
+        const uint64_t t1 = t0 + NODE_RUN < m ? t0 + NODE_RUN : m;
+        for (uint64_t t = t0; t < t1; ++t) {
+            const uint64_t j = c0 + t;
+            while ((uint64_t)coarse[p + 1] <= j) ++p;
+            direct_store<I>(table, (uint32_t)(p << 8) | (uint32_t)(file_key<4, I>(recs, j).lo & 0xFFu), file_rank<4, I>(recs, j));
+        }
+    }
+}
+template <int I, typename OFF>
+__global__ void direct_exact_k(const OFF *__restrict__ coarse, const uint64_t *__restrict__ recs, uint64_t n_nodes, const uint32_t *__restrict__ irreg,
+                               void *__restrict__ table) {
+    // one workgroup of 256 threads per bin and pass over the bins: thread s answers suffix s
+    for (uint32_t p = blockIdx.x; p < (1u << 24); p += gridDim.x) {
+        if (!((irreg[p >> 5] >> (p & 31)) & 1u)) continue;
+        const uint64_t s = coarse[p], e = coarse[p + 1];
+        uint32_t rank = INVALID;
+        if (s < e && e <= n_nodes) {                                     // itree.c:726; a bin that leaves the node array counts as empty
+            Key<4> q; q.hi = 0; q.lo = threadIdx.x;
+            rank = exact_probe<4, I>(recs, s, e, q);
+        }
+        direct_store<I>(table, (p << 8) | threadIdx.x, rank);
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
+/* PACKSIZE=16: d_table (2^32 entries of I bytes, all ones = no node) from the FILE records; irregular bins as validate_k flagged them (all of
+ * them when the bin table is not monotone: `generic`) */
+int utk_build_direct(uint32_t I_, int off64, int generic, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes, uint64_t c0, uint64_t m,
+                     const uint32_t *d_irreg, uint64_t n_irregular, void *d_table, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d_table, 0xFF, ((size_t)1 << 32) * I_, st);
+    if (e != hipSuccess) return (int)e;
+    if (I_ != 2 && I_ != 4) return (int)hipErrorInvalidValue;
+#define GO(I__, OFF__) do { \
+        if (!generic && m) direct_fill_k<I__, OFF__><<<grid_for((m + NODE_RUN - 1) / NODE_RUN), 256, 0, st>>>((const OFF__ *)d_coarse, d_recs, c0, m, d_table); \
+        if (generic || n_irregular) direct_exact_k<I__, OFF__><<<dim3(generic ? 65536u : 4096u), 256, 0, st>>>((const OFF__ *)d_coarse, d_recs, n_nodes, d_irreg, d_table); \
+    } while (0)
+    if (I_ == 2) { if (off64) GO(2, uint64_t); else GO(2, uint32_t); }
+    else { if (off64) GO(4, uint64_t); else GO(4, uint32_t); }
+#undef GO
+    return (int)hipGetLastError();
+}
+
 int utk_repack(uint32_t W_, uint32_t I_, const void *d_raw, uint64_t count, const uint32_t *d_ix2rank,
                uint32_t n_labels, uint64_t *d_recs, unsigned long long *d_invalid, void *stream) {
     if (!count) return 0;
-    return dispatch_wi(W_, I_, [&](auto w, auto i) {
+    return dispatch_wi_all(W_, I_, [&](auto w, auto i) {
         repack_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(count) > 65536 ? 65536 : grid_for(count)), dim3(256), 0, (hipStream_t)stream>>>(
             (const uint8_t *)d_raw, count, d_ix2rank, n_labels, d_recs, d_invalid);
     });
@@ -524,7 +579,7 @@ int utk_validate(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, cons
     if (off64) monotone_k<uint64_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, st>>>((const uint64_t *)d_coarse, n_nodes, d_counters);
     else monotone_k<uint32_t><<<dim3((UTREE_NUMBINS + 255) / 256), dim3(256), 0, st>>>((const uint32_t *)d_coarse, n_nodes, d_counters);
     const unsigned blocks = grid_for(n_nodes) > 65536 ? 65536 : grid_for(n_nodes);
-    return dispatch_wi(W_, I_, [&](auto w, auto i) {
+    return dispatch_wi_all(W_, I_, [&](auto w, auto i) {
         constexpr int W = decltype(w)::value, I = decltype(i)::value;
         if (off64) validate_k<W, I, uint64_t><<<dim3(blocks), dim3(256), 0, st>>>((const uint64_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
         else validate_k<W, I, uint32_t><<<dim3(blocks), dim3(256), 0, st>>>((const uint32_t *)d_coarse, d_recs, n_nodes, d_irreg, d_counters);
@@ -534,7 +589,7 @@ int utk_validate(uint32_t W_, uint32_t I_, int off64, const void *d_coarse, cons
 int utk_compress_chunk(uint32_t W_, uint32_t I_, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
                        void *d_out, void *stream) {
     if (!count) return 0;
-    return dispatch_wi(W_, I_, [&](auto w, auto i) {
+    return dispatch_wi_all(W_, I_, [&](auto w, auto i) {
         compress_chunk_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(count) > 16384 ? 16384 : grid_for(count)), dim3(256), 0, (hipStream_t)stream>>>(
             (const uint8_t *)d_in, first, count, d_first, (uint8_t *)d_out);
     });

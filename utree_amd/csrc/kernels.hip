@@ -136,6 +136,22 @@ template <int W, int I, bool EXC, typename OFF, uint32_t TILE, bool CHECKBAD, bo
 __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const LaneBits &lb, const uint64_t *sbad, uint64_t *Kk,
                                                   uint32_t w0, uint32_t n, const RegionLds &rg, uint32_t lane, HitFn &&on_rank PH_ARG) {
     constexpr uint32_t K = 4 * W;
+    if constexpr (W == 4) {
+        // PACKSIZE=16: no minimizers, no buckets -- lane l of round `it` takes window w0 + 64 it + l, whose 16 bases ARE the word
+        for (uint32_t it = 0; it * 64 < n; ++it) {
+            bool ok = lane < n - it * 64;
+            if constexpr (CHECKBAD) {
+                const uint32_t ch = (w0 + it * 64) >> 6;
+                const uint64_t b0 = sbad[ch], b1 = sbad[ch + 1];
+                const uint64_t x = (b0 >> lane) | (lane ? (b1 << (64u - lane)) : 0ull);   // bad flags of bases i..i+63
+                ok = ok && ((uint32_t)x & 0xFFFFu) == 0u;
+            }
+            uint32_t rank = INVALID;
+            if (ok) rank = direct_rank<I>(im, mmer_l(lb.swl + ((w0 + it * 64) >> 4), 0, lb.sh));
+            on_rank(rank);                                                   // itree.c:929-931
+        }
+        return;
+    }
     static_assert(TILE + 64 <= (1u << MIN_LOW_BITS), "tile positions must fit the key's position field");
     uint32_t *Kp = (uint32_t *)Kk;                                          // the wave's 8 * (TILE + 128) bytes: keys, then hashes
     uint32_t *Kl = Kp + lane, *Hl = Kp + (TILE + 128) + lane;
@@ -1221,7 +1237,7 @@ int utk_classify_short(const utk_image *im, const uint8_t *d_bases, const uint64
     uint32_t blocks = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     uint32_t cap = (uint32_t)n_cu * 8u;
     if (blocks > cap) blocks = cap;
-    return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
+    return dispatch_img_all(im, [&](auto w, auto i, auto exc, auto offt) {
         if (ws->short_cap == UTREE_SHORT2_CAP)
             classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), SHORT2_CAP, false>
                 <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
@@ -1247,7 +1263,7 @@ int utk_classify_mid(const utk_image *im, const uint8_t *d_bases, const uint64_t
     uint32_t blocks = (n_reads + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     uint32_t cap = (uint32_t)n_cu * 5u;
     if (blocks > cap) blocks = cap;
-    return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
+    return dispatch_img_all(im, [&](auto w, auto i, auto exc, auto offt) {
         classify_short_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt), MID_CAP, true>
             <<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws);
     });
@@ -1280,7 +1296,7 @@ int utk_classify_long(const utk_image *im, const uint8_t *d_bases, const uint64_
                       int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
     (void)n_cu;
     if (!ws->long_blocks) return 0;
-    return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
+    return dispatch_img_all(im, [&](auto w, auto i, auto exc, auto offt) {
         classify_long_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt)>
             <<<dim3(ws->long_blocks), dim3(LONG_THREADS), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, do_rc, d_out, *ws);
     });
@@ -1297,7 +1313,7 @@ int utk_lookup(const utk_image *im, const uint64_t *d_hi, const uint64_t *d_lo, 
     if (!n) return 0;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    return dispatch_img(im, [&](auto w, auto i, auto exc, auto offt) {
+    return dispatch_img_all(im, [&](auto w, auto i, auto exc, auto offt) {
         lookup_k<decltype(w)::value, decltype(i)::value, decltype(exc)::value, decltype(offt)>
             <<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(*im, d_hi, d_lo, n, d_ix);
     });

@@ -11,7 +11,13 @@ int main(int argc, char *argv[]) {
     int rc = utree_compress_file(argv[1], argv[2], 0, &st);
     if (rc == UTREE_E_IO) { puts("Invalid input filename"); exit(0); }               /* itree.c:1236 / 1299 */
     if (rc == UTREE_E_FORMAT) { puts("Tree malformatted."); exit(0); }               /* itree.c:1239 */
-    if (rc == UTREE_E_UNSUPPORTED) { puts("ERROR. Input tree requires a PACKSIZE/CNTTYPE/IXTYPE this build has no kernel for"); exit(0); }
+    if (rc == UTREE_E_UNSUPPORTED) {                                                 /* the reference's words for a tree its build does not read (itree.c:1247-1251) */
+        unsigned long long md[4] = {0, 0, 0, 0};
+        FILE *dp = fopen(argv[1], "rb");
+        if (dp) { if (fread(md, sizeof *md, 4, dp) != 4) md[0] = 0; fclose(dp); }
+        printf("ERROR. Input tree requires PACKSIZE=%u, CNTTYPE=%s, IXTYPE=%s\n", (unsigned)(md[0] << 2), md[1] <= 16 ? TYPEARR[md[1]] : "NA", md[2] <= 16 ? TYPEARR[md[2]] : "NA");
+        exit(0);
+    }
     if (rc) { fprintf(stderr, "ERROR: %s\n", utree_strerror(rc)); exit(3); }
     printf("Nodes in input tree: %llu (PACKSIZE=%u, CNTTYPE=%s, IXTYPE=%s, el=%u)\n", (unsigned long long)st.n_nodes, st.W << 2,
            TYPEARR[0], TYPEARR[st.I], st.W + st.I);                                  /* itree.c:1254 */

@@ -58,7 +58,14 @@ int main(int argc, char *argv[]) {
     int rc = utree_ctr_open(argv[1], &ctr);
     if (rc == UTREE_E_IO) { puts("Invalid DB file"); exit(0); }                          /* itree.c:735 */
     if (rc == UTREE_E_FORMAT) { puts("Tree malformatted."); exit(0); }                   /* itree.c:738 */
-    if (rc == UTREE_E_UNSUPPORTED) { puts("ERROR. Input tree requires a PACKSIZE/CNTTYPE/IXTYPE this build has no kernel for"); exit(0); }
+    if (rc == UTREE_E_UNSUPPORTED) {
+        /* the reference's own words for a tree its build does not read (itree.c:746-751): what the header asks for */
+        uint64_t md[4] = {0, 0, 0, 0};
+        FILE *dp = fopen(argv[1], "rb");
+        if (dp) { if (fread(md, sizeof *md, 4, dp) != 4) md[0] = 0; fclose(dp); }
+        printf("ERROR. Input tree requires PACKSIZE=%u, CNTTYPE=%s, IXTYPE=%s\n", (unsigned)(md[0] << 2), md[1] <= 16 ? TYPEARR[md[1]] : "NA", md[2] <= 16 ? TYPEARR[md[2]] : "NA");
+        exit(0);
+    }
     if (rc == UTREE_E_NOLABELS) { puts("No annotation found in tree file."); exit(0); }   /* itree.c:776 */
     if (rc) { fprintf(stderr, "%s\n", utree_strerror(rc)); exit(3); }
     utree_ctr_info ci;

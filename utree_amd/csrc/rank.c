@@ -115,6 +115,7 @@ int utree_rank_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d_off
                      utree_result *d_out, void *d_workspace, size_t workspace_bytes, void *stream) {
     int rc = UTREE_OK;
     if (!d || !d_out || (!d_workspace && n_reads) || !params_ok(d, params) || max_len > RANK_MAX_LEN) return UTREE_E_ARG;
+    if (d->hdr.W == 4) return UTREE_E_UNSUPPORTED;      /* PACKSIZE=16 trees: the GG search only (the rank-specific kernels exist for k = 32 and 64) */
     if (!n_reads) return UTREE_OK;
     if (!d_bases || !d_off || !d_len) return UTREE_E_ARG;
     hipStream_t st = (hipStream_t)stream;

@@ -58,6 +58,8 @@ extern "C" {
 #define UTREE_F_VOTE_TABLE 16u /* labels are short and token-structured: vote_k takes its decisions from the table at off_vote */
 #define UTREE_F_STRAND_VIEWS 32u /* every k-mer is also stored under its mirrored view where that differs (device_common.hpp): a window's reverse
                                     complement is found from the window's own minimizer run, in the other bucket of the pair */
+#define UTREE_F_DIRECT 64u       /* PACKSIZE=16 (W = 4): off_table is a direct-address table, 2^32 ranks of I bytes (all ones: no node), every word's
+                                    answer as the reference gives it; no buckets, no records                               */
 #define UTREE_F_INVALID_RANKS 8u   /* some node's label index is >= the number of labels (itree.c:929: never a hit): wave-per-read kernels only */
 
 /* At offset 0 of the flat device image (position independent: offsets, never pointers). */
@@ -115,7 +117,7 @@ typedef struct {
     uint32_t irr_n, irr_p[4];
 } utk_image;
 
-static inline uint32_t utree_rec_words(uint32_t W, uint32_t I) { return (W == 16 ? 2u : 1u) * (I == 4 ? 2u : 1u); }
+static inline uint32_t utree_rec_words(uint32_t W, uint32_t I) { return (W == 16 ? 2u : 1u) * (I == 4 ? 2u : 1u); }   /* (W = 4 as W = 8) */
 
 /* ---- launchers implemented in kernels.hip (all asynchronous on `stream`, return hipError_t as int) ---- */
 /* *d_invalid += records whose label index is >= n_labels */
@@ -130,6 +132,8 @@ int utk_validate(uint32_t W, uint32_t I, int off64, const void *d_coarse, const 
 int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const uint64_t *d_recs, uint64_t c0, uint64_t m, uint64_t dup_cap,
                   const uint64_t *d_regions, const uint64_t *h_regions, uint64_t n_buckets, uint32_t bucket_words, uint64_t *d_table, uint64_t *d_mrecs,
                   uint32_t *d_irreg, unsigned long long *d_overflow, uint64_t *n_min, int *views, void *stream);
+int utk_build_direct(uint32_t I, int off64, int generic, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes, uint64_t c0, uint64_t m,
+                     const uint32_t *d_irreg, uint64_t n_irregular, void *d_table, void *stream);
 int utk_compact_overflow(uint32_t W, uint32_t I, uint64_t *d_table, uint64_t n_buckets, uint32_t bucket_words, uint64_t *d_mrecs, uint64_t *n_kept, void *stream);
 int utk_compress_chunk(uint32_t W, uint32_t I, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
                        void *d_out, void *stream);

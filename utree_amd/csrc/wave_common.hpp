@@ -147,8 +147,17 @@ __device__ __forceinline__ uint32_t resolve_bucket8(const utk_image &im, const B
     return resolve_bucket<8, I, EXC, OFF>(im, b, baddr, mk, 0ull, ((uint64_t)x0 << 32) | x1);
 }
 
+// PACKSIZE=16 (W = 4): a k-mer is one 32-bit word, and the image holds the answer of XT_getIX32 for every one of the 2^32 words -- the
+// label's rank, or all ones -- in a direct-address table (built at load time with the reference's own probe order where a bin is not
+// strictly ascending): one 2- or 4-byte load per window, nothing to search
+template <int I> __device__ __forceinline__ uint32_t direct_rank(const utk_image &im, uint32_t word) {
+    if constexpr (I == 2) { const uint32_t r = ((const uint16_t *)im.table)[word]; return r == 0xFFFFu ? INVALID : r; }
+    else return ((const uint32_t *)im.table)[word];
+}
+
 template <int W, int I, bool EXC, typename OFF>
 __device__ __forceinline__ uint32_t lookup_word(const utk_image &im, uint64_t khi, uint64_t klo) {
+    if constexpr (W == 4) return direct_rank<I>(im, (uint32_t)klo);
     uint64_t bucket; MinKey<W> mk;
     min_split<W>(khi, klo, im.regions, bucket, mk);
     const Bucket<W, I> b = load_bucket<W, I>(im.table, bucket, im.bucket_words);
