@@ -191,7 +191,8 @@ int utree_classify_batch(utree_dev *dev, const uint8_t *d_bases, const uint64_t 
  * that comes back with the batch (no kernel writes past a buffer, none drops a read silently).  Once `stream` has drained,
  * utree_classify_poll returns UTREE_E_DEVICE if a batch finished since the last call reported something (its results are not to
  * be used; utree_last_hip_error says what), else UTREE_OK.  utree_classify_batch also returns UTREE_E_DEVICE when an EARLIER
- * batch's report has arrived by the time it is called.  utree_search_file polls after every chunk. */
+ * batch's report has arrived by the time it is called (the new batch has been launched all the same; the condition stays until
+ * utree_classify_poll has returned it once).  utree_search_file polls after every chunk. */
 int utree_classify_poll(utree_dev *dev);
 /* The innermost operator alone (XT_getIX32, itree.c:720): words (hi:lo, hi = 0 for k = 32) -> stored label
  * index, 0xFFFFFFFF when absent or when the stored index is >= n_labels.  For tests and micro-benchmarks. */

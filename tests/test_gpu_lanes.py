@@ -90,7 +90,7 @@ def test_mixed_reads_lanes_vs_wave_per_read_vs_oracle(torch_cuda, name, tmp_path
     for rc in (False, True):
         monkeypatch.setenv("UTREE_LANE_PASS", "1")
         got = classify_fasta_bytes(db, tree, data, rc=rc)
-        assert tree.kernel_name().startswith("classify_lanes_k<")
+        assert tree.kernel_name().startswith("classify_lanes_")
         monkeypatch.setenv("UTREE_LANE_PASS", "0")
         plain = classify_fasta_bytes(db, tree, data, rc=rc)
         assert "classify_short_k" in tree.kernel_name()
@@ -114,7 +114,7 @@ def test_reference_golden_lines_through_the_lane_pass(torch_cuda, name, rc, monk
     want = b"".join(l + b"\n" for l in out.split(b"\n") if l and l.split(b"\t")[0] in names)
     monkeypatch.setenv("UTREE_LANE_PASS", "1")
     got = classify_fasta_bytes(db, tree, b"".join(h + b"\n" + q + b"\n" for h, q in keep), rc=bool(rc))
-    assert tree.kernel_name().startswith("classify_lanes_k<%d, %d," % (db.k // 4, db.I))     # (ix32: the u32-label instantiation)
+    assert tree.kernel_name().startswith(("classify_lanes_k<%d, %d," % (db.k // 4, db.I), "classify_lanes_mixed_k<%d, %d," % (db.k // 4, db.I)))     # (ix32: the u32-label instantiation; reads beyond 160 bases: the classes in one launch)
     assert got == want and len(want) > 0
 
 
@@ -145,7 +145,7 @@ def test_longer_reads_take_two_to_sixteen_lanes(torch_cuda, k, max_len, tmp_path
         monkeypatch.setenv("UTREE_LANE_PASS", "1")
         got = classify_fasta_bytes(db, tree, data, rc=rc)
         if 2 * max_len + 1 <= 2112 or not rc:
-            assert tree.kernel_name().startswith("classify_lanes_k<")
+            assert tree.kernel_name().startswith("classify_lanes_")
         monkeypatch.setenv("UTREE_LANE_PASS", "0")
         assert got == classify_fasta_bytes(db, tree, data, rc=rc)
         assert got == oracle_text(o, data, tmp_path, rc=rc)
@@ -163,7 +163,7 @@ def test_batch_sizes_around_the_grab_of_64(torch_cuda, tmp_path, monkeypatch):
     for n in (1, 2, 63, 64, 65, 127, 129, 300):
         data = fasta_bytes(reads[:n])
         assert classify_fasta_bytes(db, tree, data, rc=False) == oracle_text(o, data, tmp_path), n
-        assert tree.kernel_name().startswith("classify_lanes_k<")
+        assert tree.kernel_name().startswith("classify_lanes_")
     tree.close()
 
 
@@ -216,11 +216,11 @@ def test_hit_dense_reads_and_reads_with_more_labels_than_the_tally_table(torch_c
     for rc in (False, True):
         data = fasta_bytes(cut(4000) + [("sparse%d" % i, "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 150))) for i in range(500)])
         got = classify_fasta_bytes(db, tree, data, rc=rc)
-        assert tree.kernel_name().startswith("classify_lanes_k<")
+        assert tree.kernel_name().startswith("classify_lanes_")
         assert got == oracle_text(o, data, tmp_path, rc=rc)
     mixed = fasta_bytes(cut(300) + patchwork(300))
     got = classify_fasta_bytes(db, tree, mixed, rc=False)
-    assert tree.kernel_name().startswith("classify_lanes_k<8, 2, 16")   # 60 x 32 = 1920 bases: sixteen lanes per read (the batch's other reads take one)
+    assert tree.kernel_name().startswith("classify_lanes_mixed_k<8, 2,")   # 60 x 32 = 1920 bases: sixteen lanes per read, the batch's other reads one -- one launch for both
     assert got == oracle_text(o, mixed, tmp_path)
     big = fasta_bytes(patchwork(30_000))
     for _ in range(10):                                                              # > 256 Ki reads, all of them left over
@@ -234,7 +234,7 @@ def test_hit_dense_reads_and_reads_with_more_labels_than_the_tally_table(torch_c
     for _ in range(12):
         assert classify_fasta_bytes(db, tree, easy, rc=False) == want_easy
         names.append(tree.kernel_name())
-    assert any("classify_short_k" in x for x in names[:4]) and all(x.startswith("classify_lanes_k<") for x in names[-3:]), names
+    assert any("classify_short_k" in x for x in names[:4]) and all(x.startswith("classify_lanes_") for x in names[-3:]), names
     tree.close()
 
 
@@ -247,7 +247,7 @@ def test_synthetic_config2_shape_lanes_equals_wave_per_read(torch_cuda, monkeypa
     for rc in (False, True):
         monkeypatch.setenv("UTREE_LANE_PASS", "1")
         a = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
-        assert sdb.tree.kernel_name().startswith("classify_lanes_k<")
+        assert sdb.tree.kernel_name().startswith("classify_lanes_")
         monkeypatch.setenv("UTREE_LANE_PASS", "0")
         b = sdb.tree.classify(reads.bases, reads.off, reads.length, rc=rc)
         assert torch.equal(a, b)
@@ -273,7 +273,11 @@ def test_batch_of_mixed_lengths_is_split_by_lanes_per_read(torch_cuda, k, tmp_pa
         for rc in (False, True):
             monkeypatch.setenv("UTREE_LANE_PASS", "1")
             got = classify_fasta_bytes(db, tree, data, rc=rc)
-            assert tree.kernel_name().startswith("classify_lanes_k<")
+            assert tree.kernel_name().startswith("classify_lanes_")          # (..._mixed_k: the classes in one launch; ..._k<.., 16, .., 2, ..>: the pieces of the long reads)
+            # a launch per class (the shape until round 3) gives the same records
+            monkeypatch.setenv("UTREE_LANES_CLASS_LAUNCHES", "1")
+            assert got == classify_fasta_bytes(db, tree, data, rc=rc)
+            monkeypatch.delenv("UTREE_LANES_CLASS_LAUNCHES")
             monkeypatch.setenv("UTREE_LANE_PASS", "0")
             assert got == classify_fasta_bytes(db, tree, data, rc=rc)
             assert got == oracle_text(o, data, tmp_path, rc=rc)
@@ -383,7 +387,7 @@ def test_line_sized_buckets_option(torch_cuda, name, rc, tmp_path, monkeypatch):
             assert classify_fasta_bytes(db, tree, data, rc=bool(rc)) == want
         assert classify_fasta_bytes(db, tree, more, rc=bool(rc)) == oracle_text(o, more, tmp_path, rc=bool(rc))
         if lane_pass == "1":
-            assert tree.kernel_name().startswith("classify_lanes_k<") and tree.kernel_name().endswith(", 2, false>")
+            assert tree.kernel_name().startswith("classify_lanes_") and tree.kernel_name().endswith(", 2, false>")
     tree.close()
     monkeypatch.delenv("UTREE_BUCKET_BYTES")
     t64 = DeviceTree.upload(db, 0)

@@ -752,11 +752,26 @@ static int ring_post(utree_dev *d, const utk_workspace *w, uint32_t lane_reads, 
         const unsigned c = (d->lanes_ring_next + k) & 63u;
         if (!d->ring_inflight[c]) { slot = c; break; }
     }
-    /* (all 64 slots wait for their copies: more than 64 batches in flight on one handle -- this batch goes unreported) */
     if (slot < 64) { d->lanes_ring_next = slot + 1; d->ring_inflight[slot] = 1; d->lanes_ring_reads[slot] = lane_reads; }
     ring_unlock(d);
-    if (slot == 64) return 0;
-    return hipMemcpyAsync((void *)&d->lanes_ring[2 * slot], w->cursors + UTREE_CUR_MID, 16, hipMemcpyDeviceToHost, st) != hipSuccess;
+    if (slot == 64) {
+        /* all 64 slots wait for their copies -- more than 64 batches in flight on one handle: this batch's words are fetched with a wait (no
+         * batch's error word is dropped) */
+        unsigned long long two[2] = {0, 0};
+        if (hipMemcpyAsync(two, w->cursors + UTREE_CUR_MID, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 1;
+        ring_lock(d);
+        if (two[1] && !d->dev_error) d->dev_error = two[1];
+        ring_unlock(d);
+        ring_collect(d);
+        return 0;
+    }
+    if (hipMemcpyAsync((void *)&d->lanes_ring[2 * slot], w->cursors + UTREE_CUR_MID, 16, hipMemcpyDeviceToHost, st) != hipSuccess) {
+        ring_lock(d);                                                   /* the copy was not posted: the slot is free again */
+        d->ring_inflight[slot] = 0; d->lanes_ring_reads[slot] = 0;
+        ring_unlock(d);
+        return 1;
+    }
+    return 0;
 }
 
 int utree_classify_poll(utree_dev *d) {
@@ -943,7 +958,8 @@ int utree_classify_batch(utree_dev *d, const uint8_t *d_bases, const uint64_t *d
     if (ring_post(d, &w, lanes ? n_reads : 0, st)) { (void)hipGetLastError(); }
     /* an earlier batch's error that has arrived meanwhile is this call's to report too (utree_classify_poll after the stream has
      * drained reports this batch's own) */
-    { ring_lock(d); const unsigned long long pe = d->dev_error; ring_unlock(d); if (pe) rc = UTREE_E_DEVICE; }
+    { ring_lock(d); const unsigned long long pe = d->dev_error; ring_unlock(d);
+      if (pe) { rc = UTREE_E_DEVICE; snprintf(g_hip_msg, sizeof g_hip_msg, "an earlier batch's kernels reported error %llu: utree_classify_poll returns (and clears) it", pe); } }
 #ifdef UTREE_LANES_TIMERS
     { extern void utk_lanes_phase_dump(void); static int lcalls; if (++lcalls == 6) utk_lanes_phase_dump(); }
 #endif
@@ -972,7 +988,13 @@ const char *utree_classify_kernel_name(const utree_dev *dc) {
                  utk_lanes_both_strands(&d->kimg, d->last_rc) ? "true" : "false");
         return d->kernel_sig;
     }
-    if (d->last_lanes) {      /* (a mixed batch: the instantiation its longest read takes) */
+    if (d->last_lanes && d->last_mixed && !(getenv("UTREE_LANES_CLASS_LAUNCHES") && atoi(getenv("UTREE_LANES_CLASS_LAUNCHES")) > 0)) {
+        /* a batch of mixed lengths: one launch whose wavefronts work through the lanes-per-read classes */
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_mixed_k<%u, %u, %s, %u, %s>", d->hdr.W, d->hdr.I, d->kimg.irr_n ? "true" : "false",
+                 d->hdr.bucket_words / 8, utk_lanes_both_strands(&d->kimg, d->last_rc) ? "true" : "false");
+        return d->kernel_sig;
+    }
+    if (d->last_lanes) {      /* (a launch per class: the instantiation the batch's longest read takes) */
         snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, %d, %s, %d, %u, %s>", d->hdr.W, d->hdr.I, d->last_lanes, d->kimg.irr_n ? "true" : "false",
                  d->last_mixed ? 1 : 0, d->hdr.bucket_words / 8, utk_lanes_both_strands(&d->kimg, d->last_rc) ? "true" : "false");
         return d->kernel_sig;

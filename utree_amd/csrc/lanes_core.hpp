@@ -124,9 +124,12 @@ __device__ __forceinline__ void rest96(const uint32_t (&A)[3], const uint32_t (&
 // buckets (two requests, the two halves of one line)
 // BS: both strands from one pass (NL = 1 only; do_rc is set): a quad fetches both buckets of a run's pair -- two requests, the two halves of one line
 template <int W, int I, int SEGS, bool IRR, int MODE, int NL, bool BS>
-__global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
-void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
-                      uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws, uint32_t cls) {
+__device__ __forceinline__ void lanes_body(const utk_image &im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+                                           uint32_t n_reads, const int do_rc, utree_result *__restrict__ out, const utk_workspace &ws, const uint32_t cls,
+                                           uint32_t *stream, uint32_t *runs, uint32_t *tab, uint32_t *full, uint32_t *pref, uint64_t *ost, const uint64_t *s_reg,
+                                           const uint32_t wv) {
+    // (the wavefront's LDS -- slots, run list, tally tables, the region table -- is the kernel's: LANES_PROLOGUE; one kernel may run this body for
+    // several lanes-per-read classes one after the other, classify_lanes_mixed_k)
     constexpr bool PIECE = MODE == 2, LISTED = MODE == 1;
     static_assert(!BS || NL == 1, "both strands in one pass: 64-byte buckets");
     constexpr int NLX = BS ? 2 : NL;                                 // 16-byte loads per lane and run: the pipeline is that of the 128-byte buckets
@@ -142,16 +145,6 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
     constexpr uint32_t CB = I == 2 ? 16u : 13u, CMASK = (1u << CB) - 1u;
     // a hit waiting for its push is {lane of its read << QS | rank}
     constexpr uint32_t QS = I == 2 ? 16u : 20u, QMASK = (1u << QS) - 1u;
-    __shared__ uint32_t s_stream[LANES_WAVES][64 * STRIDE];
-    __shared__ uint32_t s_runs[LANES_WAVES][RUNS_CAP];
-    // a read's hits are tallied as they are found: TSR slots {rank << 16 | count} per read, filled from slot 0 (itree.c:1031-1040
-    // needs the distinct labels with their counts, in any order); [slot][read]: a lane's walk over its own slots is conflict-free
-    __shared__ uint32_t s_tab[LANES_WAVES][64 * TSLOTS];
-    __shared__ uint32_t s_full[LANES_WAVES][2];               // reads with more distinct labels than slots
-    __shared__ uint32_t s_pref[LANES_WAVES][64];
-    __shared__ uint64_t s_ost[LANES_WAVES][64];               // overflow descriptors of up to 64 runs
-    __shared__ uint64_t s_reg[256];
-    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) s_reg[x] = im.regions[x];   // {first bucket << 25 | buckets} of every hash region
     const uint64_t tbl = (uint64_t)(uintptr_t)im.table;
     // the bucket of a minimizer: the hash of its canonical form picks the pair, the orientation the bucket (device_common.hpp: bucket_of)
     auto bucket_addr = [&](uint32_t h, uint32_t o) -> uint64_t {
@@ -159,18 +152,7 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
         return tbl + ((2u * ((re >> UTREE_REGION_NB_BITS) + __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u))) + o) << (NL == 2 ? 7 : 6));
     };
     const uint32_t lane = lane_id();
-    const uint32_t wv = uni32(threadIdx.x >> 6);
-    uint32_t *stream = s_stream[wv];
-    uint32_t *runs = s_runs[wv];
-    uint32_t *tab = s_tab[wv];
-    uint32_t *full = s_full[wv];
-    uint32_t *pref = s_pref[wv];
-    uint64_t *ost = s_ost[wv];
     uint32_t *sl = stream + lane * STRIDE + FRONT;                        // the lane's slot, word 0
-#pragma unroll
-    for (uint32_t i = 1; i <= FRONT; ++i) sl[-(int)i] = 0;                // pads: zero for good
-    sl[NWORD] = 0; sl[NWORD + 1] = 0;
-    __syncthreads();
 
     unsigned long long chunk_base = 0;
     uint32_t chunk_left = 0;
@@ -888,15 +870,76 @@ _Pragma("unroll") for (uint32_t x = 0; x < NA; ++x) { A[x] = RA[x]; B[x] = RB[x]
 #endif
 }
 
+// the wavefront's LDS and what is set up once per launch: slots (13 or 15 words per lane), run list, tally tables {slot}{read} (a read's hits are
+// tallied as they are found: TSR slots {rank << 16 | count} per read, filled from slot 0 -- itree.c:1031-1040 needs the distinct labels with
+// their counts, in any order; a lane's walk over its own slots is conflict-free), the reads with more labels than slots, a prefix-sum scratch,
+// the overflow descriptors of up to 64 runs, the region table {first pair << 25 | pairs}
+#define LANES_PROLOGUE(W_) \
+    using G_ = Geo<W_>; \
+    __shared__ uint32_t s_stream[LANES_WAVES][64 * G_::STRIDE]; \
+    __shared__ uint32_t s_runs[LANES_WAVES][G_::RUNS]; \
+    __shared__ uint32_t s_tab[LANES_WAVES][64 * TSLOTS]; \
+    __shared__ uint32_t s_full[LANES_WAVES][2]; \
+    __shared__ uint32_t s_pref[LANES_WAVES][64]; \
+    __shared__ uint64_t s_ost[LANES_WAVES][64]; \
+    __shared__ uint64_t s_reg[256]; \
+    for (uint32_t x = threadIdx.x; x < 256; x += blockDim.x) s_reg[x] = im.regions[x]; \
+    const uint32_t wv = uni32(threadIdx.x >> 6); \
+    { uint32_t *sl_ = s_stream[wv] + lane_id() * G_::STRIDE + G_::FRONT; \
+      _Pragma("unroll") for (uint32_t i = 1; i <= G_::FRONT; ++i) sl_[-(int)i] = 0;      /* pads: zero for good */ \
+      sl_[NWORD] = 0; sl_[NWORD + 1] = 0; } \
+    __syncthreads();
+#define LANES_LDS s_stream[wv], s_runs[wv], s_tab[wv], s_full[wv], s_pref[wv], s_ost[wv], s_reg, wv
+
+template <int W, int I, int SEGS, bool IRR, int MODE, int NL, bool BS>
+__global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
+void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+                      uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws, uint32_t cls) {
+    LANES_PROLOGUE(W)
+    lanes_body<W, I, SEGS, IRR, MODE, NL, BS>(im, bases, off, len, n_reads, do_rc, out, ws, cls, LANES_LDS);
+}
+
+// A batch of mixed read lengths in ONE launch: lanes_route_k has listed the reads by the lanes they need; a wavefront works through the classes
+// one after the other -- the reads of one lane (the plain walk over the batch, passing over the longer ones), then the listed reads of two, four,
+// eight and sixteen lanes -- so that a class with few reads costs its grabs, not a launch with its start and its drain (a launch per class:
+// +10.6 % for 1 % longer reads in a 16 M-read batch, profiles/r03/mixed_batches_16M_launches.json).  max_cls: the largest class a read of the
+// batch can need.
+template <int W, int I, bool IRR, int NL, bool BS>
+__global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
+void classify_lanes_mixed_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+                            uint32_t n_reads, int do_rc, utree_result *__restrict__ out, utk_workspace ws, uint32_t max_cls) {
+    LANES_PROLOGUE(W)
+    lanes_body<W, I, 1, IRR, 0, NL, BS>(im, bases, off, len, n_reads, do_rc, out, ws, 1u, LANES_LDS);
+    if (max_cls >= 1u) lanes_body<W, I, 2, IRR, 1, NL, BS>(im, bases, off, len, n_reads, do_rc, out, ws, 1u, LANES_LDS);
+    if (max_cls >= 2u) lanes_body<W, I, 4, IRR, 1, NL, BS>(im, bases, off, len, n_reads, do_rc, out, ws, 2u, LANES_LDS);
+    if (max_cls >= 3u) lanes_body<W, I, 8, IRR, 1, NL, BS>(im, bases, off, len, n_reads, do_rc, out, ws, 3u, LANES_LDS);
+    if (max_cls >= 4u) lanes_body<W, I, 16, IRR, 1, NL, BS>(im, bases, off, len, n_reads, do_rc, out, ws, 4u, LANES_LDS);
+}
+
+static inline uint32_t lanes_resident_blocks(int W, int n_cu) {
+    const uint32_t wps = W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS;
+    return (uint32_t)n_cu * (4u * wps / LANES_WAVES > 0 ? 4u * wps / LANES_WAVES : 1u);
+}
+
 template <int W, int I, int SEGS, bool IRR, int MODE, int NL, bool BS = false>
 static int launch_lanes(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
                         int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream, uint32_t cls = 0) {
     static_assert(NL == 1 || NL == 2, "bucket size");
     uint32_t blocks = (n_reads + (64u / SEGS) * LANES_WAVES - 1) / ((64u / SEGS) * LANES_WAVES);
-    const uint32_t wps = W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS;
-    const uint32_t cap = (uint32_t)n_cu * (4u * wps / LANES_WAVES > 0 ? 4u * wps / LANES_WAVES : 1u);
+    const uint32_t cap = lanes_resident_blocks(W, n_cu);
     if (blocks > cap) blocks = cap;
     classify_lanes_k<W, I, SEGS, IRR, MODE, NL, BS><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws, cls);
+    return (int)hipGetLastError();
+}
+
+template <int W, int I, bool IRR, int NL, bool BS = false>
+static int launch_lanes_mixed(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
+                              int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream, uint32_t max_cls) {
+    // (the classes' read counts are on the device: the grid is what the batch's reads of one lane could fill, at most the resident one)
+    uint32_t blocks = (n_reads + 64u * LANES_WAVES - 1) / (64u * LANES_WAVES);
+    const uint32_t cap = lanes_resident_blocks(W, n_cu);
+    if (blocks > cap) blocks = cap;
+    classify_lanes_mixed_k<W, I, IRR, NL, BS><<<dim3(blocks), dim3(LANES_WAVES * 64), 0, (hipStream_t)stream>>>(*im, d_bases, d_off, d_len, n_reads, do_rc, d_out, *ws, max_cls);
     return (int)hipGetLastError();
 }
 

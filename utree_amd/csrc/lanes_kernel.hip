@@ -240,12 +240,18 @@ int utk_classify_lanes_mixed(const utk_image *im, const uint8_t *d_bases, const 
     lc.mid_cap = UTREE_MID_CAP;
     lanes_route_k<<<dim3((n_reads + ROUTE_CHUNK - 1) / ROUTE_CHUNK), dim3(256), 0, (hipStream_t)stream>>>(d_len, n_reads, do_rc, *ws, lc);
     int rc = (int)hipGetLastError();
+    int max_cls = 0;
+    while (max_cls < 4 && max_len > lc.cap[max_cls]) ++max_cls;             // the largest class a read of the batch can need
+    const char *pe = getenv("UTREE_LANES_CLASS_LAUNCHES");                  // =1: a launch per class, as until round 3 (A/B, tests)
+    const int per_class = pe && atoi(pe) > 0;
+    if (!per_class) {
+        // ONE launch: its wavefronts work through the classes one after the other (classify_lanes_mixed_k)
+        if (!rc) rc = lanes_launch(im, 0, 3, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, (uint32_t)max_cls);
+        return rc;
+    }
     // the reads of one lane: the plain launch over the batch, told to pass over the longer ones (no list, no trip to it per grab)
     if (!rc) rc = lanes_launch(im, 1, 0, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, 1u);
-    for (int c = 1; c < 5 && !rc; ++c) {
-        if (max_len <= lc.cap[c - 1]) break;                               // no read of the batch needs this many lanes
-        rc = lanes_class_launch(im, c, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream);
-    }
+    for (int c = 1; c <= max_cls && !rc; ++c) rc = lanes_class_launch(im, c, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream);
     return rc;
 }
 

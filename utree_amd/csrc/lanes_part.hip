@@ -16,6 +16,17 @@ extern "C" int CAT(utk_lanes_part_, LANES_W, LANES_I, LANES_NL)(int segs, int ir
 #else
 #define GO(S_, M_) { if (bs) return (int)hipErrorInvalidValue; GO2(S_, M_, false); }
 #endif
+    if (mode == 3) {                                           // a batch of mixed lengths, every lanes-per-read class in one launch (cls: the largest class)
+#define GOM(B_) return irr ? launch_lanes_mixed<LANES_W, LANES_I, true, LANES_NL, B_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls) \
+                           : launch_lanes_mixed<LANES_W, LANES_I, false, LANES_NL, B_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
+#if LANES_NL == 1
+        if (bs && do_rc) { GOM(true); }
+#else
+        if (bs) return (int)hipErrorInvalidValue;
+#endif
+        GOM(false);
+#undef GOM
+    }
     if (mode == 0 && segs == 1) GO(1, 0)                       // a batch of reads of up to 160 bases, whole
     if (mode == 2 && segs == 16) GO(16, 2)                     // pieces of long reads
     if (mode == 1) {                                           // one length class of a mixed batch
