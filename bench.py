@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- reads classified / second on BASELINE.json's config 2: 8 GB L2 CTR (1 217 000 000 synthetic
 32-mer nodes, 21 844 labels), 150 bp synthetic reads, 160 M reads per GPU by default (10 steps x 16 M-read batches; a
-launch over 16 M reads classifies a read 10-12 % faster than one over 4 M: profiles/r03/batch_sizes.txt).
+launch over 16 M reads classifies a read 10-12 % faster than one over 4 M: profiles/r03/batch_sizes.txt, DESIGN_APPENDIX.md section 0.12).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -12,7 +12,7 @@ HBM; the database image is resident too.  Reads shard across ranks (each rank ha
 scaling, no data-path collective); the only collective is the one-off RCCL broadcast of the database image
 from rank 0 before the timed region, issued from C (utree_dev_replicate_rank).  Rank 0 prints ONE JSON line.
 
-Extra objects on that line:
+Extra objects on that line (DESIGN.md sections 6 and 9):
   roofline      dominant kernel (classify_lanes_k, or classify_short_k / classify_long_k for images it does not take): bytes the kernel must move per launch by the byte model of the image AS
                 BUILT (distinct 128-byte buckets per read, counted on the device) / average launch duration measured with
                 HIP events on the launch stream, against 8 TB/s; next to it the PMC-measured HBM fraction and the VALU / SALU
@@ -55,7 +55,7 @@ def contract_bytes_per_read(n_nodes: int, W: int, I: int, read_len: int):
 
 
 def resolve_defaults(args):
-    """Launch size and file-leg size when the command line leaves them open: 16 M reads per launch (about the same
+    """Launch size and file-leg size when the command line leaves them open: 16 M reads per launch (DESIGN_APPENDIX.md section 0.12; about the same
     number of BASES per launch for long reads; 4 M for the hit-dense workload, whose kept profile is of that size), and config 2's 40 M
     reads -- or all the reads of the run, if fewer -- through the file -> file leg."""
     if args.batch_reads <= 0:
@@ -81,7 +81,7 @@ def main():
                          "the CPU / file legs are for fixed-length batches only")
     ap.add_argument("--workload", default="config", choices=("config", "hit_dense"),
                     help="hit_dense: a database of RELATED genomes built by the product's own utree-buildGG + xtree-compress (--refs x --ref-len) and "
-                         "reads cut from them (a secondary workload, DESIGN.md section 11; N = 1, no CPU / file legs)")
+                         "reads cut from them (a secondary workload, DESIGN_APPENDIX.md section 11; N = 1, no CPU / file legs)")
     ap.add_argument("--refs", type=int, default=1000)
     ap.add_argument("--ref-len", type=int, default=1_000_000)
     ap.add_argument("--kmer", type=int, default=32, choices=(32, 64))
@@ -317,7 +317,7 @@ def main():
             line["bcast"] = bcast_how
             line["scaling_note"] = ("value is the HBM-resident rate: every rank classifies its own batches, so it scales with the GPUs by construction (weak scaling, "
                                     "no data-path collective).  The file -> file rate (`e2e`) scales only while every rank writes its own output file; "
-                                    "ONE concatenated output file fills at the host's page-allocation rate (~6 GB/s on this class of box, DESIGN.md section 5b) "
+                                    "ONE concatenated output file fills at the host's page-allocation rate (~6 GB/s on this class of box, DESIGN.md section 7) "
                                     "whatever the number of GPUs")
     if want_e2e_dist:
         # every rank takes part: its own shard of the reads, file -> file on its own GPU; rank 0 reports
@@ -435,7 +435,7 @@ def e2e_leg_dist(args, sdb, tree, rank, world, dev, udist):
             out["concat_seconds"] = time.time() - t0
             out["value_with_concat"] = reads / (slowest + out["concat_seconds"])
             out["bound"] = ("per-rank output files: each rank fills its own file; the host-side concatenation of %.2f GB into ONE file took %.2f s "
-                            "(page allocation of one file, DESIGN.md section 5b)" % (sum(p["bytes_out"] for p in parts) / 1e9, out["concat_seconds"]))
+                            "(page allocation of one file, DESIGN.md section 7)" % (sum(p["bytes_out"] for p in parts) / 1e9, out["concat_seconds"]))
             # the last rank's shard once more on rank 0's replica
             code, st2 = search_gg(sdb.ctr, [tree], os.path.join(d, "reads_%d.fa" % (world - 1)), os.path.join(d, "again.txt"), rc=bool(args.rc), threads=16)
             ulib.check(code, "utree_search_file (cross-replica check)")
@@ -640,7 +640,7 @@ def roofline(args, tree, batch, out0, W, avg_launch_s, k_launches, kernel_sig, u
                                             "traffic runs at random_line_frac of the rate at which this chip serves random lines -- the lever is lines per read, not bytes per line" % what)
                 else:
                     roof["limiter_note"] = ("no unit is saturated: the kernel is bound by each wavefront's chain of dependent steps (LDS round trips, two bucket "
-                                            "fetches, the tally) at the hardware's limit of 8 wavefronts per SIMD -- DESIGN.md section 5 has the experiments")
+                                            "fetches, the tally) at the hardware's limit of 8 wavefronts per SIMD -- DESIGN_APPENDIX.md section 5a has the experiments")
     except Exception as ex:                                   # a broken profile file must not take the line down
         prof["why_not"] = repr(ex)
     roof["profile"] = prof

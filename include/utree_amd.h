@@ -201,7 +201,7 @@ int utree_lookup_words(utree_dev *dev, const uint64_t *d_hi, const uint64_t *d_l
 /* Name of the dominant kernel as rocprofv3 reports it and the wall time (ms) HIP events measured around
  * its launches since the last call with reset != 0 (bench.py's roofline leg). */
 const char *utree_classify_kernel_name(const utree_dev *dev);
-/* Measurement aid for the byte model of the bucketed image (bench.py): over the reads of up to 640 staged
+/* Measurement aid for the byte model of the bucketed image (bench.py, DESIGN.md sections 4 and 6): over the reads of up to 640 staged
  * bases, h_counts5 = { reads, valid k-mer windows, distinct 64-byte buckets per read (summed), distinct 128-byte HBM lines per
  * read (summed), distinct buckets that carry an overflow descriptor }.  Synchronous.  Evaluated window by window with the
  * load-time minimizer code, independently of the search kernels' sliding minimum. */

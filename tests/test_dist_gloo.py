@@ -101,7 +101,7 @@ def test_bench_gpus_flag_launches_one_rank_per_gpu(monkeypatch):
 
 
 def test_bench_launch_size_defaults():
-    """What bench.py runs when the command line leaves the launch size open: 16 M reads per launch for the 150-bp
+    """What bench.py runs when the command line leaves the launch size open (DESIGN_APPENDIX.md section 0.12): 16 M reads per launch for the 150-bp
     configurations, about as many bases per launch for long reads, the kept profile's 4 M for the hit-dense workload; the file -> file leg
     takes config 2's 40 M reads, or the whole run when that is less.  An explicit --batch-reads / --e2e-reads stands."""
     import argparse

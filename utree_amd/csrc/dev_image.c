@@ -40,7 +40,7 @@ static int timing_on(void) { return getenv("UTREE_TIMING") != NULL || getenv("UT
 static uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 
 /* A bucket's size, in 8-byte words: 8 (64 bytes) unless UTREE_BUCKET_BYTES=128 asks for line-sized buckets (16).  Same-box on config 2
- * (profiles/r03/ab_v8_vs_v9.txt): 64-byte buckets make the classify kernels 5-10 % faster -- half the entries to scan
+ * (profiles/r03/ab_v8_vs_r03_128B_buckets.txt, DESIGN_APPENDIX.md section 0.2): 64-byte buckets make the classify kernels 5-10 % faster -- half the entries to scan
  * per lookup, one request per bucket instead of two --, 128-byte buckets make the image a third smaller (twice the nodes per bucket at the
  * same overflow rate) and every fetched byte one that is looked at. */
 /* The default depends on the database: a 16-mer's hash is one of 2^32 values and the minimizer is a MINIMUM, so at the dense end of the hash
@@ -65,7 +65,7 @@ static uint32_t bucket_words_default(uint64_t n_nodes, uint32_t W) {
  * 8 = as many as the density asks, 0 = 256 values per bucket everywhere).  Default TARGET: 128-byte buckets are filled to 56 % (config
  * 2: 9 of 16 entries, image 17.6 GiB, 0.3 overflowing buckets per 150 bp read), 64-byte buckets to 37.5 % (3 of 8, 22.9 GiB, 0.28).  The
  * dense end of the hash range has several nodes per hash VALUE, so a bucket there holds the nodes of one, two or three values: a
- * mixture, not one Poisson mean -- which is why the small buckets want the lower load (DESIGN.md section 3 has the sweeps). */
+ * mixture, not one Poisson mean -- which is why the small buckets want the lower load (DESIGN_APPENDIX.md sections 0.2 and 3 have the sweeps). */
 /* share of a bucket's NODES that sit in a bucket of more than `cap` of them, the bucket's load being Poisson(lam): sum_{k > cap} k P(k) / lam */
 static double pois_tail_nodes(double lam, uint32_t cap) {
     if (lam <= 0) return 0;
