@@ -71,7 +71,7 @@ template <int W> struct Geo {
     static constexpr uint32_t NA = W == 16 ? 3 : 1;                    // words of bases in front of / behind the minimizer a k-mer may reach
     static constexpr uint32_t FRONT = NA;                              // pad words in front of a lane's slot
     static constexpr uint32_t STRIDE = NWORD + FRONT + 2;              // ... and two behind; odd: lane slots fall on different banks
-    static constexpr uint32_t RUNS = W == 16 ? 512 : 1024;             // runs per 64 reads (150 bp: mean 14 per read for k = 32, 4 for k = 64)
+    static constexpr uint32_t RUNS = W == 16 ? 512 : 1280;             // runs per 64 lanes (150 bp reads: mean 14.1 per lane for k = 32, 4.4 for k = 64; pieces of long reads: 15.3 per lane of 129 windows -- 980 +- 20 per wavefront, and a wavefront whose list is full leaves its reads to the wave-per-read kernels: 1024 did that to 120 of 400 000 10 kb reads, 1.4 ms of classify_long_k per 17 ms step)
     static constexpr uint32_t DNONE = 63;                              // minimizer offset no run has (<= 48)
     static_assert((STRIDE & 1) == 1, "slot geometry");
 };
@@ -904,6 +904,8 @@ void classify_lanes_k(utk_image im, const uint8_t *__restrict__ bases, const uin
 // eight and sixteen lanes -- so that a class with few reads costs its grabs, not a launch with its start and its drain (a launch per class:
 // +10.6 % for 1 % longer reads in a 16 M-read batch, profiles/r03/mixed_batches_16M_launches.json).  max_cls: the largest class a read of the
 // batch can need.
+// (the bodies are inlined: called as functions -- one register allocation each -- their LDS pointers become generic ones and every LDS access a flat
+// one: 1.87 x the time, profiles/r04/mixed_one_launch_called_16M.json; inlined five times over, the hot body spills 70-90 registers and is still the faster)
 template <int W, int I, bool IRR, int NL, bool BS>
 __global__ __launch_bounds__(LANES_WAVES * 64, W == 16 ? UTREE_LANES_WPS64 : UTREE_LANES_WPS)
 void classify_lanes_mixed_k(utk_image im, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
