@@ -119,6 +119,9 @@ def main():
     cli_leg_result = None
     if ((int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0 and not args.no_cli_leg) or os.environ.get("UTREE_BENCH_CLI_LEG")) \
             and args.workload == "config" and args.len_dist == "fixed":
+        import torch as _t
+        if _t.cuda.device_count() < 1:                             # (counting devices does not initialise one)
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
         try:
             cli_leg_result = cli_leg(args)
         except Exception as ex:                                   # the leg must never take the benchmark line down
@@ -151,10 +154,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:
+        # (rank 0 may arrive minutes late: it times the command-line leg first, as children, before it touches a GPU)
+        import datetime
+        pg_timeout = datetime.timedelta(minutes=30)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=pg_timeout)
     W = args.kmer // 4
     var_len = args.len_dist != "fixed"
     hit_dense = args.workload == "hit_dense"
@@ -497,7 +503,7 @@ def cli_leg(args):
         t0 = time.time()
         gen = [sys.executable, os.path.abspath(__file__), "--make-files", d, "--nodes", str(args.nodes), "--kmer", str(args.kmer), "--read-len", str(args.read_len),
                "--e2e-reads", str(args.e2e_reads), "--fine-bits", str(args.fine_bits)]
-        subprocess.run(gen, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+        subprocess.run(gen, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420)
         out["make_files_seconds"] = time.time() - t0
         time.sleep(15)                                             # (the generator has just freed ~100 GB of HBM: see db_load_leg)
         cli = os.path.join(ROOT, "utree_amd", "xtree-searchGG")
@@ -505,7 +511,8 @@ def cli_leg(args):
         env["UTREE_TIMING"] = "1"                                  # the loader's and the pipeline's phase lines on stderr
         cmd = [cli, os.path.join(d, "db.ctr"), os.path.join(d, "reads.fa"), os.path.join(d, "out.txt"), "16"] + (["RC"] if args.rc else [])
         t0 = time.time()
-        p = subprocess.run(cmd, env=env, capture_output=True, timeout=900)
+        # (a fan-out that hangs on a machine this code has never seen must not take the ranks' rendezvous down with it)
+        p = subprocess.run(cmd, env=env, capture_output=True, timeout=300)
         wall = time.time() - t0
         err = p.stderr.decode(errors="replace")
         out.update(exit_code=p.returncode, wall_seconds=wall, reads=args.e2e_reads, output_bytes=os.path.getsize(os.path.join(d, "out.txt")) if p.returncode == 0 else 0)
