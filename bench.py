@@ -879,26 +879,35 @@ def db_load_leg(args, sdb, tree, files):
     # erratically: tools/alloc_probe.c, profiles/r04/alloc_probe.txt.  A command line started on an idle GPU does not meet that; this process
     # has just freed tens of GB, so it idles first)
     idle = float(os.environ.get("UTREE_BENCH_IDLE_BEFORE_LOAD", "15"))
-    time.sleep(idle)
-    t0 = time.time()
-    db2 = CtrDB.open(path)
-    t1 = time.time()
-    t2_tree = DeviceTree.upload(db2, tree.info.device)
-    torch.cuda.synchronize()
-    t2 = time.time()
-    ph = (C.c_double * 4)()
-    ulib.load().utree_dev_upload_seconds(ph)
     from utree_amd import synth
     chk = synth.make_reads(sdb, 200_000, args.read_len, seed=synth.READ_SEED + 4242, device=tree_device(tree))
-    same = bool(torch.equal(tree.classify(chk.bases, chk.off, chk.length, rc=bool(args.rc)), t2_tree.classify(chk.bases, chk.off, chk.length, rc=bool(args.rc))))
-    img = t2_tree.info.image_bytes
-    t2_tree.close()
-    db2.close()
-    return {"seconds": t2 - t0, "idle_seconds_before": idle, "file_bytes": os.path.getsize(path), "image_bytes": int(img),
+    want = tree.classify(chk.bases, chk.off, chk.length, rc=bool(args.rc))
+    runs = []
+    same = True
+    for rep in range(2):                                           # twice, idling before each: the waits are erratic, the smaller one is the loader's own time
+        time.sleep(idle)
+        t0 = time.time()
+        db2 = CtrDB.open(path)
+        t1 = time.time()
+        t2_tree = DeviceTree.upload(db2, tree.info.device)
+        torch.cuda.synchronize()
+        t2 = time.time()
+        ph = (C.c_double * 4)()
+        ulib.load().utree_dev_upload_seconds(ph)
+        same = same and bool(torch.equal(want, t2_tree.classify(chk.bases, chk.off, chk.length, rc=bool(args.rc))))
+        img = t2_tree.info.image_bytes
+        t2_tree.close()
+        db2.close()
+        runs.append((t2 - t0, t1 - t0, ph[0], ph[1], ph[2]))
+    best = min(runs)
+    t0, t1, t2 = 0.0, best[1], best[0]
+    ph = [best[2], best[3], best[4]]
+    return {"seconds": t2 - t0, "runs_seconds": [r[0] for r in runs], "idle_seconds_before": idle, "file_bytes": os.path.getsize(path), "image_bytes": int(img),
             "phases_seconds": {"utree_ctr_open (header, bin table, labels)": t1 - t0, "device + image allocation, labels": ph[0],
                                "node dump: file -> pinned -> HBM, repacked as it arrives": ph[1], "bin-table check, minimizer sort, buckets, packing": ph[2]},
             "file_GBps": os.path.getsize(path) / max(1e-9, ph[1]) / 1e9,
-            "note": "the .ctr file is in /dev/shm (page cache): a cold file adds its storage's read time",
+            "note": "the .ctr file is in /dev/shm (page cache): a cold file adds its storage's read time; `seconds` and the phases are the faster of two loads: a large "
+                    "hipMalloc that follows a large free waits for the driver's background scrub of the freed HBM (DESIGN.md section 3), which this process cannot avoid",
             "classifies_like_the_benchmarked_image": same}
 
 

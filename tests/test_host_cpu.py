@@ -340,3 +340,30 @@ def test_fanout_falls_back_to_uploads_when_the_broadcast_fails(capfd):
     rc = L.utree_dev_fanout_with(None, dev0, devs, n, lib.FINE_AUTO, out, C.byref(how),
                                  C.cast(lib.REPLICATE_FN(lambda *a: lib.E_ARG), C.c_void_p), C.cast(lib.UPLOAD_FN(up), C.c_void_p))
     assert rc == lib.E_ARG and calls["up"] == []
+
+
+def test_image_size_follows_the_region_model(monkeypatch):
+    """utree_dev_image_bytes = the layout the loader builds in (dev_image.c: compute_regions + layout), evaluated on the host.  The table is
+    sized region by region from the minimizer-hash density and, since image version 11, from the lumps that half-occupied hash values make
+    (only every other hash value is some canonical 16-mer's): BASELINE's config 2 needs 40-odd GiB built (its final image: 40.8), without
+    the lump model a third less at four times the overflow, a PACKSIZE=16 tree 8 GiB whatever its size."""
+    L = lib.load()
+    bins = np.zeros((1 << 24) + 1, dtype=np.uint64)
+
+    def image_gib(W, n):
+        bins[-1] = n
+        db = CtrDB.from_memory(W, 2, n, bins, None, b"k__A;p__B\t1\n")
+        g = L.utree_dev_image_bytes(db._h, lib.FINE_AUTO) / 2.0**30
+        db.close()
+        return g
+    monkeypatch.delenv("UTREE_BUCKET_BYTES", raising=False)
+    monkeypatch.delenv("UTREE_LUMP_SLACK", raising=False)
+    c2 = image_gib(8, 1_217_000_000)
+    assert 55 < c2 < 66                                    # table 40.6 + build areas (all nodes' records twice)
+    monkeypatch.setenv("UTREE_LUMP_SLACK", "0")
+    assert c2 - 18 < image_gib(8, 1_217_000_000) < c2 - 12  # the naive sizing: 15 GiB less table
+    monkeypatch.delenv("UTREE_LUMP_SLACK")
+    assert image_gib(8, 2_000_000) < 3.0                   # a toy: the floor of 2^16 pairs per region
+    sizes = [image_gib(8, n) for n in (100_000_000, 300_000_000, 600_000_000, 1_217_000_000)]
+    assert sizes == sorted(sizes)
+    assert 8.0 < image_gib(4, 1000) < 8.3 and 8.0 < image_gib(4, 3_000_000_000) < 8.0 + 3 * 8 * 3.1   # PACKSIZE=16: 2^32 ranks + the records while building
