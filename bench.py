@@ -829,6 +829,27 @@ def e2e_leg(args, sdb, tree, files, cpu):
                          "bytes_out": int(st.bytes_out), "pipeline": "device text" if st.pipeline else "host text", "lanes": int(st.n_lanes),
                          "lane_seconds": {"read": st.seconds_read, "h2d_frame": st.seconds_frame, "classify_format": st.seconds_classify_format,
                                           "order_and_write_turn_wait": st.seconds_order_wait, "d2h": st.seconds_d2h, "write": st.seconds_write}})
+        # opt-in: the output as 8 part files filled side by side (UTREE_OUTPUT_PARTS; their concatenation must be the one-file output)
+        try:
+            P = 8
+            os.environ["UTREE_OUTPUT_PARTS"] = str(P)
+            t0 = time.time()
+            code, stp = search_gg(sdb.ctr, [tree], fa, files.path("outp.txt"), rc=bool(args.rc), threads=16)
+            wall = time.time() - t0
+            os.environ.pop("UTREE_OUTPUT_PARTS", None)
+            ulib.check(code, "utree_search_file (output in parts)")
+            hp = hashlib.sha256()
+            for q in range(P):
+                pp = files.path("outp.txt.part%03d" % q)
+                with open(pp, "rb") as f:
+                    hp.update(f.read())
+                os.unlink(pp)
+            out["output_in_parts"] = {"parts": P, "wall_seconds": wall, "reads_per_second": stp.n_reads / wall, "bytes_out": int(stp.bytes_out),
+                                      "concatenation_identical_to_the_one_file_output": hp.hexdigest() == hashes[0],
+                                      "what": "UTREE_OUTPUT_PARTS=%d: output.txt.part000 ... filled side by side (one new file fills at ~6-7 GB/s whatever writes it, "
+                                              "8 files at 58 GB/s: tools/hostio_probe3.c); opt-in, the default stays one file like the reference's" % P}
+        finally:
+            os.environ.pop("UTREE_OUTPUT_PARTS", None)
         to_file = sorted(runs[:3], key=lambda r: r["reads_per_second"])
         best = to_file[1]                                     # the median of the three runs that write the file
         out["value"] = best["reads_per_second"]

@@ -393,3 +393,37 @@ def test_three_byte_records_fill_a_chunk(torch_cuda, tmp_path):
     assert code == lib.OK and ocode == 0
     assert got == want.read_bytes() and len(got) > 0
     assert st.n_reads == nr == data.count(b"\n") // 2 and st.good_finds == good
+
+
+@pytest.mark.parametrize("parts", [3, 7])
+def test_output_in_parts_concatenates_to_the_one_file_output(torch_cuda, parts, tmp_path, monkeypatch):
+    """UTREE_OUTPUT_PARTS=P: part p holds the lines of the chunks that start in the p-th P-th of the input, the parts are filled side by
+    side (writers of ONE file serialise on its inode: tools/hostio_probe3.c), and their concatenation is byte for byte the file the
+    reference writes -- also when the host pipeline takes the search over (everything in part 000) and with two device handles."""
+    monkeypatch.setenv("UTREE_CHUNK_BYTES", "20000")
+    monkeypatch.setenv("UTREE_OUTPUT_PARTS", str(parts))
+    db, tree = tree_for("toy")
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    want = util.fixture_bytes("toy_out_rc.txt.gz")
+    fa, out = tmp_path / "in.fa", tmp_path / "out.txt"
+    fa.write_bytes(data)
+
+    def cat():
+        names = sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("out.txt.part"))
+        assert names == ["out.txt.part%03d" % i for i in range(parts)] and not out.exists()
+        return b"".join((tmp_path / n).read_bytes() for n in names), [(tmp_path / n).stat().st_size for n in names]
+    code, st = search_gg(db, [tree], str(fa), str(out), rc=True, threads=4)
+    got, sizes = cat()
+    assert code == lib.OK and st.pipeline == 1 and got == want and st.bytes_out == len(want)
+    assert min(sizes) > 0.5 * len(want) / parts                                   # (the parts really share the output)
+    # the host pipeline (a NUL byte in a late chunk hands the search over): all of the output in part 000
+    o = orc.OracleDB.load(util.fixture_ctr("toy"))
+    bad = bytearray(data[:300_000]); bad = bad[: bad.rfind(b"\n>") + 1]
+    at = bad.index(b"\n", bad.index(b"\n>", 200_000) + 1) + 20
+    bad[at] = 0
+    fa.write_bytes(bytes(bad))
+    wantf = tmp_path / "want.txt"
+    ocode, nr, good, err = o.search_file(str(fa), str(wantf), threads=4, rc=True)
+    code, st = search_gg(db, [tree], str(fa), str(out), rc=True, threads=4)
+    got, sizes = cat()
+    assert code == lib.OK and st.pipeline == 0 and got == wantf.read_bytes() and sizes[1:] == [0] * (parts - 1)

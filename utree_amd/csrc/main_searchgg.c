@@ -13,6 +13,8 @@
  *     UTREE_FINE_BITS=<F>   extra prefix bits of the device index (default: auto)
  *     UTREE_INPUT=auto|fastq|fasta   opt-in: FASTQ / multi-line FASTA records, plain or gzip (default: the reference's
  *                           two-lines-per-read framing, bit-compatible)
+ *     UTREE_OUTPUT_PARTS=<P> opt-in: the output as P files output.txt.part000 ... (their concatenation is output.txt as the reference writes
+ *                           it with one thread); ONE new file fills at ~6 GB/s on a Linux host whatever writes it, P files P times that
  * `threads` sizes the host formatting team (the GPU does the search).  `SPEED` is parsed and ignored, as
  * in the reference (itree.c:858, 907-918).
  */

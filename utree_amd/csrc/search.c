@@ -359,6 +359,15 @@ static int search_file(const utree_ctr *ctr, utree_dev **devs, int n_dev, const 
         /* the output is a pipe and the device pipeline has written the chunks in front of `in_off`: go on from there, on the same descriptor */
         P->fo = resume.fo; P->start_off = (off_t)resume.in_off;
         P->st.n_reads = resume.n_reads; P->st.good_finds = resume.good_finds; P->st.bytes_in = resume.bytes_in; P->st.bytes_out = resume.bytes_out;
+    } else if (utree_output_parts() > 1) {
+        /* UTREE_OUTPUT_PARTS: this pipeline writes in input order with one writer, so all of the output is part 000 and the other parts are
+         * empty files -- the parts' concatenation is the output, as with the device pipeline's side-by-side parts */
+        char name[4096];
+        for (int p = utree_output_parts() - 1; p >= 0; --p) {
+            snprintf(name, sizeof name, "%s.part%03d", out_path, p);
+            const int f = open(name, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (p == 0) P->fo = f; else if (f >= 0) close(f); else { P->fo = -1; break; }
+        }
     } else
     P->fo = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);                   /* fopen(outfile, "wb"), itree.c:834 */
     if (P->fd < 0 || P->fo < 0) {                                                 /* itree.c:835 */

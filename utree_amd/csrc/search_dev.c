@@ -174,10 +174,19 @@ struct dpipe {
     off_t file_size;
     size_t chunk_bytes;
     pthread_mutex_t mu; pthread_cond_t cv;
-    pthread_mutex_t wmu;                        /* one pwrite at a time: writers of ONE file serialise on its inode anyway, and
-                                                 * concurrent ones only fight over it (tmpfs, measured: 4 writers 3.0 GB/s, one 5.7 GB/s) */
-    off_t next_off; uint64_t n_taken;           /* chunk dispenser                                                  */
-    uint64_t published; off_t cum_out;          /* chunks whose output offset is fixed; text bytes before the next  */
+    /* one pwrite at a time PER FILE: writers of one file serialise on its inode anyway, and concurrent ones only fight over it (tmpfs,
+     * measured: 4 writers 3.0 GB/s, one 5.7 GB/s).  Different files do not: UTREE_OUTPUT_PARTS=P writes <out>.part000 ... <out>.part(P-1) --
+     * part p takes the chunks that start in the p-th P-th of the input, so the parts' concatenation is the one-file output -- and fills them side
+     * by side (tools/hostio_probe3.c: 1 file 7.5 GB/s, 4 files 28.8, 16 files 93) */
+    int n_parts;
+    int fo_part[UTREE_MAX_OUT_PARTS];
+    pthread_mutex_t wmu[UTREE_MAX_OUT_PARTS];
+    uint64_t taken_part[UTREE_MAX_OUT_PARTS], published_part[UTREE_MAX_OUT_PARTS];   /* chunks handed out / whose output offset is fixed, per part */
+    off_t cum_part[UTREE_MAX_OUT_PARTS];        /* text bytes in front of a part's next chunk                         */
+    off_t next_off; uint64_t n_taken;           /* chunk dispenser: where the last chunk handed out ends, chunks handed out */
+    off_t next_off_part[UTREE_MAX_OUT_PARTS], part_end[UTREE_MAX_OUT_PARTS];   /* ... per part of the input (find_parts); parts take turns */
+    int next_part;
+    off_t cum_out;                              /* text bytes of all published chunks                               */
     int seq_out; uint64_t written;              /* the output cannot seek (pipe, FIFO, tty): chunks are written in order with write() */
     uint64_t printed;                           /* progress lines already on stdout (a host re-run must not repeat them) */
     uint64_t n_reads, good, next_progress, bytes_in;
@@ -206,14 +215,28 @@ static void dretry(dpipe *P, uint64_t c, off_t off, int locked) {
 }
 #define DROPPED(P, c) ((P)->retry_set && (c) > (P)->retry_at)      /* a chunk behind the one the host pipeline continues from */
 
-/* Next chunk [off, off+len): ends after a '\n' that a '>' follows, or at the end of the file.  Called with the lock held.
- * Returns 0 = none left, 1 = chunk, -1 = no record boundary inside a chunk's worth of bytes. */
-static int take_chunk(dpipe *P, off_t *off, size_t *len, int *final, uint64_t *index) {
-    if (P->next_off >= P->file_size) return 0;
-    const off_t a = P->next_off;
+/* Next chunk [off, off+len): ends after a '\n' that a '>' follows, or at the end of its part of the file.  Called with the lock held.
+ * Returns 0 = none left, 1 = chunk, -1 = no record boundary inside a chunk's worth of bytes.
+ * The input is cut into n_parts consecutive ranges at record boundaries (find_parts; one range = the whole file without UTREE_OUTPUT_PARTS)
+ * and the chunks are dealt out from the parts in turn, so that the lanes at work write to DIFFERENT output files. */
+static int take_chunk(dpipe *P, off_t *off, size_t *len, int *final, uint64_t *index, int *part, uint64_t *in_part) {
+    int p = -1;
+    for (int k = 0; k < P->n_parts; ++k) {
+        const int q = (P->next_part + k) % P->n_parts;
+        if (P->next_off_part[q] < P->part_end[q]) { p = q; break; }
+    }
+    if (p < 0) return 0;
+    P->next_part = (p + 1) % P->n_parts;
+    const off_t a = P->next_off_part[p], end = P->part_end[p];
+    *part = p;
+    *in_part = P->taken_part[p];
     const size_t cb = P->chunk_bytes;
-    size_t want = (size_t)(P->file_size - a < (off_t)cb ? P->file_size - a : (off_t)cb);
-    if (a + (off_t)want == P->file_size) { *off = a; *len = want; *final = 1; *index = P->n_taken++; P->next_off = P->file_size; return 1; }
+    size_t want = (size_t)(end - a < (off_t)cb ? end - a : (off_t)cb);
+    if (a + (off_t)want == end) {                                /* the rest of the part: it ends at a record boundary, or with the file */
+        *off = a; *len = want; *final = end == P->file_size; *index = P->n_taken++; P->taken_part[p]++; P->next_off_part[p] = end;
+        P->next_off = a + (off_t)want;
+        return 1;
+    }
     /* look backwards from the end of the range for "\n>", a window at a time (one more byte: the '>' may be the byte after) */
     size_t hi = want;                                            /* candidates: newline positions < hi (relative to a) */
     while (hi > 0) {
@@ -226,14 +249,41 @@ static int take_chunk(dpipe *P, off_t *off, size_t *len, int *final, uint64_t *i
         }
         for (size_t i = win; i-- > 0;) {
             if (P->tail[i] == '\n' && P->tail[i + 1] == '>') {
-                *off = a; *len = lo + i + 1; *final = 0; *index = P->n_taken++;
-                P->next_off = a + (off_t)(lo + i + 1);
+                *off = a; *len = lo + i + 1; *final = 0; *index = P->n_taken++; P->taken_part[p]++;
+                P->next_off_part[p] = a + (off_t)(lo + i + 1);
+                P->next_off = P->next_off_part[p];
                 return 1;
             }
         }
         hi = lo;
     }
+    P->next_off = a;                                             /* (where the host pipeline would have to go on from) */
     return -1;
+}
+
+/* the parts of the input: part p = [begin_p, begin_{p+1}), begin_p = the first record start at or behind p / n_parts of the file (a '>' that
+ * follows a newline; none: the part is empty and its neighbour in front takes the bytes) */
+static int find_parts(dpipe *P) {
+    off_t begin[UTREE_MAX_OUT_PARTS + 1];
+    begin[0] = 0; begin[P->n_parts] = P->file_size;
+    for (int p = 1; p < P->n_parts; ++p) {
+        off_t at = (off_t)((unsigned __int128)P->file_size * (unsigned)p / (unsigned)P->n_parts), found = P->file_size;
+        if (at < begin[p - 1]) at = begin[p - 1];
+        while (at < P->file_size && found == P->file_size) {
+            const size_t win = (size_t)(P->file_size - at < (off_t)(64 << 10) ? P->file_size - at : (off_t)(64 << 10));
+            size_t got = 0;
+            while (got < win) {
+                ssize_t r = pread(P->fd, P->tail + got, win - got, at + (off_t)got);
+                if (r <= 0) return UTREE_E_IO;
+                got += (size_t)r;
+            }
+            for (size_t i = 0; i + 1 < win; ++i) if (P->tail[i] == '\n' && P->tail[i + 1] == '>') { found = at + (off_t)i + 1; break; }
+            at += (off_t)(win > 1 ? win - 1 : 1);                /* (the window's last byte is looked at again as a first byte) */
+        }
+        begin[p] = found;
+    }
+    for (int p = 0; p < P->n_parts; ++p) { P->next_off_part[p] = begin[p]; P->part_end[p] = begin[p + 1]; }
+    return UTREE_OK;
 }
 
 #define LH(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); dfail(P, UTREE_E_HIP); return NULL; } } while (0)
@@ -245,9 +295,9 @@ static void *lane_main(void *arg) {
     lane_buf *b = L->b;
     if (hipSetDevice(L->dev->device) != hipSuccess) { dfail(P, UTREE_E_HIP); return NULL; }
     for (;;) {
-        off_t off = 0; size_t len = 0; int final = 0; uint64_t c = 0;
+        off_t off = 0; size_t len = 0; int final = 0, part = 0; uint64_t c = 0, cp = 0;      /* c: the chunk's number; cp: its number within its output part */
         pthread_mutex_lock(&P->mu);
-        int got = (P->stop || P->retry_set) ? 0 : take_chunk(P, &off, &len, &final, &c);
+        int got = (P->stop || P->retry_set) ? 0 : take_chunk(P, &off, &len, &final, &c, &part, &cp);
         if (got < 0) dretry(P, P->n_taken, P->next_off, 1);                    /* no record boundary within a chunk's bytes */
         pthread_mutex_unlock(&P->mu);
         if (got <= 0) return NULL;
@@ -314,9 +364,10 @@ static void *lane_main(void *arg) {
         /* ---- the chunk's place in the output: after the text of every earlier chunk (input order, like one thread) ---- */
         off_t base;
         pthread_mutex_lock(&P->mu);
-        while (P->published != c && !P->stop && !DROPPED(P, c)) pthread_cond_wait(&P->cv, &P->mu);
+        while (P->published_part[part] != cp && !P->stop && !DROPPED(P, c)) pthread_cond_wait(&P->cv, &P->mu);
         if (P->stop || DROPPED(P, c)) { pthread_mutex_unlock(&P->mu); hipStreamSynchronize(b->stream); return NULL; }
-        base = P->cum_out;
+        base = P->cum_part[part];
+        P->cum_part[part] += (off_t)m2.out_bytes;
         P->cum_out += (off_t)m2.out_bytes;
         P->n_reads += nr; P->good += nr ? m2.good_finds : 0; P->bytes_in += len;
         while (P->n_reads >= P->next_progress) {                                   /* itree.c:878 */
@@ -324,7 +375,7 @@ static void *lane_main(void *arg) {
             P->next_progress += 1048576;
             P->printed++;
         }
-        P->published++;
+        P->published_part[part]++;
         pthread_cond_broadcast(&P->cv);
         pthread_mutex_unlock(&P->mu);
         double t4 = now_s();
@@ -340,15 +391,15 @@ static void *lane_main(void *arg) {
             pthread_mutex_unlock(&P->mu);
             if (stop) return NULL;
         }
-        pthread_mutex_lock(&P->wmu);
+        pthread_mutex_lock(&P->wmu[part]);
         double t6 = now_s();
         while (done < (size_t)m2.out_bytes) {
             ssize_t w = P->seq_out ? write(P->fo, b->h_out + done, (size_t)m2.out_bytes - done)
-                                   : pwrite(P->fo, b->h_out + done, (size_t)m2.out_bytes - done, base + (off_t)done);
-            if (w <= 0) { pthread_mutex_unlock(&P->wmu); dfail(P, UTREE_E_IO); return NULL; }
+                                   : pwrite(P->fo_part[part], b->h_out + done, (size_t)m2.out_bytes - done, base + (off_t)done);
+            if (w <= 0) { pthread_mutex_unlock(&P->wmu[part]); dfail(P, UTREE_E_IO); return NULL; }
             done += (size_t)w;
         }
-        pthread_mutex_unlock(&P->wmu);
+        pthread_mutex_unlock(&P->wmu[part]);
         if (P->seq_out) {
             pthread_mutex_lock(&P->mu);
             P->written++;
@@ -365,6 +416,12 @@ static int lanes_per_device(int n_dev) {
     const char *e = getenv("UTREE_LANES");
     if (e && atoi(e) >= 1 && atoi(e) <= 16) return atoi(e);
     return n_dev <= 2 ? 4 : 3;
+}
+
+int utree_output_parts(void) {
+    const char *e = getenv("UTREE_OUTPUT_PARTS");
+    const int p = e ? atoi(e) : 1;
+    return p < 1 ? 1 : p > UTREE_MAX_OUT_PARTS ? UTREE_MAX_OUT_PARTS : p;
 }
 
 int utree_search_prepare(const utree_ctr *ctr, utree_dev **devs, int n_dev, int do_rc) {
@@ -388,22 +445,31 @@ int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, 
     if (!P) return UTREE_E_NOMEM;
     P->ctr = ctr; P->do_rc = do_rc; P->next_progress = 1048576;
     P->fd = open(fasta_path, O_RDONLY);
-    P->fo = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);                   /* fopen(outfile, "wb"), itree.c:834 */
+    P->n_parts = utree_output_parts();
+    for (int p = 0; p < P->n_parts; ++p) {
+        char name[4096];
+        if (P->n_parts > 1) snprintf(name, sizeof name, "%s.part%03d", out_path, p);
+        P->fo_part[p] = open(P->n_parts > 1 ? name : out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);   /* fopen(outfile, "wb"), itree.c:834 */
+        if (P->fo_part[p] < 0) { for (int q = 0; q < p; ++q) close(P->fo_part[q]); P->fo_part[0] = -1; break; }
+    }
+    P->fo = P->fo_part[0];
+    if (resume) resume->parts = P->n_parts;
     struct stat sb;
     if (P->fd < 0 || P->fo < 0 || fstat(P->fd, &sb) != 0) {                       /* itree.c:835 */
         if (P->fd >= 0) close(P->fd);
-        if (P->fo >= 0) close(P->fo);
+        if (P->fo >= 0) for (int p = 0; p < P->n_parts; ++p) close(P->fo_part[p]);
         free(P);
         return UTREE_E_IO;
     }
-    P->seq_out = lseek(P->fo, 0, SEEK_CUR) == (off_t)-1;                          /* `out` is a pipe, a FIFO, a tty: no pwrite there */
+    P->seq_out = P->n_parts == 1 && lseek(P->fo, 0, SEEK_CUR) == (off_t)-1;       /* `out` is a pipe, a FIFO, a tty: no pwrite there */
     if (!S_ISREG(sb.st_mode)) {                                                   /* the input is a pipe: no pread */
-        if (P->seq_out && resume) resume->fo = P->fo; else close(P->fo);          /* (an output that is a pipe too stays open for the host pipeline) */
+        if (P->seq_out && resume) resume->fo = P->fo; else for (int p = 0; p < P->n_parts; ++p) close(P->fo_part[p]);   /* (an output that is a pipe too stays open for the host pipeline) */
         close(P->fd); free(P);
         return UTREE_RETRY_HOST;
     }
     P->file_size = sb.st_size;
     P->chunk_bytes = chunk_bytes();
+    { int prc = find_parts(P); if (prc) { for (int p = 0; p < P->n_parts; ++p) close(P->fo_part[p]); close(P->fd); free(P); return prc; } }
     const int K = lanes_per_device(n_dev), n_lanes = K * n_dev;
     int rc = UTREE_OK;
     for (int g = 0; g < n_dev && !rc; ++g) { struct utree_search_ctx *c = NULL; rc = ctx_get(ctr, devs[g], K, &c); }
@@ -419,7 +485,7 @@ int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, 
     lane_t *lanes = (lane_t *)calloc((size_t)n_lanes, sizeof(lane_t));
     if (!lanes && !rc) rc = UTREE_E_NOMEM;
     pthread_mutex_init(&P->mu, NULL);
-    pthread_mutex_init(&P->wmu, NULL);
+    for (int p = 0; p < P->n_parts; ++p) pthread_mutex_init(&P->wmu[p], NULL);
     pthread_cond_init(&P->cv, NULL);
     if (!rc) {
         int started = 0;
@@ -442,7 +508,7 @@ int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, 
         }
     }
     close(P->fd);
-    if (!(resume && resume->fo == P->fo)) close(P->fo);
+    if (!(resume && resume->fo == P->fo)) for (int p = 0; p < P->n_parts; ++p) close(P->fo_part[p]);
     if (progress_printed) *progress_printed = P->printed;
     if (stats) {
         memset(stats, 0, sizeof *stats);
@@ -464,7 +530,7 @@ int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, 
                         "order + write-turn wait %.3f | D2H %.3f | write %.3f; wall %.3f s\n", n_lanes, per_lane, r, f, c, o, d, w, now_s() - t_start);
     }
     pthread_mutex_destroy(&P->mu);
-    pthread_mutex_destroy(&P->wmu);
+    for (int p = 0; p < P->n_parts; ++p) pthread_mutex_destroy(&P->wmu[p]);
     pthread_cond_destroy(&P->cv);
     free(lanes);
     free(P);

@@ -10,7 +10,11 @@
  * host pipeline then CONTINUES -- same descriptor, the input from `in_off` on, the counts so far -- instead of starting over (O_TRUNC does
  * nothing to a pipe: its reader would get the first chunks twice, and closing a FIFO can end its reader).  fo < 0: nothing to continue from,
  * the host pipeline opens the output itself. */
-typedef struct { int fo; long long in_off; uint64_t n_reads, good_finds, bytes_in, bytes_out; } utree_search_resume;
+typedef struct { int fo; long long in_off; uint64_t n_reads, good_finds, bytes_in, bytes_out; int parts; } utree_search_resume;
+/* parts > 1 (UTREE_OUTPUT_PARTS): the output goes to <out>.part000 ... in input order; a search the host pipeline takes over writes all of it
+ * into part 000 and leaves the others empty (the parts' concatenation is the output either way) */
+#define UTREE_MAX_OUT_PARTS 64
+int utree_output_parts(void);
 
 int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, const char *fasta_path, const char *out_path,
                              int do_rc, int host_threads, utree_search_stats *stats, uint64_t *progress_printed, utree_search_resume *resume);
