@@ -528,6 +528,17 @@ def cli_leg(args):
             out["broadcast_seconds"] = float(m.group(2))
         elif "every GPU reads it from the host" in err:
             out["fanout"] = "per-device upload over PCIe (the broadcast failed)"
+        # the same invocation with the output in part files (opt-in UTREE_OUTPUT_PARTS: what file -> file needs to scale with the GPUs)
+        try:
+            env2 = dict(env)
+            env2["UTREE_OUTPUT_PARTS"] = str(4 * n)
+            time.sleep(10)
+            p2 = subprocess.run(cmd, env=env2, capture_output=True, timeout=300)
+            m2 = re.search(r"search ([0-9.]+) s \(([0-9.]+) reads/s\)", p2.stderr.decode(errors="replace"))
+            if p2.returncode == 0 and m2:
+                out["output_in_parts"] = {"parts": 4 * n, "search_seconds": float(m2.group(1)), "value": float(m2.group(2))}
+        except Exception as ex:
+            out["output_in_parts"] = {"error": repr(ex)}
         out["bound"] = ("one output file fills at the host's page-allocation rate (~6 GB/s: DESIGN.md, file -> file): beyond ~80 M reads/s more GPUs do not "
                         "show in THIS number; they show in `value` (HBM-resident) and in a search whose output goes to several files")
         out["stderr_tail"] = err[-2500:]

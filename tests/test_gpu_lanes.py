@@ -506,3 +506,26 @@ def test_kmers_whose_two_minimizer_views_differ(torch_cuda, k, tmp_path, monkeyp
     assert classify_fasta_bytes(db, t2, data, rc=True) == want[True]
     assert t2.kernel_name().endswith(", 1, false>")
     t2.close()
+
+
+@pytest.mark.parametrize("k", [32, 64])
+def test_both_strands_when_nearly_every_bucket_overflows(torch_cuda, k, tmp_path, monkeypatch):
+    """With both strands served from one pass a minimizer run can have TWO overflowing buckets (one per orientation), and the list of
+    overflowing runs grows over the front of the run list, behind what phase B has read.  A table sized for 30 nodes per bucket
+    (UTREE_BUCKET_TARGET) overflows nearly everywhere: the list must not outgrow its room -- a read whose overflowing run does not fit is
+    left to the wave-per-read kernel -- and the lines stay the oracle's."""
+    monkeypatch.setenv("UTREE_BUCKET_TARGET", "30")
+    d = OwnDB(tmp_path, seed=31, k=k)
+    db = CtrDB.open(d.ctr)
+    tree = DeviceTree.upload(db, 0)
+    o = orc.OracleDB.load(d.ctr)
+    rng = np.random.default_rng(k + 1)
+    comp = str.maketrans("ACGT", "TGCA")
+    reads = random_reads(rng, d, 6000, 100, 160, hit_frac=0.9)
+    reads = [(n, s if i % 2 else s.translate(comp)[::-1]) for i, (n, s) in enumerate(reads)]
+    data = fasta_bytes(reads)
+    monkeypatch.setenv("UTREE_LANE_PASS", "1")
+    for rc in (True, False):
+        assert classify_fasta_bytes(db, tree, data, rc=rc) == oracle_text(o, data, tmp_path, rc=rc)
+        assert tree.kernel_name().startswith("classify_lanes_k<%d, 2, 1, false, 0, 1, %s>" % (k // 4, "true" if rc else "false"))
+    tree.close()

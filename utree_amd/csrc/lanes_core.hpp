@@ -395,7 +395,7 @@ _Pragma("unroll") \
         // quarter -- two entries -- of its quad's four runs; what it needs of a run it gets from the lane that prepared it by a
         // quad broadcast (DPP), nothing goes through LDS.  Two more batches of 64 buckets are in flight meanwhile.
         // (a lane beyond the list repeats the list's last run -- its load stays inside the table -- as a run no entry can belong to)
-        uint32_t n_ovf = 0;
+        uint32_t n_ovf = 0, ovf_room = 0;                                  // ovf_room: run records phase B has read (prepared) so far
         // what a scan needs of a run: {minimizer hash (for the bucket's address), first window | minimizer position - first << 8 | windows - 1
         // << 14 | read << 20, the range of entry tags its windows have, the 16 (k = 64: 48) bases before the minimizer, the 16 (48) behind it}.
         // An entry's tag is {flag2 | hash low bits | minimizer position in the k-mer} (its high half-word; k = 32: times two, the zero bit
@@ -532,8 +532,12 @@ _Pragma("unroll") \
                 const uint64_t om = ballot64((lane & 3u) == 3u && d != G::DNONE && more);
                 if (om) {
                     const uint32_t first = cpk & 0xFFu, q = (cpk >> 20) & 63u;
-                    if ((om >> lane) & 1ull) {
-                        const uint32_t at = n_ovf + lanes_below(om);
+                    // (the list of overflowing runs grows over the front of the run list, behind what phase B has read: ovf_room records.  One
+                    // overflowing bucket per run always fits; with both strands a run can have two -- a database most of whose buckets overflow in
+                    // both orientations then runs out of room, and the read is left to the wave-per-read kernel like one with too many labels)
+                    const uint32_t at = n_ovf + lanes_below(om);
+                    if (((om >> lane) & 1ull) && at >= ovf_room) { const uint32_t rd = q >> SEGSH; atomicOr(&full[rd >> 5], 1u << (rd & 31u)); }
+                    if (((om >> lane) & 1ull) && at < ovf_room) {
                         runs[at] = (first + d) | (first << 8) | ((first + lenm1 + 1u) << 16) | (q << 24) | (rev ? 0x80000000u : 0u);   // (bit 31: the strand)
 #ifndef UTREE_LANES_REFETCH_DESC
                         // (the descriptor is in this lane's registers: the first 64 of a grab's overflowing runs keep it, and the
@@ -541,7 +545,7 @@ _Pragma("unroll") \
                         if (at < 64u) ost[at] = (W == 8 && I == 4) ? (((uint64_t)Pk.y << 32) | Pk.x) : (((uint64_t)Pk.w << 32) | Pk.z);
 #endif
                     }
-                    n_ovf += (uint32_t)__popcll(om);
+                    n_ovf = umin(n_ovf + (uint32_t)__popcll(om), ovf_room);
                 }
             }
         };
@@ -574,10 +578,13 @@ _Pragma("unroll") \
                 prepare(1u, R1); issue(R1, 0u, P1);
                 for (uint32_t it = 0; it < nit; it += 3) {
                     prepare(it + 2, R2); issue(R2, 0u, P2);
+                    ovf_room = umin(nruns, 64u * (it + 3u));
                     scan(R0, 0u, P0);
                     prepare(it + 3, R0); issue(R0, 0u, P0);
+                    ovf_room = umin(nruns, 64u * (it + 4u));
                     if (it + 1 < nit) scan(R1, 0u, P1);
                     prepare(it + 4, R1); issue(R1, 0u, P1);
+                    ovf_room = umin(nruns, 64u * (it + 5u));
                     if (it + 2 < nit) scan(R2, 0u, P2);
                 }
             } else {
@@ -586,14 +593,17 @@ _Pragma("unroll") \
                 prepare(0u, R0); issue(R0, 0u, P0); issue(R0, 1u, P1);
                 for (uint32_t it = 0; it < nit; it += 3) {
                     prepare(it + 1, R1); issue(R1, 0u, P2);
+                    ovf_room = umin(nruns, 64u * (it + 2u));
                     scan(R0, 0u, P0);
                     issue(R1, 1u, P0);
                     scan(R0, 1u, P1);
                     prepare(it + 2, R2); issue(R2, 0u, P1);
+                    ovf_room = umin(nruns, 64u * (it + 3u));
                     if (it + 1 < nit) scan(R1, 0u, P2);
                     issue(R2, 1u, P2);
                     if (it + 1 < nit) scan(R1, 1u, P0);
                     prepare(it + 3, R0); issue(R0, 0u, P0);
+                    ovf_room = umin(nruns, 64u * (it + 4u));
                     if (it + 2 < nit) scan(R2, 0u, P1);
                     issue(R0, 1u, P1);
                     if (it + 2 < nit) scan(R2, 1u, P2);
