@@ -274,10 +274,6 @@ def test_batch_of_mixed_lengths_is_split_by_lanes_per_read(torch_cuda, k, tmp_pa
             monkeypatch.setenv("UTREE_LANE_PASS", "1")
             got = classify_fasta_bytes(db, tree, data, rc=rc)
             assert tree.kernel_name().startswith("classify_lanes_")          # (..._mixed_k: the classes in one launch; ..._k<.., 16, .., 2, ..>: the pieces of the long reads)
-            # a launch per class (the shape until round 3) gives the same records
-            monkeypatch.setenv("UTREE_LANES_CLASS_LAUNCHES", "1")
-            assert got == classify_fasta_bytes(db, tree, data, rc=rc)
-            monkeypatch.delenv("UTREE_LANES_CLASS_LAUNCHES")
             monkeypatch.setenv("UTREE_LANE_PASS", "0")
             assert got == classify_fasta_bytes(db, tree, data, rc=rc)
             assert got == oracle_text(o, data, tmp_path, rc=rc)

@@ -9,9 +9,9 @@ HF="-O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-parameter -Wno-
 /opt/rocm/bin/hipcc $HF -mllvm -amdgpu-load-store-vectorizer=0 "$@" -c kernels.hip -o /tmp/kernels_$N.o &
 /opt/rocm/bin/hipcc $HF "$@" -c lanes_kernel.hip -o /tmp/lanes_kernel_$N.o &
 PARTS=""
-for P in 8_2_1 8_2_2 8_4_1 8_4_2 16_2_1 16_2_2; do
-    IFS=_ read W I NL <<< "$P"
-    /opt/rocm/bin/hipcc $HF "$@" -DLANES_W=$W -DLANES_I=$I -DLANES_NL=$NL -c lanes_part.hip -o /tmp/lanes_part_${P}_$N.o &
+for P in 8_2_1_0 8_2_1_1 8_2_2_0 8_4_1_0 8_4_1_1 8_4_2_0 16_2_1_0 16_2_1_1 16_2_2_0; do
+    IFS=_ read W I NL BS <<< "$P"
+    /opt/rocm/bin/hipcc $HF "$@" -DLANES_W=$W -DLANES_I=$I -DLANES_NL=$NL -DLANES_BS=$BS -c lanes_part.hip -o /tmp/lanes_part_${P}_$N.o &
     PARTS="$PARTS /tmp/lanes_part_${P}_$N.o"
 done
 gcc -std=gnu11 -O2 -g -fPIC -fopenmp -I/opt/rocm/include "$@" -c dev_image.c -o /tmp/dev_image_$N.o

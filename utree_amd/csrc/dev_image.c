@@ -988,15 +988,15 @@ const char *utree_classify_kernel_name(const utree_dev *dc) {
                  utk_lanes_both_strands(&d->kimg, d->last_rc) ? "true" : "false");
         return d->kernel_sig;
     }
-    if (d->last_lanes && d->last_mixed && !(getenv("UTREE_LANES_CLASS_LAUNCHES") && atoi(getenv("UTREE_LANES_CLASS_LAUNCHES")) > 0)) {
+    if (d->last_lanes && d->last_mixed) {
         /* a batch of mixed lengths: one launch whose wavefronts work through the lanes-per-read classes */
         snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_mixed_k<%u, %u, %s, %u, %s>", d->hdr.W, d->hdr.I, d->kimg.irr_n ? "true" : "false",
                  d->hdr.bucket_words / 8, utk_lanes_both_strands(&d->kimg, d->last_rc) ? "true" : "false");
         return d->kernel_sig;
     }
-    if (d->last_lanes) {      /* (a launch per class: the instantiation the batch's longest read takes) */
-        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, %d, %s, %d, %u, %s>", d->hdr.W, d->hdr.I, d->last_lanes, d->kimg.irr_n ? "true" : "false",
-                 d->last_mixed ? 1 : 0, d->hdr.bucket_words / 8, utk_lanes_both_strands(&d->kimg, d->last_rc) ? "true" : "false");
+    if (d->last_lanes) {
+        snprintf(d->kernel_sig, sizeof d->kernel_sig, "classify_lanes_k<%u, %u, 1, %s, 0, %u, %s>", d->hdr.W, d->hdr.I, d->kimg.irr_n ? "true" : "false",
+                 d->hdr.bucket_words / 8, utk_lanes_both_strands(&d->kimg, d->last_rc) ? "true" : "false");
         return d->kernel_sig;
     }
     return d->last_long ? utk_classify_long_name(&d->kimg, d->kernel_sig, sizeof d->kernel_sig)

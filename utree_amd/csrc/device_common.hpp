@@ -272,6 +272,24 @@ template <int W> __device__ __forceinline__ void min_split(uint64_t khi, uint64_
 // tags -- and, in its low six bits, the shift 2 * position that brings a window's outer bases under the entry's rest: the lane-per-read
 // pass, lanes_kernel.hip, checks an entry with five instructions.)
 constexpr uint64_t MFLAG_EMPTY = 1ull << 62, MFLAG_RUN = 2ull << 62;
+// An overflow descriptor is {flag 2 | count22 | directory1 | start39}.  A HEAVY run -- more than OVF_DIR_MIN records, all of one hash value: the k-mers
+// of many related genomes around one minimizer -- starts with a DIRECTORY: K-16+2 16-bit offsets, [p] = the run's first record whose minimizer position is
+// >= p ([K-15] = count), in OVF_DIR_SLOTS record slots in front of the records.  A window's record can only be among those of the window's own position,
+// so a search starts in a range of count / (K-15) records instead of the whole run: three probes of one line where seven dependent trips were
+// (image_build.hip: ovf_count_k, ovf_move_k; lanes_core.hpp, wave_common.hpp: the searches).
+constexpr uint64_t M39 = (1ull << 39) - 1, OVF_HAS_DIR = 1ull << 39;
+constexpr uint32_t OVF_DIR_MIN = 32;
+template <int W, int I> struct OvfDir { static constexpr uint32_t SLOTS = (2u * (4u * W - 16u + 2u) + 8u * RecTraits<W, I>::EW - 1u) / (8u * RecTraits<W, I>::EW); };
+// start of the records and count of the run a descriptor names
+__host__ __device__ __forceinline__ uint64_t ovf_count(uint64_t d) { return (d >> 40) & 0x3FFFFFull; }
+template <int W, int I> __host__ __device__ __forceinline__ uint64_t ovf_first(uint64_t d) { return (d & M39) + ((d & OVF_HAS_DIR) ? OvfDir<W, I>::SLOTS : 0u); }
+// minimizer position of a MIN record
+template <int W, int I> __device__ __forceinline__ uint32_t mrec_pos(const uint64_t *rec) {
+    if constexpr (W == 16) return (uint32_t)(rec[1] >> 48) & 63u; else return (uint32_t)(rec[0] >> 49) & 31u;
+}
+template <int W, int I> __device__ __forceinline__ uint32_t mrec_hlow(const uint64_t *rec) {
+    if constexpr (W == 16) return (uint32_t)(rec[1] >> 54) & 0xFFu; else return (uint32_t)(rec[0] >> 54) & 0xFFu;
+}
 constexpr uint64_t M46 = (1ull << 46) - 1;
 
 template <int W, int I> __device__ __forceinline__ uint32_t mrec_flag(const Entry<W, I> &e) { return (uint32_t)(e.w[RecTraits<W, I>::KW] >> 62); }

@@ -192,7 +192,7 @@ __global__ void bucket_k(const uint64_t *__restrict__ Bs, const uint64_t *__rest
             if (rest > run_max) { atomicAdd(overflow, 1ull); rest = (1ull << 22) - 1; }
 #pragma unroll
             for (int x = 0; x < EW; ++x) o[inl * EW + x] = 0;
-            o[inl * EW + KW] = MFLAG_RUN | (rest << 40) | ((base + j + inl) & M40);
+            o[inl * EW + KW] = MFLAG_RUN | (rest << 40) | ((base + j + inl) & M39);
         }
     }
 }
@@ -222,13 +222,18 @@ __global__ void flag_saturated_k(const uint64_t *__restrict__ Bs, const IDX *__r
 // are found there).  ovf_count_k / ovf_move_k keep those runs alone, packed in bucket order, and point the descriptors at
 // their new places: the sorted array of ALL nodes (8-32 bytes per node) leaves the image.
 template <int W, int I>
-__global__ void ovf_count_k(const uint64_t *__restrict__ table, uint64_t n_buckets, uint32_t bw, uint32_t *__restrict__ cnt) {
+__global__ void ovf_count_k(const uint64_t *__restrict__ table, uint64_t n_buckets, uint32_t bw, const uint64_t *__restrict__ mrecs, int dir_on, uint32_t *__restrict__ cnt) {
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
     const int CAP = (int)bw / EW;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t d = table[b * bw + (uint64_t)(CAP - 1) * EW + KW];
         uint32_t c = (d >> 62) == 2 ? (uint32_t)((d >> 40) & 0x3FFFFFull) : 0u;
         if (c == 0x3FFFFFu) c = 0;           // a saturated run is never followed (its nodes' bins take the exact-probe path): nothing to keep
+        // a heavy run of ONE hash value (sorted by key: the first and the last record tell) gets a position directory in front (device_common.hpp)
+        if (c > OVF_DIR_MIN && c <= 0xFFFFu && dir_on) {
+            const uint64_t src = d & M39;
+            if (mrec_hlow<W, I>(mrecs + src * EW) == mrec_hlow<W, I>(mrecs + (src + c - 1) * EW)) c += OvfDir<W, I>::SLOTS | 0x80000000u;
+        }
         cnt[b] = c;
     }
 }
@@ -238,16 +243,28 @@ __global__ void ovf_move_k(uint64_t *__restrict__ table, uint64_t n_buckets, uin
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
     const int CAP = (int)bw / EW;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t c = cnt[b];
+        const bool dir = (cnt[b] & 0x80000000u) != 0u;
+        const uint32_t c = cnt[b] & 0x7FFFFFFFu;                                  // slots in the packed area: the directory's, if any, and the records'
         uint64_t *dp = table + b * bw + (uint64_t)(CAP - 1) * EW + KW;
         if (!c) {
             // a saturated descriptor becomes an empty run: a word that is no node finds nothing there (words of nodes never come here)
             if ((*dp >> 62) == 2) *dp = MFLAG_RUN;
             continue;
         }
-        const uint64_t d = *dp, src = d & M40, dst = prefix[b];
-        for (uint64_t q = 0; q < (uint64_t)c * EW; ++q) packed[dst * EW + q] = mrecs[src * EW + q];
-        *dp = (d & ~M40) | (dst & M40);
+        const uint64_t d = *dp, src = d & M39, dst = prefix[b];
+        const uint32_t hs = dir ? OvfDir<W, I>::SLOTS : 0u, nrec = c - hs;
+        if (dir) {
+            // [p] = records of the run with a minimizer position below p (they ascend by position: the hash bits in front of it are one value's)
+            uint16_t *dv = (uint16_t *)(packed + dst * EW);
+            for (uint32_t x = 0; x < hs * EW * 4u; ++x) dv[x] = (uint16_t)nrec;
+            uint32_t p = 0;
+            for (uint32_t q = 0; q < nrec; ++q) {
+                const uint32_t pq = mrec_pos<W, I>(mrecs + (src + q) * EW);
+                while (p <= pq) dv[p++] = (uint16_t)q;
+            }
+        }
+        for (uint64_t q = 0; q < (uint64_t)nrec * EW; ++q) packed[(dst + hs) * EW + q] = mrecs[src * EW + q];
+        *dp = (d & ~(M39 | OVF_HAS_DIR)) | (dst & M39) | (dir ? OVF_HAS_DIR : 0ull);
     }
 }
 
@@ -600,7 +617,7 @@ int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream) {
     return (int)hipGetLastError();
 }
 
-struct widen32 { __device__ uint64_t operator()(uint32_t v) const { return v; } };
+struct widen32 { __device__ uint64_t operator()(uint32_t v) const { return v & 0x7FFFFFFFu; } };   // (bit 31 of a count: the run gets a directory)
 /* Pack the overflow runs to the front of d_mrecs (bucket order) and repoint the buckets' descriptors; *n_kept = records kept. */
 int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n_buckets, uint32_t bw, uint64_t *d_mrecs, uint64_t *n_kept, void *stream) {
     hipStream_t st = (hipStream_t)stream;
@@ -610,6 +627,8 @@ int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n
     size_t tb = 0;
     int rc = 0;
     const uint32_t EW = utree_rec_words(W_, I_);
+    const char *de = getenv("UTREE_OVF_DIR");                            /* =0: no position directories (A/B) */
+    const int dir_on = !(de && atoi(de) == 0);
     *n_kept = 0;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto done; } } while (0)
     CK(hipMalloc((void **)&cnt, (n_buckets + 1) * 4));
@@ -617,7 +636,7 @@ int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n
     CK(hipMemsetAsync(cnt + n_buckets, 0, 4, st));
     {
         int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
-            ovf_count_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(n_buckets) > 65536 ? 65536 : grid_for(n_buckets)), dim3(256), 0, st>>>(d_table, n_buckets, bw, cnt);
+            ovf_count_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(n_buckets) > 65536 ? 65536 : grid_for(n_buckets)), dim3(256), 0, st>>>(d_table, n_buckets, bw, d_mrecs, dir_on, cnt);
         });
         if (drc) { rc = drc; goto done; }
     }

@@ -653,7 +653,7 @@ _Pragma("unroll") \
 #endif
             if (i < n_ovf) {
                 const uint32_t rec = runs[i];
-                const uint64_t n = (dsc >> 40) & 0x3FFFFFull;
+                const uint64_t n = ovf_count(dsc);
                 ost[lane] = dsc;
                 if (n <= OVF_SCAN) nrec = (uint32_t)n; else wn = ((rec >> 16) & 0xFFu) - ((rec >> 8) & 0xFFu);
             }
@@ -692,7 +692,7 @@ _Pragma("unroll") \
                         uint32_t j;
                         const uint32_t it_ = item_of(t, j);
                         recs[u] = runs[ib + it_];
-                        e[u] = load_entry<W, I>(im.mrecs, (ost[it_] & M40) + j);
+                        e[u] = load_entry<W, I>(im.mrecs, ovf_first<W, I>(ost[it_]) + j);
                     }
                 }
 #pragma unroll
@@ -733,10 +733,12 @@ _Pragma("unroll") for (uint32_t x = 0; x < NA; ++x) { A[x] = RA[x]; B[x] = RB[x]
                 uint64_t lo[OVF_WAYS], hi[OVF_WAYS];                               // the searches' ranges (empty: done or no window)
                 MinKey<W> mk[OVF_WAYS];
                 uint32_t qs[OVF_WAYS];
+                const uint16_t *dirp[OVF_WAYS];                                    // where a heavy run's directory says which of its records have the window's position
 #pragma unroll
                 for (uint32_t u = 0; u < OVF_WAYS; ++u) {
                     const uint32_t t = t0 + 64u * u + lane;
                     lo[u] = hi[u] = 0; qs[u] = 0; mk[u].lo = mk[u].hi = 0;
+                    dirp[u] = nullptr;
                     if (t < total_win) {
                         uint32_t j;
                         const uint32_t it_ = item_of(t, j);
@@ -752,7 +754,8 @@ _Pragma("unroll") for (uint32_t x = 0; x < NA; ++x) { A[x] = RA[x]; B[x] = RB[x]
                         const uint32_t h = canon_hash(m, o);
                         const uint32_t hlow = h & 0xFFu;
                         const uint64_t dsc = ost[it_];
-                        lo[u] = dsc & M40; hi[u] = lo[u] + ((dsc >> 40) & 0x3FFFFFull); qs[u] = q;
+                        lo[u] = ovf_first<W, I>(dsc); hi[u] = lo[u] + ovf_count(dsc); qs[u] = q;
+                        if (dsc & OVF_HAS_DIR) dirp[u] = (const uint16_t *)(im.mrecs + (dsc & M39) * EW) + pos;
                         if constexpr (W == 8) {
                             const uint32_t rest = (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos));
                             mk[u].hi = 0; mk[u].lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
@@ -762,6 +765,18 @@ _Pragma("unroll") for (uint32_t x = 0; x < NA; ++x) { A[x] = RA[x]; B[x] = RB[x]
                             mk[u].lo = ((uint64_t)r1 << 32) | r2; mk[u].hi = ((uint64_t)hlow << 38) | ((uint64_t)pos << 32) | r0;
                         }
                     }
+                }
+                // a heavy run: its directory narrows the range to the records of the window's own minimizer position (one trip for all the searches of the
+                // round; a lane without a directory reads the image's first bytes)
+                {
+                    uint32_t da[OVF_WAYS], db[OVF_WAYS];
+#pragma unroll
+                    for (uint32_t u = 0; u < OVF_WAYS; ++u) {
+                        const uint16_t *dp_ = dirp[u] ? dirp[u] : (const uint16_t *)im.mrecs;
+                        da[u] = dp_[0]; db[u] = dp_[1];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < OVF_WAYS; ++u) if (dirp[u]) { hi[u] = lo[u] + db[u]; lo[u] += da[u]; }
                 }
                 // exact-match bisection in runs that ascend by key, OVF_WAYS searches per lane in step (a finished one reads record 0 of its range again: no branch around a load)
                 for (;;) {

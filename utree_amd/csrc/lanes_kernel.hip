@@ -16,10 +16,11 @@ using namespace utk;
 #endif
 
 extern "C" {
-#define PART_DECL(W_, I_, NL_) int utk_lanes_part_##W_##_##I_##_##NL_(int segs, int irr, int mode, int bs, const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, \
-                                                                   const uint32_t *d_len, uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws,     \
-                                                                   int n_cu, void *stream, uint32_t cls);
-PART_DECL(8, 2, 1) PART_DECL(8, 2, 2) PART_DECL(8, 4, 1) PART_DECL(8, 4, 2) PART_DECL(16, 2, 1) PART_DECL(16, 2, 2)
+#define PART_DECL(W_, I_, NL_, BS_) int utk_lanes_part_##W_##_##I_##_##NL_##_##BS_(int segs, int irr, int mode, const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, \
+                                                                              const uint32_t *d_len, uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws, \
+                                                                              int n_cu, void *stream, uint32_t cls);
+PART_DECL(8, 2, 1, 0) PART_DECL(8, 2, 1, 1) PART_DECL(8, 2, 2, 0) PART_DECL(8, 4, 1, 0) PART_DECL(8, 4, 1, 1) PART_DECL(8, 4, 2, 0)
+PART_DECL(16, 2, 1, 0) PART_DECL(16, 2, 1, 1) PART_DECL(16, 2, 2, 0)
 #undef PART_DECL
 }
 
@@ -49,11 +50,12 @@ int lanes_launch(const utk_image *im, int segs, int mode, const uint8_t *d_bases
                  utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream, uint32_t cls) {
     const int irr = im->irr_n != 0, nl = im->bucket_words == 16u ? 2 : 1;
     const int bs = utk_lanes_both_strands(im, do_rc);
-#define PART(W_, I_, NL_) return utk_lanes_part_##W_##_##I_##_##NL_(segs, irr, mode, bs, im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
-    if (im->W == 16) { if (nl == 2) PART(16, 2, 2); PART(16, 2, 1); }
-    if (im->I == 4) { if (nl == 2) PART(8, 4, 2); PART(8, 4, 1); }
-    if (nl == 2) PART(8, 2, 2);
-    PART(8, 2, 1);
+#define PART(W_, I_, NL_, BS_) return utk_lanes_part_##W_##_##I_##_##NL_##_##BS_(segs, irr, mode, im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
+    if (im->W == 16) { if (nl == 2) PART(16, 2, 2, 0); if (bs) PART(16, 2, 1, 1); PART(16, 2, 1, 0); }
+    if (im->I == 4) { if (nl == 2) PART(8, 4, 2, 0); if (bs) PART(8, 4, 1, 1); PART(8, 4, 1, 0); }
+    if (nl == 2) PART(8, 2, 2, 0);
+    if (bs) PART(8, 2, 1, 1);
+    PART(8, 2, 1, 0);
 #undef PART
 }
 
@@ -223,12 +225,6 @@ int utk_classify_lanes(const utk_image *im, const uint8_t *d_bases, const uint64
     return lanes_launch(im, 1, 0, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, 0u);
 }
 
-static int lanes_class_launch(const utk_image *im, int c, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
-                              int do_rc, utree_result *d_out, const utk_workspace *ws, int n_cu, void *stream) {
-    // (the number of reads of a class is on the device: the grid is what n_reads could fill, at most the resident one)
-    return lanes_launch(im, 1 << c, 1, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, (uint32_t)c);
-}
-
 // A batch of mixed lengths: reads are listed by the lanes they need (lanes_route_k; longer ones on ws->long_list for the pieces pass) and
 // every class that can hold a read of the batch runs as its own launch.
 int utk_classify_lanes_mixed(const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off, const uint32_t *d_len, uint32_t n_reads,
@@ -242,16 +238,9 @@ int utk_classify_lanes_mixed(const utk_image *im, const uint8_t *d_bases, const 
     int rc = (int)hipGetLastError();
     int max_cls = 0;
     while (max_cls < 4 && max_len > lc.cap[max_cls]) ++max_cls;             // the largest class a read of the batch can need
-    const char *pe = getenv("UTREE_LANES_CLASS_LAUNCHES");                  // =1: a launch per class, as until round 3 (A/B, tests)
-    const int per_class = pe && atoi(pe) > 0;
-    if (!per_class) {
-        // ONE launch: its wavefronts work through the classes one after the other (classify_lanes_mixed_k)
-        if (!rc) rc = lanes_launch(im, 0, 3, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, (uint32_t)max_cls);
-        return rc;
-    }
-    // the reads of one lane: the plain launch over the batch, told to pass over the longer ones (no list, no trip to it per grab)
-    if (!rc) rc = lanes_launch(im, 1, 0, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, 1u);
-    for (int c = 1; c <= max_cls && !rc; ++c) rc = lanes_class_launch(im, c, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream);
+    // ONE launch: its wavefronts work through the classes one after the other (classify_lanes_mixed_k; a launch per class, the shape until round 3,
+    // cost +5.4 % instead of +4.9 % for 1 % of 300 bp reads among 16 M of 150 bp: profiles/r04/mixed_*_16M.json)
+    if (!rc) rc = lanes_launch(im, 0, 3, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, (uint32_t)max_cls);
     return rc;
 }
 

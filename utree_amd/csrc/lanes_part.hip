@@ -1,43 +1,29 @@
-// lanes_part.hip -- the instantiations of classify_lanes_k (lanes_core.hpp) for ONE (W, I, NL) = (k / 4, label-index bytes, 16-byte loads per
-// bucket), compiled once per combination (Makefile: -DLANES_W= -DLANES_I= -DLANES_NL=) so that the six sets build side by side.
+// lanes_part.hip -- the instantiations of the lane-per-read kernels (lanes_core.hpp) for ONE (W, I, NL, BS) = (k / 4, label-index bytes, 16-byte loads per
+// bucket, both strands from one pass), compiled once per combination (Makefile: -DLANES_W= -DLANES_I= -DLANES_NL= -DLANES_BS=) so that the sets build
+// side by side: a batch of reads of one lane (MODE 0), pieces of long reads (MODE 2), a batch of mixed lengths (classify_lanes_mixed_k: MODE 0 and the
+// listed classes, MODE 1, in one launch).
 #include "lanes_core.hpp"
 
-#define CAT_(a, b, c, d) a##b##_##c##_##d
-#define CAT(a, b, c, d) CAT_(a, b, c, d)
+#define CAT_(a, b, c, d, e) a##b##_##c##_##d##_##e
+#define CAT(a, b, c, d, e) CAT_(a, b, c, d, e)
+#if LANES_BS
+#define BS_ true
+#else
+#define BS_ false
+#endif
 
-// bs: both strands in one pass (64-byte buckets, an image with UTREE_F_STRAND_VIEWS, do_rc set)
-extern "C" int CAT(utk_lanes_part_, LANES_W, LANES_I, LANES_NL)(int segs, int irr, int mode, int bs, const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off,
-                                                                const uint32_t *d_len, uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws,
-                                                                int n_cu, void *stream, uint32_t cls) {
-#define GO2(S_, M_, B_) return irr ? launch_lanes<LANES_W, LANES_I, S_, true, M_, LANES_NL, B_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls) \
-                                   : launch_lanes<LANES_W, LANES_I, S_, false, M_, LANES_NL, B_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
-#if LANES_NL == 1
-#define GO(S_, M_) { if (bs && do_rc) { GO2(S_, M_, true); } GO2(S_, M_, false); }
-#else
-#define GO(S_, M_) { if (bs) return (int)hipErrorInvalidValue; GO2(S_, M_, false); }
-#endif
-    if (mode == 3) {                                           // a batch of mixed lengths, every lanes-per-read class in one launch (cls: the largest class)
-#define GOM(B_) return irr ? launch_lanes_mixed<LANES_W, LANES_I, true, LANES_NL, B_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls) \
-                           : launch_lanes_mixed<LANES_W, LANES_I, false, LANES_NL, B_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
-#if LANES_NL == 1
-        if (bs && do_rc) { GOM(true); }
-#else
-        if (bs) return (int)hipErrorInvalidValue;
-#endif
-        GOM(false);
-#undef GOM
-    }
-    if (mode == 0 && segs == 1) GO(1, 0)                       // a batch of reads of up to 160 bases, whole
-    if (mode == 2 && segs == 16) GO(16, 2)                     // pieces of long reads
-    if (mode == 1) {                                           // one length class of a mixed batch
-        if (segs == 1) GO(1, 1)
-        if (segs == 2) GO(2, 1)
-        if (segs == 4) GO(4, 1)
-        if (segs == 8) GO(8, 1)
-        if (segs == 16) GO(16, 1)
-    }
+extern "C" int CAT(utk_lanes_part_, LANES_W, LANES_I, LANES_NL, LANES_BS)(int segs, int irr, int mode, const utk_image *im, const uint8_t *d_bases, const uint64_t *d_off,
+                                                                          const uint32_t *d_len, uint32_t n_reads, int do_rc, utree_result *d_out, const utk_workspace *ws,
+                                                                          int n_cu, void *stream, uint32_t cls) {
+#define GO(S_, M_) return irr ? launch_lanes<LANES_W, LANES_I, S_, true, M_, LANES_NL, BS_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls) \
+                              : launch_lanes<LANES_W, LANES_I, S_, false, M_, LANES_NL, BS_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
+    if (BS_ && !do_rc) return (int)hipErrorInvalidValue;
+    if (mode == 3)                                             // a batch of mixed lengths, every lanes-per-read class in one launch (cls: the largest class)
+        return irr ? launch_lanes_mixed<LANES_W, LANES_I, true, LANES_NL, BS_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls)
+                   : launch_lanes_mixed<LANES_W, LANES_I, false, LANES_NL, BS_>(im, d_bases, d_off, d_len, n_reads, do_rc, d_out, ws, n_cu, stream, cls);
+    if (mode == 0 && segs == 1) GO(1, 0);                      // a batch of reads of up to 160 bases, whole
+    if (mode == 2 && segs == 16) GO(16, 2);                    // pieces of long reads
 #undef GO
-#undef GO2
     return (int)hipErrorInvalidValue;
 }
 
@@ -45,7 +31,7 @@ extern "C" int CAT(utk_lanes_part_, LANES_W, LANES_I, LANES_NL)(int segs, int ir
 #ifndef UTREE_LANES_TIMERS_W
 #define UTREE_LANES_TIMERS_W 8
 #endif
-#if defined(UTREE_LANES_TIMERS) && LANES_W == UTREE_LANES_TIMERS_W && LANES_I == 2 && LANES_NL == 1
+#if defined(UTREE_LANES_TIMERS) && LANES_W == UTREE_LANES_TIMERS_W && LANES_I == 2 && LANES_NL == 1 && !LANES_BS
 extern "C" {
 void utk_lanes_phase_dump(void) {
     unsigned long long h[8];

@@ -13,7 +13,7 @@ extern "C" {
 #define UTREE_INVALID 0xFFFFFFFFu
 #define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
 #define UTREE_IMG_HEADER_BYTES 4096u
-#define UTREE_IMG_VERSION 11u                    /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region; 10: the vote records carry the file-order index; 11: canonical minimizers, strand-paired buckets */
+#define UTREE_IMG_VERSION 12u                    /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region; 10: the vote records carry the file-order index; 11: canonical minimizers, strand-paired buckets; 12: heavy overflow runs start with a position directory */
 /* How a 16-mer gets its strand-independent rank and address (image version 11, device_common.hpp):
  *   1: the hash of its canonical form, the smaller of the 16-mer and its reverse complement -- three vector instructions per base of a read
  *      on top of the forward walk, but only every other hash value is some canonical 16-mer's: where the table has a pair of buckets per

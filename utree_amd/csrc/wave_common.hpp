@@ -133,7 +133,13 @@ __device__ __forceinline__ uint32_t resolve_bucket(const utk_image &im, const Bu
         last = u.e[HCAP - 1].w[RecTraits<W, I>::KW];
     } else if (im.bucket_words == 16u) last = 0;                                           // (the lower half's last entry is never a descriptor)
     if ((last >> 62) == 2 && rank == INVALID) {                                            // the rest of the bucket's nodes
-        const uint64_t start = last & M40, n = (last >> 40) & 0x3FFFFFull;
+        uint64_t start = ovf_first<W, I>(last), n = ovf_count(last);
+        if (last & OVF_HAS_DIR) {                                                         // a heavy run: only the records of the key's own position
+            const uint16_t *dir = (const uint16_t *)(im.mrecs + (last & M39) * RecTraits<W, I>::EW);
+            const uint32_t pos = W == 16 ? (uint32_t)(mk.hi >> 32) & 63u : (uint32_t)(mk.lo >> 32) & 31u;
+            const uint32_t a = dir[pos], b = dir[pos + 1];
+            n = b - a; start += a;
+        }
         rank = min_find<W, I>(im.mrecs, start, start + n, mk);
     }
     return rank;
