@@ -768,7 +768,10 @@ _Pragma("unroll") for (uint32_t x = 0; x < NA; ++x) { A[x] = RA[x]; B[x] = RB[x]
                 }
                 // a heavy run: its directory narrows the range to the records of the window's own minimizer position (one trip for all the searches of the
                 // round; a lane without a directory reads the image's first bytes)
-                {
+                bool anydir = false;
+#pragma unroll
+                for (uint32_t u = 0; u < OVF_WAYS; ++u) anydir = anydir || dirp[u] != nullptr;
+                if (ballot64(anydir)) {                                            // (no run of the round has one -- the usual case outside related genomes --: no trip)
                     uint32_t da[OVF_WAYS], db[OVF_WAYS];
 #pragma unroll
                     for (uint32_t u = 0; u < OVF_WAYS; ++u) {
