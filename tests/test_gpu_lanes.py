@@ -525,3 +525,34 @@ def test_both_strands_when_nearly_every_bucket_overflows(torch_cuda, k, tmp_path
         assert classify_fasta_bytes(db, tree, data, rc=rc) == oracle_text(o, data, tmp_path, rc=rc)
         assert tree.kernel_name().startswith("classify_lanes_k<%d, 2, 1, false, 0, 1, %s>" % (k // 4, "true" if rc else "false"))
     tree.close()
+
+
+@pytest.mark.parametrize("sub", [3, 7])
+def test_k64_slots_split_by_the_four_bases_around_the_minimizer(torch_cuda, sub, tmp_path, monkeypatch):
+    """Image version 13, k = 64: a window's minimizer keeps two bases' distance from the window's ends, and where one hash value holds more
+    nodes than a bucket its slot is several pairs of buckets, picked by the four bases around the minimizer in its canonical orientation
+    (utree_internal.h: UTREE_MIN_MARGIN; dev_image.c: compute_regions).  Databases of the test suite's size never get there by themselves
+    (the full-size configs[4] test does): UTREE_TEST_SUB gives every slot `sub` pairs.  Reads in both orientations, both strand modes,
+    both kernel families: the oracle's lines."""
+    monkeypatch.setenv("UTREE_TEST_SUB", str(sub))
+    d = OwnDB(tmp_path, seed=77 + sub, k=64)
+    db = CtrDB.open(d.ctr)
+    o = orc.OracleDB.load(d.ctr)
+    rng = np.random.default_rng(sub)
+    comp = str.maketrans("ACGT", "TGCA")
+    reads = random_reads(rng, d, 5000, 64, 160, hit_frac=0.9)
+    reads = [(n, s if i % 2 else s.translate(comp)[::-1]) for i, (n, s) in enumerate(reads)]
+    reads += random_reads(rng, d, 300, 200, 2500, hit_frac=0.8)
+    data = fasta_bytes(reads)
+    want = {rc: oracle_text(o, data, tmp_path, rc=rc) for rc in (False, True)}
+    tree = DeviceTree.upload(db, 0)
+    for lane_pass, bs in (("1", "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("UTREE_LANE_PASS", lane_pass)
+        monkeypatch.setenv("UTREE_LANES_BS", bs)
+        for rc in (False, True):
+            assert classify_fasta_bytes(db, tree, data, rc=rc) == want[rc], (lane_pass, bs, rc)
+    monkeypatch.delenv("UTREE_TEST_SUB")
+    plain = DeviceTree.upload(db, 0)
+    assert tree.info.image_bytes > plain.info.image_bytes + (sub - 1) * (1 << 31) - (1 << 28)      # 2^24 more pairs per pair and slot
+    plain.close()
+    tree.close()

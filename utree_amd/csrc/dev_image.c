@@ -96,10 +96,17 @@ static double lumpy_overflow(double nb, double expect, uint32_t cap) {
     return totw > 0 ? tot / totw : 0;
 }
 
-static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32_t bucket_words, uint32_t F, uint64_t regions[256]) {
+/* k = 64 (UTREE_MIN_MARGIN): where a region has a slot per hash value and a value still holds more nodes than the design load, the slot is
+ * `sub` pairs of buckets, picked by the four bases around the minimizer (256 combinations: a pair gets floor or ceil(256 / sub) of them).
+ * UTREE_SUB_SLICES=0: none (A/B). */
+static int sub_slices_on(uint32_t W, uint32_t F) {
+    const char *e = getenv("UTREE_SUB_SLICES");
+    return W == 16 && F >= 8 && !(e && e[0] == '0');
+}
+static uint64_t compute_regions_sub(uint64_t n_nodes, uint32_t W, uint32_t I, uint32_t bucket_words, uint32_t F, int sub_on, uint64_t regions[256]) {
     /* (image version 11: the region table counts PAIRS of buckets -- the two orientations of a canonical 16-mer --, a pair is sized for
      * 2 TARGET nodes) */
-    const double m = (UTREE_CANON_MODE == 2 ? 2.0 : 1.0) * (4.0 * W - 15.0);   /* mode 2: the smallest of 2 (K - 15) hashes */
+    const double m = (UTREE_CANON_MODE == 2 ? 2.0 : 1.0) * (4.0 * W - 15.0 - 2.0 * UTREE_MIN_MARGIN(W));   /* mode 2: the smallest of 2 (K - 15) hashes */
     const uint32_t cap_entries = bucket_words / utree_rec_words(W, I);
     const char *te = getenv("UTREE_BUCKET_TARGET");                     /* nodes per bucket; experiments only */
     const double target = te && atof(te) > 0 ? atof(te) : (bucket_words == 16 ? 0.5625 : 0.375) * cap_entries;
@@ -111,17 +118,35 @@ static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32
     for (int r = 0; r < 256; ++r) {
         const double expect = (double)n_nodes * (pow(1.0 - r / 256.0, m) - pow(1.0 - (r + 1) / 256.0, m));
         double want = ceil(expect / (2.0 * target));
-        uint64_t nb = want >= (double)nb_max ? nb_max : (uint64_t)want;
+        uint64_t nb = want >= (double)nb_max ? nb_max : (uint64_t)want, sub = 1;
         if (nb < nb_min) nb = nb_min;
         if (nb > nb_max) nb = nb_max;
         /* mode 1: more pairs where a pair holds so few hash values that the occupied ones make lumps: up to the overflow share the design
          * load has without them (times `slack`), at most one pair per value */
         if (UTREE_CANON_MODE != 2 && slack > 0)
             while (nb < nb_max && lumpy_overflow((double)nb, expect, cap_entries) > slack * p0 + 1e-4) { nb += nb / 20 + 1; if (nb > nb_max) nb = nb_max; }
-        if (regions) regions[r] = (base << UTREE_REGION_NB_BITS) | nb;
-        base += nb;
+        /* ... and beyond one slot per value (k = 64): an occupied value -- every other one in mode 1 -- has expect / 2^23 nodes, half of them per
+         * orientation, spread over the slot's pairs by the 256 combinations of four bases; the fullest pair gets ceil(256 / sub) of them */
+        if (sub_on && nb == (1ull << 24)) {
+            const double per_value = expect / 16777216.0 * (UTREE_CANON_MODE == 2 ? 0.5 : 1.0);   /* nodes per occupied value and orientation */
+            while (sub < 256 && pois_tail_nodes(per_value * ceil(256.0 / (double)sub) / 256.0, cap_entries) > slack * p0 + 1e-4) ++sub;
+        }
+        /* test hook: that many pairs per slot in every region (the addressing does not need a slot to be one hash value) */
+        { const char *ts = getenv("UTREE_TEST_SUB"); if (sub_on && ts && atoi(ts) >= 1 && atoi(ts) <= 256) sub = (uint64_t)atoi(ts); }
+        if (regions) regions[r] = (base << UTREE_REGION_BASE_SHIFT) | (sub << UTREE_REGION_NB_BITS) | nb;
+        base += nb * sub;
     }
     return 2 * base;
+}
+static uint64_t compute_regions(uint64_t n_nodes, uint32_t W, uint32_t I, uint32_t bucket_words, uint32_t F, uint64_t regions[256]) {
+    /* sub-slices as long as the table stays within the cap (utree_pick_fine_bits lowers F only after they are gone) */
+    if (sub_slices_on(W, F)) {
+        const char *cap_env = getenv("UTREE_TABLE_MAX_GB");
+        const double cap = (cap_env && atof(cap_env) > 0 ? atof(cap_env) : 96.0) * 1073741824.0;
+        if ((double)compute_regions_sub(n_nodes, W, I, bucket_words, F, 1, NULL) * 8.0 * bucket_words <= cap)
+            return compute_regions_sub(n_nodes, W, I, bucket_words, F, 1, regions);
+    }
+    return compute_regions_sub(n_nodes, W, I, bucket_words, F, 0, regions);
 }
 
 /* MIN records beyond one per node the build area holds: the second views of k-mers whose two views differ (ties in the 23-bit rank,

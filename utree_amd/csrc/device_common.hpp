@@ -214,14 +214,27 @@ template <int W> __device__ __forceinline__ uint32_t mer_at(uint64_t khi, uint64
 // per-position hashes shared by the lanes of a wave): f = leftmost 16-mer of the smallest rank, g = rightmost, o_g = 1 for a palindrome.
 template <int W> __device__ __forceinline__ void minimizer_views(uint64_t khi, uint64_t klo, uint32_t &hf, uint32_t &of, uint32_t &pf,
                                                                 uint32_t &hg, uint32_t &og, uint32_t &pg) {
+    // (k = 64: positions UTREE_MIN_MARGIN .. K-16 - UTREE_MIN_MARGIN only -- utree_internal.h)
+    constexpr uint32_t J0 = UTREE_MIN_MARGIN(W);
     uint32_t best = 0xFFFFFFFFu;
     hf = hg = of = og = pf = pg = 0;
-    for (uint32_t j = 0; j <= 4u * W - 16u; ++j) {
+    for (uint32_t j = J0; j <= 4u * W - 16u - J0; ++j) {
         const uint32_t m = mer_at<W>(khi, klo, j);
         uint32_t o1, o2;
         const uint32_t hh = canon_of(m, rc16(m), o1, o2), key = hh >> MIN_LOW_BITS;
-        if (j == 0 || key < best) { best = key; hf = hh; of = o1; pf = j; }
-        if (j == 0 || key <= best) { hg = hh; og = o2; pg = j; }
+        if (j == J0 || key < best) { best = key; hf = hh; of = o1; pf = j; }
+        if (j == J0 || key <= best) { hg = hh; og = o2; pg = j; }
+    }
+}
+// The four bases around a minimizer -- two in front of it, two behind: in `rest` they are neighbours, bases pos-2 .. pos+1 -- in the minimizer's
+// canonical orientation (o = 1: the reverse complement of the four): the same eight bits for a window and for its reverse complement, whose
+// minimizer is the same 16-mer read the other way.  k = 64 only (UTREE_MIN_MARGIN: the four bases exist in every k-mer of the run).
+__host__ __device__ __forceinline__ uint32_t ext_canon(uint32_t four, uint32_t o) { return o ? (rc16(four << 24) & 0xFFu) : four; }
+template <int W> __host__ __device__ __forceinline__ uint32_t min_ext(uint32_t rest_hi32, uint64_t rest_lo, uint32_t pos, uint32_t o) {
+    if constexpr (W != 16) return 0u;
+    else {
+        const unsigned __int128 r = ((unsigned __int128)rest_hi32 << 64) | rest_lo;    // 48 bases, base 0 on top
+        return ext_canon((uint32_t)(r >> (92u - 2u * pos)) & 0xFFu, o);               // pos in 2 .. 46
     }
 }
 // view f alone
@@ -233,15 +246,19 @@ template <int W> __device__ __forceinline__ void minimizer(uint64_t khi, uint64_
 }
 
 // Bucket of a minimizer (hash of the canonical 16-mer, orientation) and the hash bits the bucket does not imply (utree_image_header.regions):
-// region r = the hash's top 8 bits has nb_r PAIRS of buckets (any number from 2^16 to 2^24) over its 2^24 hash values, pair = base_r +
-// ((h24 * nb_r) >> 24) -- one multiply-high of (h << 8) --, so that a pair spans at most 256 consecutive hash values and the hash's low 8
-// bits tell them apart; bucket = 2 * pair + o.
+// region r = the hash's top 8 bits has nb_r SLOTS (any number from 2^16 to 2^24) over its 2^24 hash values, slot = (h24 * nb_r) >> 24 -- one
+// multiply-high of (h << 8) --, so that a slot spans at most 256 consecutive hash values and the hash's low 8 bits tell them apart; a slot is
+// one PAIR of buckets (k = 64 where a slot is one hash value: sub_r pairs, picked by the four bases around the minimizer); bucket = 2 * pair + o.
 __host__ __device__ __forceinline__ uint32_t bucket_in_region(uint32_t h, uint32_t nb) {
     return (uint32_t)(((uint64_t)(h << 8) * nb) >> 32);
 }
-__host__ __device__ __forceinline__ void bucket_of(const uint64_t *__restrict__ regions, uint32_t h, uint32_t o, uint64_t &bucket, uint32_t &hlow) {
-    const uint64_t e = regions[h >> 24];
-    bucket = 2u * ((e >> UTREE_REGION_NB_BITS) + bucket_in_region(h, (uint32_t)e & ((1u << UTREE_REGION_NB_BITS) - 1u))) + o;
+// (ext: min_ext -- k = 64: a slot of the region has sub_r pairs, the minimizer's four neighbours pick one; k = 32: 0, and sub_r is 1)
+__host__ __device__ __forceinline__ uint64_t pair_of(uint64_t e, uint32_t h, uint32_t ext) {
+    const uint32_t nb = (uint32_t)e & ((1u << UTREE_REGION_NB_BITS) - 1u), sub = (uint32_t)(e >> UTREE_REGION_NB_BITS) & ((1u << UTREE_REGION_SUB_BITS) - 1u);
+    return (e >> UTREE_REGION_BASE_SHIFT) + (uint64_t)bucket_in_region(h, nb) * sub + ((ext * sub) >> 8);
+}
+__host__ __device__ __forceinline__ void bucket_of(const uint64_t *__restrict__ regions, uint32_t h, uint32_t o, uint32_t ext, uint64_t &bucket, uint32_t &hlow) {
+    bucket = 2u * pair_of(regions[h >> 24], h, ext) + o;
     hlow = h & 0xFFu;
 }
 
@@ -250,7 +267,7 @@ template <int W> __device__ __forceinline__ void min_finish(uint64_t khi, uint64
                                                            const uint64_t *__restrict__ regions, uint64_t &bucket, MinKey<W> &mk) {
     uint32_t rh, hl; uint64_t rl;
     min_rest<W>(khi, klo, pos, rh, rl);
-    bucket_of(regions, h, o, bucket, hl);
+    bucket_of(regions, h, o, min_ext<W>(rh, rl, pos, o), bucket, hl);
     const uint64_t hlow = hl;
     if constexpr (W == 8) { mk.hi = 0; mk.lo = (hlow << 37) | ((uint64_t)pos << 32) | rl; }
     else { mk.lo = rl; mk.hi = (hlow << 38) | ((uint64_t)pos << 32) | rh; }

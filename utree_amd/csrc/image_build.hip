@@ -145,6 +145,11 @@ __global__ void assign_k(const OFF *__restrict__ coarse, const uint64_t *__restr
     }
 }
 
+// the four bases around entry i's minimizer (device_common.hpp: min_ext) from its sort keys
+template <int W> __device__ __forceinline__ uint32_t entry_ext(const uint64_t *__restrict__ K1, const uint64_t *__restrict__ K2, const uint8_t *__restrict__ O, uint64_t i) {
+    if constexpr (W == 16) return min_ext<W>((uint32_t)K2[i], K1[i], (uint32_t)(K2[i] >> 32), O[i]); else return 0u;
+}
+
 // MIN record j = entry idx[j] in the final (bucket, hash bits, pos, rest) order; entry i is node i, or node SRC[i - m] under its second view
 template <int W, int I, typename IDX>
 __global__ void emit_k(const uint64_t *__restrict__ recs, uint64_t c0, const IDX *__restrict__ idx, const uint32_t *__restrict__ H, const uint8_t *__restrict__ O,
@@ -155,7 +160,7 @@ __global__ void emit_k(const uint64_t *__restrict__ recs, uint64_t c0, const IDX
         const uint64_t i = idx[j];
         const uint32_t h = H[i];
         uint64_t bucket; uint32_t hl;
-        bucket_of(regions, h, O[i], bucket, hl);
+        bucket_of(regions, h, O[i], entry_ext<W>(K1, K2, O, i), bucket, hl);
         const uint64_t hlow = hl;
         MinKey<W> mk;
         if constexpr (W == 16) { mk.lo = K1[i]; mk.hi = (hlow << 38) | K2[i]; } else { mk.hi = 0; mk.lo = (hlow << 37) | K1[i]; }
@@ -304,18 +309,19 @@ int sort_pass(const uint64_t *key_by_node, uint32_t nbits, IDX *&idx, IDX *&idx_
 // the last pass: by { bucket | the hash's low 8 bits } -- the bucket is monotone in the hash, but a bucket's up to 256 consecutive
 // hash values need not ascend in their low 8 bits, and inside a bucket (and its overflow run) records ascend by their KEY, whose top
 // field those 8 bits are
-template <typename IDX> __global__ void gather_bkey_k(const uint32_t *__restrict__ H, const uint8_t *__restrict__ O, const IDX *__restrict__ idx, const uint64_t *__restrict__ regions,
-                                                      uint64_t *__restrict__ dst, uint64_t n) {
+template <int W, typename IDX> __global__ void gather_bkey_k(const uint32_t *__restrict__ H, const uint8_t *__restrict__ O, const uint64_t *__restrict__ K1, const uint64_t *__restrict__ K2,
+                                                             const IDX *__restrict__ idx, const uint64_t *__restrict__ regions, uint64_t *__restrict__ dst, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t b; uint32_t hl;
-        bucket_of(regions, H[idx[i]], O[idx[i]], b, hl);
+        const uint64_t t = idx[i];
+        bucket_of(regions, H[t], O[t], entry_ext<W>(K1, K2, O, t), b, hl);
         dst[i] = (b << 8) | hl;
     }
 }
-template <typename IDX>
-int sort_pass_bucket(const uint32_t *H, const uint8_t *O, const uint64_t *regions, uint32_t nbits, IDX *&idx, IDX *&idx_alt, uint64_t *kg, uint64_t *kg_alt, uint64_t m,
+template <int W, typename IDX>
+int sort_pass_bucket(const uint32_t *H, const uint8_t *O, const uint64_t *K1, const uint64_t *K2, const uint64_t *regions, uint32_t nbits, IDX *&idx, IDX *&idx_alt, uint64_t *kg, uint64_t *kg_alt, uint64_t m,
                      void *tmp, size_t tmp_bytes, hipStream_t st) {
-    gather_bkey_k<IDX><<<grid_for(m), 256, 0, st>>>(H, O, idx, regions, kg, m);
+    gather_bkey_k<W, IDX><<<grid_for(m), 256, 0, st>>>(H, O, K1, K2, idx, regions, kg, m);
     hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, kg, kg_alt, idx, idx_alt, m, 0, nbits, st);
     if (e != hipSuccess) return (int)e;
     IDX *t = idx; idx = idx_alt; idx_alt = t;
@@ -486,7 +492,7 @@ int build_min(const OFF *coarse, const uint64_t *recs, uint64_t c0, const uint64
         {
             uint32_t bbits = 1;
             while (bbits < 56 && (n_buckets >> bbits)) ++bbits;
-            if ((rc = sort_pass_bucket<IDX>(H, O, regions, 8 + bbits, idx, idx2, kg, kg2, mq, tmp, t64, st))) goto done;   // bucket (pair, orientation), low hash bits
+            if ((rc = sort_pass_bucket<W, IDX>(H, O, K1, K2, regions, 8 + bbits, idx, idx2, kg, kg2, mq, tmp, t64, st))) goto done;   // bucket (pair, orientation), low hash bits
         }
         Bs = kg;
         // emit_k recomputes the buckets from H[idx], O[idx]: Bs becomes the array of bucket numbers in the final order

@@ -70,14 +70,15 @@ __device__ __forceinline__ uint32_t mmer_l(const uint32_t *s, uint32_t word, uin
 // once per window that contains it).  The order among 16-mers is that of minimizer<W>() (device_common.hpp): the hash
 // without its MIN_LOW_BITS low bits, leftmost on ties -- which makes a 32-bit key { hash bits | position in the tile }
 // enough, and the sliding minimum one v_min_u32 per step.  After the call, for the window that starts at tile position t:
-//     p = min(Kk[t], Kk[t + NEXT]) & MIN_POS_MASK  =  tile position of its minimizer,  Hh[p] = that 16-mer's full hash,
+//     p = min(Kk[t + FIRST], Kk[t + FIRST + NEXT]) & MIN_POS_MASK  =  tile position of its minimizer,  Hh[p] = that 16-mer's full hash,
 // the same (h, pos) minimizer<W>() computes from the word.  Kk and Hh need (NCH + 1) * 64 entries.
 // In place: step s replaces K[t] by min(K[t], K[t+s]); chunks ascend, so chunk c still sees chunk c+1's old values.
 // Straight-line per chunk count NCH (the dispatcher below picks it): all LDS offsets are immediates off the per-lane
 // pointers Kl = Kk + lane, Hl = Hh + lane.  Positions past the read's last full 16-mer hash stale bytes; no valid window
 // looks at them (a window's 16-mers lie inside the read).
 constexpr uint32_t MIN_POS_MASK = (1u << MIN_LOW_BITS) - 1u;       // a tile has < 2^MIN_LOW_BITS positions
-template <int W> struct MinWin { static constexpr uint32_t NEXT = (W == 16) ? 17u : 1u; };   // [t,t+16)+[t+1,t+17) / [t,t+32)+[t+17,t+49)
+// (k = 64: the candidates of window t are the 16-mers t+2 .. t+46 -- UTREE_MIN_MARGIN)
+template <int W> struct MinWin { static constexpr uint32_t FIRST = UTREE_MIN_MARGIN(W), NEXT = (W == 16) ? 13u : 1u; };   // [t,t+16)+[t+1,t+17) / [t+2,t+34)+[t+15,t+47)
 template <int W, uint32_t NCH>
 __device__ __forceinline__ void build_minkeys_n(const uint32_t *s, uint32_t sh, uint32_t *Kl, uint32_t *Hl, uint64_t *Ob, uint32_t lane) {
     uint32_t x[NCH];
@@ -124,7 +125,7 @@ __device__ __forceinline__ void build_minkeys(const uint32_t *s, uint32_t sh, ui
 }
 
 // The block's copy of the image's region table in the form the window loop wants it (stage_regions):
-//   s_reg[r] = the header's entry, first bucket << 25 | buckets of the region: bucket address = table + ((first + mulhi(h << 8, nb)) << 6 or 7)
+//   s_reg[r] = the header's entry, first pair << 34 | pairs per slot << 25 | slots of the region (device_common.hpp: pair_of)
 struct RegionLds { const uint64_t *reg; uint64_t table; uint32_t bshift; };   // bshift: log2 of a bucket's bytes
 
 // One wave looks up the windows [w0, w0+n) of a staged buffer (lb / sw = packed bases, sbad = bad-base bit words, both
@@ -171,17 +172,26 @@ __device__ __forceinline__ void wave_scan_windows(const utk_image &im, const Lan
         // it) of the lane's window in round `it`; resolve(): the rank its bucket holds for the window.
         auto locate = [&](uint32_t it, uint64_t &baddr, uint32_t &tag) {
             const uint32_t *Kr = Kl + it * 64;
-            const uint32_t ka = Kr[0], kb = Kr[MinWin<W>::NEXT];
+            const uint32_t ka = Kr[MinWin<W>::FIRST], kb = Kr[MinWin<W>::FIRST + MinWin<W>::NEXT];
             const uint32_t p = (kb < ka ? kb : ka) & MIN_POS_MASK;
             const uint32_t h = Hh[p];
             const uint32_t o = (uint32_t)(Ob[p >> 6] >> (p & 63u)) & 1u;    // the read holds the canonical 16-mer (0) or its reverse complement
             const uint32_t pos = p + nlane - it * 64;                       // minimizer position inside the window
             const uint64_t re = rg.reg[h >> 24];
-            const uint32_t bl = __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u));
+            uint32_t bl = __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u));
+            if constexpr (W == 16) {
+                // the slot's pair: by the four bases around the minimizer, bases pos-2 .. pos+17 of the window being a 20-mer whose ends they are
+                const uint32_t *sr = st + it * 4;
+                const uint32_t x0 = mmer_l(sr, 0, lb.sh), x1 = mmer_l(sr, 1, lb.sh), x2 = mmer_l(sr, 2, lb.sh), x3 = mmer_l(sr, 3, lb.sh);
+                const unsigned __int128 w = ((unsigned __int128)(((uint64_t)x0 << 32) | x1) << 64) | (((uint64_t)x2 << 32) | x3);
+                const uint64_t v = (uint64_t)(w >> (92u - 2u * pos));                  // its low 40 bits: the 20-mer
+                const uint32_t sub = (uint32_t)(re >> UTREE_REGION_NB_BITS) & ((1u << UTREE_REGION_SUB_BITS) - 1u);
+                bl = bl * sub + ((ext_canon((uint32_t)((v >> 32) & 0xF0u) | (uint32_t)(v & 0xFu), o) * sub) >> 8);
+            }
 #ifdef UTREE_ABLATE_L2
             baddr = rg.table + ((uint64_t)(bl & 0x1FFFu) << rg.bshift);     // timing experiment: every bucket inside 1 MB (L2 hits), answers wrong
 #else
-            baddr = rg.table + ((2u * ((re >> UTREE_REGION_NB_BITS) + bl) + o) << rg.bshift);
+            baddr = rg.table + ((2u * ((re >> UTREE_REGION_BASE_SHIFT) + bl) + o) << rg.bshift);
 #endif
             tag = ((h & 0xFFu) << 6) | pos;                                 // hash bits the bucket does not imply | position (< 64)
         };

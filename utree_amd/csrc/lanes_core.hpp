@@ -67,7 +67,7 @@ static_assert(LCAP % 32 == 0, "slot geometry");
 static_assert(LCAP + 16 + 48 <= 256, "positions are 8-bit fields of a run record");
 // per k-mer length (W = 8: k = 32, W = 16: k = 64)
 template <int W> struct Geo {
-    static constexpr uint32_t K = 4 * W, NB = K - 15;                  // bases, and 16-mers, of a window
+    static constexpr uint32_t K = 4 * W, OFS = UTREE_MIN_MARGIN(W), NB = K - 15 - 2 * OFS;   // bases of a window; its 16-mers that may be its minimizer: those at OFS .. OFS + NB - 1 (k = 64 leaves two at either end out: utree_internal.h)
     static constexpr uint32_t NA = W == 16 ? 3 : 1;                    // words of bases in front of / behind the minimizer a k-mer may reach
     static constexpr uint32_t FRONT = NA;                              // pad words in front of a lane's slot
     static constexpr uint32_t STRIDE = NWORD + FRONT + 2;              // ... and two behind; odd: lane slots fall on different banks
@@ -134,7 +134,7 @@ __device__ __forceinline__ void lanes_body(const utk_image &im, const uint8_t *_
     static_assert(!BS || NL == 1, "both strands in one pass: 64-byte buckets");
     constexpr int NLX = BS ? 2 : NL;                                 // 16-byte loads per lane and run: the pipeline is that of the 128-byte buckets
     using G = Geo<W>;
-    constexpr uint32_t K = G::K, NB = G::NB, NA = G::NA, STRIDE = G::STRIDE, FRONT = G::FRONT, RUNS_CAP = G::RUNS;
+    constexpr uint32_t K = G::K, NB = G::NB, OFS = G::OFS, NA = G::NA, STRIDE = G::STRIDE, FRONT = G::FRONT, RUNS_CAP = G::RUNS;
     constexpr uint32_t SW = LCAP - K + 1, RPW = 64 / SEGS;            // windows per lane; reads per wavefront
     constexpr uint32_t SEGSH = SEGS == 16 ? 4 : SEGS == 8 ? 3 : SEGS == 4 ? 2 : SEGS == 2 ? 1 : 0;
     constexpr uint32_t TSR = TSLOTS * SEGS < 48u ? TSLOTS * SEGS : 48u;   // tally slots per read: the table space of its lanes, up to 48 labels
@@ -147,9 +147,21 @@ __device__ __forceinline__ void lanes_body(const utk_image &im, const uint8_t *_
     constexpr uint32_t QS = I == 2 ? 16u : 20u, QMASK = (1u << QS) - 1u;
     const uint64_t tbl = (uint64_t)(uintptr_t)im.table;
     // the bucket of a minimizer: the hash of its canonical form picks the pair, the orientation the bucket (device_common.hpp: bucket_of)
-    auto bucket_addr = [&](uint32_t h, uint32_t o) -> uint64_t {
+    // (k = 64: `ext`, the four bases around the minimizer in its canonical orientation, picks one of the pairs of the hash value's slot)
+    // (the bucket's NUMBER: 32 bits -- 2^32 buckets are 256 GiB --, which is what a run keeps of its minimizer's hash between prepare and issue)
+    auto bucket_index = [&](uint32_t h, uint32_t o, uint32_t ext) -> uint32_t {
         const uint64_t re = s_reg[h >> 24];
-        return tbl + ((2u * ((re >> UTREE_REGION_NB_BITS) + __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u))) + o) << (NL == 2 ? 7 : 6));
+        uint32_t slot = __umulhi(h << 8, (uint32_t)re & ((1u << UTREE_REGION_NB_BITS) - 1u));
+        if constexpr (W == 16) {
+            const uint32_t sub = (uint32_t)(re >> UTREE_REGION_NB_BITS) & ((1u << UTREE_REGION_SUB_BITS) - 1u);
+            slot = slot * sub + ((ext * sub) >> 8);
+        }
+        return 2u * ((uint32_t)(re >> UTREE_REGION_BASE_SHIFT) + slot) + o;
+    };
+    auto bucket_addr = [&](uint32_t h, uint32_t o, uint32_t ext) -> uint64_t { return tbl + ((uint64_t)bucket_index(h, o, ext) << (NL == 2 ? 7 : 6)); };
+    // the four bases around a minimizer from the words in front of it and behind it (device_common.hpp: min_ext)
+    auto ext_of = [&](const uint32_t (&A)[G::NA], const uint32_t (&B)[G::NA], uint32_t o) -> uint32_t {
+        if constexpr (W == 16) return ext_canon(((A[G::NA - 1u] & 0xFu) << 4) | (B[0] >> 28), o); else return 0u;
     };
     const uint32_t lane = lane_id();
     uint32_t *sl = stream + lane * STRIDE + FRONT;                        // the lane's slot, word 0
@@ -315,12 +327,14 @@ __device__ __forceinline__ void lanes_body(const utk_image &im, const uint8_t *_
                 }
             };
             irregular(m16, 0u);
-            A[0] = CKEY();
 #pragma unroll
-            for (uint32_t p = 16; p < K; ++p) {
+            for (uint32_t p = 16; p < 16 + OFS; ++p) { ROLL16(p) irregular(m16, p - 15u); }   // (16-mers in front of the first candidate)
+            A[0] = CKEY() | OFS;
+#pragma unroll
+            for (uint32_t p = 16 + OFS; p < K - OFS; ++p) {
                 ROLL16(p)
                 irregular(m16, p - 15u);
-                A[p - 15] = CKEY() | (p - 15u);
+                A[p - 15 - OFS] = CKEY() | (p - 15u);
             }
             // A window that does not exist (beyond the read's last) or holds the bad base (itree.c:919-927) carries the key ~0 -- no
             // 16-mer's -- instead of its minimizer's: the run before it ends there like at any change of minimizer, and a "run" of
@@ -342,10 +356,10 @@ _Pragma("unroll") \
                     uint32_t wmin; \
                     if (rr == 0) wmin = A[0]; \
                     else { \
-                        const uint32_t p = s + (K - 1u); \
+                        const uint32_t p = s + (K - 1u - OFS); \
                         ROLL16(p) \
-                        irregular(m16, s + (NB - 1u)); \
-                        const uint32_t k = CKEY() | (s + (NB - 1u)); \
+                        irregular(m16, s + (OFS + NB - 1u)); \
+                        const uint32_t k = CKEY() | (s + (OFS + NB - 1u)); \
                         const uint32_t Sr = A[rr]; \
                         A[rr - 1] = k; \
                         P = rr == 1 ? k : umin(P, k); \
@@ -368,10 +382,10 @@ _Pragma("unroll") \
                     if ((rr % 6u) == 0u && s >= maxnwin) { done = true; break; } \
                 } \
                 if (done) break; \
-                const uint32_t p = NB * (b + 1u) + (K - 1u); \
+                const uint32_t p = NB * (b + 1u) + (K - 1u - OFS); \
                 ROLL16(p) \
-                irregular(m16, NB * (b + 1u) + (NB - 1u)); \
-                A[NB - 1] = CKEY() | (NB * (b + 1u) + (NB - 1u)); \
+                irregular(m16, NB * (b + 1u) + (OFS + NB - 1u)); \
+                A[NB - 1] = CKEY() | (NB * (b + 1u) + (OFS + NB - 1u)); \
             }
 #ifdef UTREE_LANES_NOCLEAN
             const bool clean = false;
@@ -396,7 +410,7 @@ _Pragma("unroll") \
         // quad broadcast (DPP), nothing goes through LDS.  Two more batches of 64 buckets are in flight meanwhile.
         // (a lane beyond the list repeats the list's last run -- its load stays inside the table -- as a run no entry can belong to)
         uint32_t n_ovf = 0, ovf_room = 0;                                  // ovf_room: run records phase B has read (prepared) so far
-        // what a scan needs of a run: {minimizer hash (for the bucket's address), first window | minimizer position - first << 8 | windows - 1
+        // what a scan needs of a run: {its bucket, first window | minimizer position - first << 8 | windows - 1
         // << 14 | read << 20, the range of entry tags its windows have, the 16 (k = 64: 48) bases before the minimizer, the 16 (48) behind it}.
         // An entry's tag is {flag2 | hash low bits | minimizer position in the k-mer} (its high half-word; k = 32: times two, the zero bit
         // below the position included): the run's windows have the tags tlo .. tlo + span -- hash bits of the run's minimizer, positions
@@ -404,7 +418,7 @@ _Pragma("unroll") \
         // (pk bit 31: the orientation o of the run's minimizer in the read -- the bucket of the pair its windows' records are in.  BS: tr, RA, RB
         // are the same for the windows' reverse complements: they have the mirrored positions K-16-p in bucket 1-o, and their outer bases are
         // the reverse complement of the 2 (K-16) bases around the minimizer, read the same way)
-        struct RunRegs { uint32_t h, pk, t, A[NA], B[NA], tr, RA[NA], RB[NA]; };
+        struct RunRegs { uint32_t b, pk, t, A[NA], B[NA], tr, RA[NA], RB[NA]; };   // b: the run's bucket (its number)
         constexpr uint32_t TSH = W == 8 ? 1u : 0u, PB = W == 8 ? 5u : 6u;             // tag scale; bits of the position field
         constexpr uint32_t KM = K - 16u;                                              // the largest minimizer position
         auto rev_context = [&](const uint32_t (&A)[NA], const uint32_t (&B)[NA], uint32_t (&RA)[NA], uint32_t (&RB)[NA]) {
@@ -434,15 +448,16 @@ _Pragma("unroll") \
             const uint32_t end = (rec >> 16) & 0xFFu;
             uint32_t m, o;
             context(q, ustar, m, c.A, c.B);
-            c.h = canon_hash(m, o);
+            const uint32_t h = canon_hash(m, o);
+            c.b = bucket_index(h, o, ext_of(c.A, c.B, o));
             // (beyond the list: an offset no run has -- no entry's position field names a window of that run)
             const uint32_t dl = act ? ((ustar - first) << 8) | ((end - 1u - first) << 14) : (G::DNONE << 8);
             c.pk = first | dl | (q << 20) | (o << 31);
             // (beyond the list: a range no entry's tag lies in)
-            c.t = act ? (((((c.h & 0xFFu) << PB) | (ustar - (end - 1u))) << TSH) | (((end - 1u - first) << TSH) << 16)) : 0xFFFFu;
+            c.t = act ? (((((h & 0xFFu) << PB) | (ustar - (end - 1u))) << TSH) | (((end - 1u - first) << TSH) << 16)) : 0xFFFFu;
             if constexpr (BS) {
                 rev_context(c.A, c.B, c.RA, c.RB);
-                c.tr = act ? (((((c.h & 0xFFu) << PB) | (KM - (ustar - first))) << TSH) | (((end - 1u - first) << TSH) << 16)) : 0xFFFFu;
+                c.tr = act ? (((((h & 0xFFu) << PB) | (KM - (ustar - first))) << TSH) | (((end - 1u - first) << TSH) << 16)) : 0xFFFFu;
             }
         };
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -458,7 +473,7 @@ _Pragma("unroll") \
 #define ISSUE_K(k, at) { const uint64_t b_ = ((uint64_t)QUAD_BCAST(ahi, k) << 32) | (QUAD_BCAST(alo, k) | mine); \
                          P[at] = *(gptr128)b_; if constexpr (NL == 2) P[at + 1] = *(gptr128)(b_ | 64u); if constexpr (BS) P[at + 1] = *(gptr128)(b_ ^ 64u); }
         auto issue = [&](const RunRegs &c, const uint32_t half, u32x4 (&P)[4]) {
-            const uint64_t a = bucket_addr(c.h, c.pk >> 31);                                           // aligned to the bucket's size
+            const uint64_t a = tbl + ((uint64_t)c.b << (NL == 2 ? 7 : 6));                              // aligned to the bucket's size
             const uint32_t alo = (uint32_t)a, ahi = (uint32_t)(a >> 32), mine = 16u * (lane & 3u);
             if constexpr (NLX == 1) { ISSUE_K(0, 0) ISSUE_K(1, 1) ISSUE_K(2, 2) ISSUE_K(3, 3) }
             else if (half == 0u) { ISSUE_K(0, 0) ISSUE_K(1, 2) } else { ISSUE_K(2, 0) ISSUE_K(3, 2) }
@@ -633,7 +648,7 @@ _Pragma("unroll") \
                 uint32_t m, o, A[NA], B[NA];
                 context((rec >> 24) & 63u, rec & 0xFFu, m, A, B);
                 const uint32_t h = canon_hash(m, o);
-                const uint64_t baddr = bucket_addr(h, o ^ (rec >> 31));                 // (the reverse strand's records: the other bucket of the pair)
+                const uint64_t baddr = bucket_addr(h, o ^ (rec >> 31), ext_of(A, B, o));   // (the reverse strand's records: the other bucket of the pair)
                 dsc = *(const __attribute__((address_space(1))) uint64_t *)(baddr + (64u * NL - 8u * EW + 8u * KW));
             }
             return dsc;

@@ -13,7 +13,7 @@ extern "C" {
 #define UTREE_INVALID 0xFFFFFFFFu
 #define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
 #define UTREE_IMG_HEADER_BYTES 4096u
-#define UTREE_IMG_VERSION 12u                    /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region; 10: the vote records carry the file-order index; 11: canonical minimizers, strand-paired buckets; 12: heavy overflow runs start with a position directory */
+#define UTREE_IMG_VERSION 13u                    /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region; 10: the vote records carry the file-order index; 11: canonical minimizers, strand-paired buckets; 12: heavy overflow runs start with a position directory; 13: k = 64: minimizers keep two bases' distance from the k-mer's ends and those four bases split a hash value's pair of buckets (UTREE_MIN_MARGIN, sub-slices) */
 /* How a 16-mer gets its strand-independent rank and address (image version 11, device_common.hpp):
  *   1: the hash of its canonical form, the smaller of the 16-mer and its reverse complement -- three vector instructions per base of a read
  *      on top of the forward walk, but only every other hash value is some canonical 16-mer's: where the table has a pair of buckets per
@@ -22,7 +22,16 @@ extern "C" {
 #ifndef UTREE_CANON_MODE
 #define UTREE_CANON_MODE 1
 #endif
-#define UTREE_REGION_NB_BITS 25                  /* regions[r] = base_r << 25 | nb_r (nb_r <= 2^24)                    */
+#define UTREE_REGION_NB_BITS 25                  /* regions[r] = base_r << 34 | sub_r << 25 | nb_r (nb_r <= 2^24 slots of hash values, each of sub_r <= 256 pairs) */
+#define UTREE_REGION_SUB_BITS 9
+#define UTREE_REGION_BASE_SHIFT (UTREE_REGION_NB_BITS + UTREE_REGION_SUB_BITS)
+/* k = 64 (W = 16): a window's minimizer is chosen among the 16-mers that keep UTREE_MIN_MARGIN bases' distance from both of the window's
+ * ends (positions 2 .. 46: 45 of the 49), so that the two bases on either side of it belong to every k-mer it is the minimizer of -- the same
+ * four bases for all the windows of a run, read in the minimizer's canonical orientation: eight more address bits.  Where the hash range is
+ * so crowded that ONE hash value holds more nodes than a bucket (568 M nodes: 6.5 per value and orientation at the dense end, four entries
+ * per bucket) they split the value's pair of buckets into up to 256 (device_common.hpp: bucket_of; dev_image.c: compute_regions).  k = 32
+ * keeps all its 17 positions: a margin would cost it a quarter more minimizer runs per read. */
+#define UTREE_MIN_MARGIN(W_) ((W_) == 16 ? 2u : 0u)
 #define UTREE_TALLY_CHUNK 8192u                  /* tally entries a wave reserves with one atomic              */
 #define UTREE_CUR_LONG 32                        /* cursors[] index of the long-read counter (own 256-B line)   */
 #define UTREE_CUR_MID 16                         /* ... of the mid-length-read counter                           */
@@ -76,8 +85,9 @@ typedef struct {
     uint64_t total_bytes;
     uint64_t off_vote;               /* 32 bytes per label, rank order (UTREE_F_VOTE_TABLE): see utk_vote_rec                    */
     uint32_t bucket_words, pad0;     /* 8-byte words of a bucket: 8 (64 bytes: the faster kernels) or 16 (a whole 128-byte line: the smaller image) */
-    /* Bucket addressing: region r = top 8 bits of the minimizer hash h (of the canonical 16-mer); regions[r] = base_r << 25 | nb_r and
-     * pair = base_r + (((h & 0xFFFFFF) * nb_r) >> 24) with 2^16 <= nb_r <= 2^24 PAIRS of buckets in the region, bucket = 2 pair + orientation,
+    /* Bucket addressing: region r = top 8 bits of the minimizer hash h (of the canonical 16-mer); regions[r] = base_r << 34 | sub_r << 25 | nb_r and
+     * pair = base_r + (((h & 0xFFFFFF) * nb_r) >> 24) * sub_r + ((e * sub_r) >> 8) with 2^16 <= nb_r <= 2^24 slots in the region, sub_r pairs of
+     * buckets per slot (1 unless nb_r = 2^24 and k = 64; e = the four bases around the minimizer, canonical), bucket = 2 pair + orientation,
      * so a pair spans at most 256 consecutive hash values and the low 8 bits of h go into the record key.  The hash is a MINIMUM of K-15
      * hashes, so nodes crowd towards h = 0: every region gets the number of pairs its expected share of the nodes asks for. */
     uint64_t regions[256];
