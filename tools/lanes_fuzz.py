@@ -25,6 +25,12 @@ def main():
         os.environ["UTREE_FINE_BITS"] = str(int(rng.choice([8, 8, 6, 4, 2, 0])))
         os.environ["UTREE_BUCKET_BYTES"] = str(int(rng.choice([64, 64, 128])))
         os.environ["UTREE_BUCKET_TARGET"] = "%.2f" % float(rng.choice([0, 0, 0.7, 1.5, 3, 6, 12, 30]))     # 0: the default load; small: few overflow runs, large: most buckets overflow
+        # k = 64: several pairs of buckets per slot, picked by the four bases around the minimizer (image version 13; needs UTREE_FINE_BITS=8)
+        ts = str(int(rng.choice([0, 2, 5]))) if W == 16 else "0"
+        if ts != "0":
+            os.environ["UTREE_TEST_SUB"] = ts
+        else:
+            os.environ.pop("UTREE_TEST_SUB", None)
         if rng.random() < 0.25:
             os.environ["UTREE_VOTE_BYTES"] = "1"
         else:
