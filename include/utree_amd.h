@@ -91,7 +91,9 @@ typedef struct utree_dev utree_dev;
 #define UTREE_FINE_AUTO (-1)
 
 /* Bytes of HBM the image needs for `ctr`.  `fine_bits` (0..8) bounds the width of a bucket from below, 2^(8-fine_bits)
- * hash values: UTREE_FINE_AUTO = 8 unless the table would exceed UTREE_TABLE_MAX_GB (then the largest value that fits). */
+ * hash values: UTREE_FINE_AUTO = 8 unless the table would exceed UTREE_TABLE_MAX_GB (default 96; then the largest value that
+ * fits).  k = 64 at fine_bits 8: where one hash value still holds more nodes than a bucket its slot is several pairs of buckets
+ *  as long as the table stays within the same cap -- 47 GiB for 568 M 64-mers (8.5 GB on disk). */
 size_t utree_dev_image_bytes(const utree_ctr *ctr, int fine_bits);
 /* Stream the node dump (from the .ctr file or the host copy given to utree_ctr_from_memory) to `device`
  * and build the image there. */
