@@ -367,3 +367,32 @@ def test_image_size_follows_the_region_model(monkeypatch):
     sizes = [image_gib(8, n) for n in (100_000_000, 300_000_000, 600_000_000, 1_217_000_000)]
     assert sizes == sorted(sizes)
     assert 8.0 < image_gib(4, 1000) < 8.3 and 8.0 < image_gib(4, 3_000_000_000) < 8.0 + 3 * 8 * 3.1   # PACKSIZE=16: 2^32 ranks + the records while building
+
+
+def test_k64_sub_slices_in_the_size_model(monkeypatch):
+    """Image version 13, k = 64: where one hash value holds more nodes than a bucket, its slot is several pairs of buckets (dev_image.c:
+    compute_regions) -- as long as the table stays within UTREE_TABLE_MAX_GB; beyond the cap the slots stay single pairs, and only then is
+    the table coarsened.  BASELINE's configs[4] (568 M 64-mers): 21 GiB more table with the sub-slices; none at a tenth of the size,
+    where no hash value is that crowded."""
+    L = lib.load()
+    bins = np.zeros((1 << 24) + 1, dtype=np.uint64)
+
+    def image_gib(n):
+        bins[-1] = n
+        db = CtrDB.from_memory(16, 2, n, bins, None, b"k__A;p__B\t1\n")
+        g = L.utree_dev_image_bytes(db._h, lib.FINE_AUTO) / 2.0**30
+        db.close()
+        return g
+    for v in ("UTREE_BUCKET_BYTES", "UTREE_LUMP_SLACK", "UTREE_SUB_SLICES", "UTREE_TABLE_MAX_GB", "UTREE_TEST_SUB"):
+        monkeypatch.delenv(v, raising=False)
+    with_sub = image_gib(568_000_000)
+    monkeypatch.setenv("UTREE_SUB_SLICES", "0")
+    without = image_gib(568_000_000)
+    assert 19 < with_sub - without < 23                    # table 47.1 against 26.6 GiB
+    small_without = image_gib(56_000_000)
+    monkeypatch.delenv("UTREE_SUB_SLICES")
+    assert image_gib(56_000_000) == small_without
+    monkeypatch.setenv("UTREE_TABLE_MAX_GB", "40")         # the sub-sliced table (47 GiB) is over the cap, the plain one is not
+    assert image_gib(568_000_000) == without
+    monkeypatch.setenv("UTREE_TABLE_MAX_GB", "20")         # ... and now the plain one is too: coarser slots
+    assert image_gib(568_000_000) < without - 4
