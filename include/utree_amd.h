@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UTREE_ABI_VERSION 3
+#define UTREE_ABI_VERSION 4
 
 enum {
     UTREE_OK = 0,
@@ -130,6 +130,10 @@ typedef struct {
     uint32_t strand_views;      /* 1: the image stores every k-mer under its mirrored minimizer view too (where that differs), so a
                                    search with RC finds a window and its reverse complement in ONE pass over the read: both are
                                    in the two buckets of one pair                     */
+    uint32_t overflow_chains;   /* 1: heavy overflow runs (one minimizer's k-mers in many related genomes) are stored as chains of
+                                   consecutive k-mers (k = 32); 0 with UTREE_OVF_CHAINS=0 at build time  (ABI 4) */
+    uint32_t pad0;
+    uint64_t overflow_bytes;    /* bytes of the image's overflow area                                         (ABI 4) */
 } utree_dev_info;
 int utree_dev_get_info(const utree_dev *dev, utree_dev_info *info);
 

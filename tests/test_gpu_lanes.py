@@ -184,6 +184,74 @@ def genome_db(tmp_path, rng, n_contigs=12, contig=6000):
     return ctr, contigs
 
 
+def related_db(tmp_path, rng, label_bytes, roots=3, length=3000, relatives=40):
+    """Every 32-mer of `relatives` mutated copies (3 % substitutions, every fifth 10 %) of a few random roots: the k-mers of the copies
+    crowd around each minimizer -- hundreds of records of one hash value, a HEAVY overflow run."""
+    seqs, kmers, labs = [], {}, []
+    for r in range(roots):
+        root = rng.integers(0, 4, length)
+        for c in range(relatives):
+            s = root.copy()
+            mut = rng.random(length) < (0.10 if c % 5 == 4 else 0.03)
+            s[mut] = rng.integers(0, 4, int(mut.sum()))
+            seqs.append("".join("ACGT"[int(x)] for x in s))
+            labs.append("k__B;p__P%d;c__C%d;o__O%d" % (r, c % 4, r * relatives + c))
+    for ci, s in enumerate(seqs):
+        for i in range(len(s) - 31):
+            kmers.setdefault(s[i:i + 32], ci)
+    ks = sorted(kmers)
+    hi, lo = ctrfile.encode_kmers(ks)
+    ix = np.array([kmers[x] for x in ks], dtype=np.uint32)
+    order = np.lexsort((lo, hi))
+    ctr = str(tmp_path / ("related%d.ctr" % label_bytes))
+    ctrfile.write_ctr(ctr, 8, label_bytes, hi[order], lo[order], ix[order], labs)
+    return ctr, seqs
+
+
+@pytest.mark.parametrize("label_bytes", [2, 4])
+def test_heavy_overflow_runs_as_chains(torch_cuda, tmp_path, monkeypatch, label_bytes):
+    """k = 32, opt-in UTREE_OVF_CHAINS=1: a heavy run is stored as chains of consecutive k-mers (image flag UTREE_F_OVF_CHAINS, device_common.hpp).
+    Reads cut from related genomes (1 % errors, some reverse-complemented) and random reads, both strand modes, through the lane pass and through
+    the wave-per-read kernels, against the oracle; the default image (records behind a position directory) gives the same bytes."""
+    rng = np.random.default_rng(23 + label_bytes)
+    ctr, seqs = related_db(tmp_path, rng, label_bytes)
+    db = CtrDB.open(ctr)
+    o = orc.OracleDB.load(ctr)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    reads = []
+    for i in range(6000):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        p = int(rng.integers(0, len(s) - 150))
+        r = list(s[p:p + 150])
+        for x in np.nonzero(rng.random(150) < 0.01)[0]:
+            r[int(x)] = "ACGT"[int(rng.integers(0, 4))]
+        r = "".join(r)
+        if i % 4 == 0:
+            r = "".join(comp[c] for c in reversed(r))
+        reads.append(("h%d" % i, r))
+    data = fasta_bytes(reads + [("sparse%d" % i, "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 150))) for i in range(500)])
+    want = {rc: oracle_text(o, data, tmp_path, rc=rc) for rc in (False, True)}
+    assert want[False].count(b"\n") > 4000                                           # the reads do hit
+    monkeypatch.setenv("UTREE_OVF_CHAINS", "1")
+    tree = DeviceTree.upload(db, 0)
+    assert tree.info.overflow_chains == 1, "the image carries no chains"
+    n_ovf = tree.info.overflow_bytes
+    for lane_pass in ("1", "0"):
+        monkeypatch.setenv("UTREE_LANE_PASS", lane_pass)
+        for rc in (False, True):
+            got = classify_fasta_bytes(db, tree, data, rc=rc)
+            assert tree.kernel_name().startswith("classify_lanes_" if lane_pass == "1" else "classify_short_k"), tree.kernel_name()
+            assert got == want[rc], (lane_pass, rc)
+    tree.close()
+    monkeypatch.delenv("UTREE_OVF_CHAINS")
+    tree = DeviceTree.upload(db, 0)
+    assert tree.info.overflow_chains == 0 and tree.info.overflow_bytes > n_ovf                   # records take more room than chains
+    monkeypatch.setenv("UTREE_LANE_PASS", "1")
+    for rc in (False, True):
+        assert classify_fasta_bytes(db, tree, data, rc=rc) == want[rc]
+    tree.close()
+
+
 def test_hit_dense_reads_and_reads_with_more_labels_than_the_tally_table(torch_cuda, tmp_path, monkeypatch):
     """Reads cut from the database's own contigs hit in every window (119 hits, buckets that overflow): tallied in the kernel.  Reads
     pieced together from 60 contigs carry more distinct labels than a read's tally table has slots (48): those are left to the

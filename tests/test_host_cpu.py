@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), "libutree_amd.so does not export %s" % name
         assert name in lib.SYMBOLS, "python binding lacks %s" % name
-    assert L.utree_abi_version() == 3
+    assert L.utree_abi_version() == 4
     assert L.utree_strerror(lib.E_FORMAT) == b"Tree malformatted."
 
 

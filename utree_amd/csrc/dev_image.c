@@ -496,7 +496,9 @@ static int build_finish(builder *b, const void *d_binix_raw) {
         {
             uint64_t kept = 0;
             const utree_image_header o = d->hdr;
-            KCHK(utk_compact_overflow(o.W, o.I, (uint64_t *)(img + o.off_table), o.n_slots, o.bucket_words, (uint64_t *)(img + o.off_mrecs), &kept, st));
+            int chains = 0;
+            KCHK(utk_compact_overflow(o.W, o.I, (uint64_t *)(img + o.off_table), o.n_slots, o.bucket_words, (uint64_t *)(img + o.off_mrecs), &kept, &chains, st));
+            if (chains) d->hdr.flags |= UTREE_F_OVF_CHAINS;
             KCHK(utk_fill_recs_pad((uint64_t *)(img + o.off_mrecs) + kept * o.rec_words, 8 * o.rec_words, st));
             utree_image_header *h = &d->hdr;
             const uint64_t coarse_b = (uint64_t)UTREE_NUMBINS * ((o.flags & UTREE_F_OFF64) ? 8 : 4), irreg_b = (1u << 24) / 8;
@@ -706,6 +708,9 @@ int utree_dev_get_info(const utree_dev *d, utree_dev_info *info) {
     info->bucket_bytes = 8u * d->hdr.bucket_words;
     info->strand_views = (d->hdr.flags & UTREE_F_STRAND_VIEWS) ? 1u : 0u;
     if (d->hdr.flags & UTREE_F_DIRECT) info->bucket_bytes = 0;
+    info->overflow_chains = (d->hdr.flags & UTREE_F_OVF_CHAINS) ? 1u : 0u;
+    info->pad0 = 0;
+    info->overflow_bytes = (d->hdr.flags & UTREE_F_DIRECT) ? 0 : d->hdr.n_min * d->hdr.rec_words * 8;
     return UTREE_OK;
 }
 

@@ -289,16 +289,26 @@ template <int W> __device__ __forceinline__ void min_split(uint64_t khi, uint64_
 // tags -- and, in its low six bits, the shift 2 * position that brings a window's outer bases under the entry's rest: the lane-per-read
 // pass, lanes_kernel.hip, checks an entry with five instructions.)
 constexpr uint64_t MFLAG_EMPTY = 1ull << 62, MFLAG_RUN = 2ull << 62;
-// An overflow descriptor is {flag 2 | count22 | directory1 | start39}.  A HEAVY run -- more than OVF_DIR_MIN records, all of one hash value: the k-mers
-// of many related genomes around one minimizer -- starts with a DIRECTORY: K-16+2 16-bit offsets, [p] = the run's first record whose minimizer position is
-// >= p ([K-15] = count), in OVF_DIR_SLOTS record slots in front of the records.  A window's record can only be among those of the window's own position,
-// so a search starts in a range of count / (K-15) records instead of the whole run: three probes of one line where seven dependent trips were
+// An overflow descriptor is {flag 2 | count22 | heavy1 | start39}.  A HEAVY run -- more than OVF_DIR_MIN records, all of one hash value: the k-mers
+// of many related genomes around one minimizer -- is stored in one of two ways:
+// * k = 64 (and k = 32 with UTREE_OVF_CHAINS=0): a DIRECTORY in front of the records: K-16+2 16-bit offsets, [p] = the run's first record whose minimizer
+//   position is >= p ([K-15] = count), in OVF_DIR_SLOTS record slots.  A window's record can only be among those of the window's own position,
+//   so a search starts in a range of count / (K-15) records instead of the whole run.
+// * k = 32 (image flag UTREE_F_OVF_CHAINS): as CHAINS.  The k-mers around one occurrence of the minimizer in a genome -- positions 16 down to 0 as the
+//   k-mer slides to the right -- are windows of ONE 48-base stretch, and related genomes share most of it: a chain is a maximal sequence of records at
+//   consecutive positions p0 .. p1 each of which overlaps the next in 31 bases (image_build.hip: ChainRun links them), so it is described by the 16 bases
+//   in front of the minimizer (A, those the records know, the rest 0) and the 16 behind it (B): record p of the chain has rest (A:B) >> 2p.  The run is
+//   {A:B}{p0 8 | p1 8 | 0 16 | index of the chain's first rank 32} per chain (count22 = chains), then one rank per record, chain after chain.  A window
+//   (position p, rest r) is in the database iff some chain has p0 <= p <= p1 and (uint32)((A:B) >> 2p) == r -- every record is in exactly one chain --, and
+//   then its rank is ranks[first + p - p0]: 16 bytes per chain and 2 (4) per k-mer instead of 8 (16) per k-mer, and a search is one pass over a dozen
+//   chains plus one load instead of a directory trip and a bisection.
 // (image_build.hip: ovf_count_k, ovf_move_k; lanes_core.hpp, wave_common.hpp: the searches).
 constexpr uint64_t M39 = (1ull << 39) - 1, OVF_HAS_DIR = 1ull << 39;
 constexpr uint32_t OVF_DIR_MIN = 32;
 template <int W, int I> struct OvfDir { static constexpr uint32_t SLOTS = (2u * (4u * W - 16u + 2u) + 8u * RecTraits<W, I>::EW - 1u) / (8u * RecTraits<W, I>::EW); };
 // start of the records and count of the run a descriptor names
 __host__ __device__ __forceinline__ uint64_t ovf_count(uint64_t d) { return (d >> 40) & 0x3FFFFFull; }
+// (directory format)
 template <int W, int I> __host__ __device__ __forceinline__ uint64_t ovf_first(uint64_t d) { return (d & M39) + ((d & OVF_HAS_DIR) ? OvfDir<W, I>::SLOTS : 0u); }
 // minimizer position of a MIN record
 template <int W, int I> __device__ __forceinline__ uint32_t mrec_pos(const uint64_t *rec) {
@@ -306,6 +316,19 @@ template <int W, int I> __device__ __forceinline__ uint32_t mrec_pos(const uint6
 }
 template <int W, int I> __device__ __forceinline__ uint32_t mrec_hlow(const uint64_t *rec) {
     if constexpr (W == 16) return (uint32_t)(rec[1] >> 54) & 0xFFu; else return (uint32_t)(rec[0] >> 54) & 0xFFu;
+}
+// A window (minimizer position pos, outer bases rest) against chain {w0, w1}: the index of its rank, or ~0
+__device__ __forceinline__ uint32_t chain_hit(uint64_t w0, uint64_t w1, uint32_t pos, uint32_t rest) {
+    const uint32_t p0 = (uint32_t)(w1 >> 56), p1 = (uint32_t)(w1 >> 48) & 0xFFu;
+    return (pos - p0 <= p1 - p0 && (uint32_t)(w0 >> (2u * pos)) == rest) ? (uint32_t)w1 + (pos - p0) : ~0u;
+}
+// ... against a run of n chains at `run` (one lane, one chain after the other: the wave-per-read kernels)
+template <int I> __device__ __forceinline__ uint32_t chain_find(const uint64_t *run, uint32_t n, uint32_t pos, uint32_t rest) {
+    uint32_t at = ~0u;
+    for (uint32_t c = 0; c < n && at == ~0u; ++c) at = chain_hit(run[2u * c], run[2u * c + 1u], pos, rest);
+    if (at == ~0u) return INVALID;
+    if constexpr (I == 2) { const uint32_t r = ((const uint16_t *)(run + 2u * n))[at]; return r == 0xFFFFu ? INVALID : r; }
+    else return ((const uint32_t *)(run + 2u * n))[at];
 }
 constexpr uint64_t M46 = (1ull << 46) - 1;
 

@@ -223,28 +223,87 @@ __global__ void flag_saturated_k(const uint64_t *__restrict__ Bs, const IDX *__r
     }
 }
 
+// ---- chains (k = 32; device_common.hpp: OvfChain) ----
+// A heavy run's records ascend by (position, rest).  The k-mer of position p holds the p bases in front of the minimizer and the 16 - p behind it;
+// the k-mer one base to the LEFT on the same sequence has position p + 1: one more base in front, one fewer behind.  Record j at p - 1 and record
+// i at p can follow each other iff rest_j >> 2 == rest_i & 0x3FFFFFFF (the 15 bases they share).  All the records at p - 1 with one such value (up
+// to four, consecutive) fit all the records at p with it (up to four, one per leading base): the t-th of the former is linked to the t-th of the
+// latter.  Every record has at most one link each way, so the links cut the run into chains, each the k-mers of one stretch of sequence.
+struct ChainRun {
+    const uint64_t *r;           // the run's records (one word each: W = 8; the rank of u32 labels in a second word)
+    uint32_t ew, n;
+    uint32_t g[18];              // [p] = first record of position >= p; [17] = n
+    __device__ __forceinline__ uint32_t rest(uint32_t i) const { return (uint32_t)r[(uint64_t)i * ew]; }
+    __device__ __forceinline__ uint32_t pos(uint32_t i) const { return (uint32_t)(r[(uint64_t)i * ew] >> 49) & 31u; }
+    __device__ uint32_t lb(uint32_t p, uint32_t v) const {              // first record of position p with rest >= v (g[p + 1]: none)
+        uint32_t lo = g[p], hi = g[p + 1];
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rest(mid) < v) lo = mid + 1; else hi = mid; }
+        return lo;
+    }
+    __device__ void init(const uint64_t *recs, uint32_t ew_, uint32_t n_) {
+        r = recs; ew = ew_; n = n_;
+        uint32_t p = 0;
+        for (uint32_t q = 0; q < n; ++q) { const uint32_t pq = pos(q); while (p <= pq && p < 18u) g[p++] = q; }
+        while (p < 18u) g[p++] = n;
+    }
+    // the record i (position p >= 1) follows, or ~0
+    __device__ uint32_t pred(uint32_t i, uint32_t p) const {
+        if (p == 0u) return ~0u;
+        const uint32_t ri = rest(i), low30 = ri & 0x3FFFFFFFu, x = ri >> 30;
+        uint32_t t = 0;                                                  // records at p with the same 15 bases and a smaller leading base
+        for (uint32_t y = 0; y < x; ++y) { const uint32_t v = (y << 30) | low30, a = lb(p, v); t += (a < g[p + 1] && rest(a) == v) ? 1u : 0u; }
+        const uint32_t a = lb(p - 1u, low30 << 2);
+        return (a + t < g[p] && (rest(a + t) >> 2) == low30) ? a + t : ~0u;
+    }
+    // the record that follows j (position p <= 15), or ~0
+    __device__ uint32_t succ(uint32_t j, uint32_t p) const {
+        if (p >= 16u) return ~0u;
+        const uint32_t low30 = rest(j) >> 2;
+        uint32_t t = j - lb(p, low30 << 2);
+        for (uint32_t y = 0; y < 4u; ++y) {
+            const uint32_t v = (y << 30) | low30, a = lb(p + 1u, v);
+            if (a < g[p + 2u] && rest(a) == v) { if (t == 0u) return a; --t; }
+        }
+        return ~0u;
+    }
+};
+// 8-byte words of a run written as chains: 2 per chain + the ranks
+__host__ __device__ __forceinline__ uint32_t chain_words(uint32_t n_chains, uint32_t n_rec, uint32_t label_bytes) { return 2u * n_chains + (n_rec * label_bytes + 7u) / 8u; }
+
 // After the table is built only the overflow runs of the MIN array are ever read again (records that sit inline in a bucket
 // are found there).  ovf_count_k / ovf_move_k keep those runs alone, packed in bucket order, and point the descriptors at
 // their new places: the sorted array of ALL nodes (8-32 bytes per node) leaves the image.
+// cnt[b] = record slots of bucket b's run in the packed area; bit 31: the run is heavy (directory or chains in front / instead)
 template <int W, int I>
-__global__ void ovf_count_k(const uint64_t *__restrict__ table, uint64_t n_buckets, uint32_t bw, const uint64_t *__restrict__ mrecs, int dir_on, uint32_t *__restrict__ cnt) {
+__global__ void ovf_count_k(const uint64_t *__restrict__ table, uint64_t n_buckets, uint32_t bw, const uint64_t *__restrict__ mrecs, int dir_on, int chains_on, uint32_t *__restrict__ cnt) {
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
     const int CAP = (int)bw / EW;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t d = table[b * bw + (uint64_t)(CAP - 1) * EW + KW];
         uint32_t c = (d >> 62) == 2 ? (uint32_t)((d >> 40) & 0x3FFFFFull) : 0u;
         if (c == 0x3FFFFFu) c = 0;           // a saturated run is never followed (its nodes' bins take the exact-probe path): nothing to keep
-        // a heavy run of ONE hash value (sorted by key: the first and the last record tell) gets a position directory in front (device_common.hpp)
-        if (c > OVF_DIR_MIN && c <= 0xFFFFu && dir_on) {
+        // a heavy run of ONE hash value (sorted by key: the first and the last record tell) gets a position directory in front (device_common.hpp),
+        // or becomes a list of chains
+        if (c > OVF_DIR_MIN && c <= 0xFFFFu && (dir_on || chains_on)) {
             const uint64_t src = d & M39;
-            if (mrec_hlow<W, I>(mrecs + src * EW) == mrec_hlow<W, I>(mrecs + (src + c - 1) * EW)) c += OvfDir<W, I>::SLOTS | 0x80000000u;
+            if (mrec_hlow<W, I>(mrecs + src * EW) == mrec_hlow<W, I>(mrecs + (src + c - 1) * EW)) {
+                if constexpr (W == 8) {
+                    if (chains_on) {
+                        ChainRun cr;
+                        cr.init(mrecs + src * EW, EW, c);
+                        uint32_t heads = 0;
+                        for (uint32_t i = 0; i < c; ++i) heads += cr.pred(i, cr.pos(i)) == ~0u ? 1u : 0u;
+                        c = ((chain_words(heads, c, I) + EW - 1u) / EW) | 0x80000000u;
+                    } else c += OvfDir<W, I>::SLOTS | 0x80000000u;
+                } else c += OvfDir<W, I>::SLOTS | 0x80000000u;
+            }
         }
         cnt[b] = c;
     }
 }
 template <int W, int I>
 __global__ void ovf_move_k(uint64_t *__restrict__ table, uint64_t n_buckets, uint32_t bw, const uint32_t *__restrict__ cnt,
-                           const uint64_t *__restrict__ prefix, const uint64_t *__restrict__ mrecs, uint64_t *__restrict__ packed) {
+                           const uint64_t *__restrict__ prefix, const uint64_t *__restrict__ mrecs, int chains_on, uint64_t *__restrict__ packed) {
     constexpr int EW = RecTraits<W, I>::EW, KW = RecTraits<W, I>::KW;
     const int CAP = (int)bw / EW;
     for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_buckets; b += (uint64_t)gridDim.x * blockDim.x) {
@@ -257,6 +316,43 @@ __global__ void ovf_move_k(uint64_t *__restrict__ table, uint64_t n_buckets, uin
             continue;
         }
         const uint64_t d = *dp, src = d & M39, dst = prefix[b];
+        if constexpr (W == 8) {
+            if (dir && chains_on) {
+                // [2 words per chain: {16 bases in front of the minimizer : 16 behind it}, {first position 8 | last position 8 | 0 | index of the first rank 32}]
+                // [one rank per record, chain after chain, each in position order]
+                const uint32_t n = (uint32_t)ovf_count(d);
+                ChainRun cr;
+                cr.init(mrecs + src * EW, EW, n);
+                uint64_t *out = packed + dst * EW;
+                uint32_t heads = 0;
+                for (uint32_t i = 0; i < n; ++i) heads += cr.pred(i, cr.pos(i)) == ~0u ? 1u : 0u;
+                for (uint32_t x = 0; x < c * EW; ++x) out[x] = 0;
+                uint16_t *r16 = (uint16_t *)(out + 2u * heads);
+                uint32_t *r32 = (uint32_t *)(out + 2u * heads);
+                uint32_t ch = 0, at = 0;
+                for (uint32_t i = 0; i < n; ++i) {
+                    const uint32_t p0 = cr.pos(i);
+                    if (cr.pred(i, p0) != ~0u) continue;
+                    uint32_t cur = i, p = p0;
+                    const uint32_t first = at;
+                    for (;;) {
+                        const uint64_t *rec = mrecs + (src + cur) * EW;
+                        if constexpr (I == 2) r16[at] = (uint16_t)(rec[0] >> 32); else r32[at] = (uint32_t)rec[1];
+                        ++at;
+                        const uint32_t nx = cr.succ(cur, p);
+                        if (nx == ~0u) break;
+                        cur = nx; ++p;
+                    }
+                    const uint32_t rl = cr.rest(cur), rf = cr.rest(i);
+                    const uint64_t A = p ? (uint64_t)(rl >> (32u - 2u * p)) : 0ull, B = p0 < 16u ? (uint64_t)(uint32_t)(rf << (2u * p0)) : 0ull;
+                    out[2u * ch] = (A << 32) | B;
+                    out[2u * ch + 1u] = ((uint64_t)p0 << 56) | ((uint64_t)p << 48) | first;
+                    ++ch;
+                }
+                *dp = (d & ~(M39 | OVF_HAS_DIR | (0x3FFFFFull << 40))) | ((uint64_t)heads << 40) | (dst & M39) | OVF_HAS_DIR;
+                continue;
+            }
+        }
         const uint32_t hs = dir ? OvfDir<W, I>::SLOTS : 0u, nrec = c - hs;
         if (dir) {
             // [p] = records of the run with a minimizer position below p (they ascend by position: the hash bits in front of it are one value's)
@@ -625,7 +721,7 @@ int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream) {
 
 struct widen32 { __device__ uint64_t operator()(uint32_t v) const { return v & 0x7FFFFFFFu; } };   // (bit 31 of a count: the run gets a directory)
 /* Pack the overflow runs to the front of d_mrecs (bucket order) and repoint the buckets' descriptors; *n_kept = records kept. */
-int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n_buckets, uint32_t bw, uint64_t *d_mrecs, uint64_t *n_kept, void *stream) {
+int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n_buckets, uint32_t bw, uint64_t *d_mrecs, uint64_t *n_kept, int *chains, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     uint32_t *cnt = nullptr;
     uint64_t *prefix = nullptr, *packed = nullptr;
@@ -635,14 +731,19 @@ int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n
     const uint32_t EW = utree_rec_words(W_, I_);
     const char *de = getenv("UTREE_OVF_DIR");                            /* =0: no position directories (A/B) */
     const int dir_on = !(de && atoi(de) == 0);
+    const char *ce = getenv("UTREE_OVF_CHAINS");                         /* =1: k = 32: heavy runs as chains (device_common.hpp) instead of records behind a directory.
+                                                                            Opt-in: a third of the bytes, parity-tested, and 25 % SLOWER on related genomes with a lane per window
+                                                                            walking the chains */
+    const int chains_on = W_ == 8 && dir_on && ce && atoi(ce) == 1;
     *n_kept = 0;
+    *chains = chains_on;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = (int)e_; goto done; } } while (0)
     CK(hipMalloc((void **)&cnt, (n_buckets + 1) * 4));
     CK(hipMalloc((void **)&prefix, (n_buckets + 1) * 8));
     CK(hipMemsetAsync(cnt + n_buckets, 0, 4, st));
     {
         int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
-            ovf_count_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(n_buckets) > 65536 ? 65536 : grid_for(n_buckets)), dim3(256), 0, st>>>(d_table, n_buckets, bw, d_mrecs, dir_on, cnt);
+            ovf_count_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(n_buckets) > 65536 ? 65536 : grid_for(n_buckets)), dim3(256), 0, st>>>(d_table, n_buckets, bw, d_mrecs, dir_on, chains_on, cnt);
         });
         if (drc) { rc = drc; goto done; }
     }
@@ -659,7 +760,7 @@ int utk_compact_overflow(uint32_t W_, uint32_t I_, uint64_t *d_table, uint64_t n
             CK(hipMalloc((void **)&packed, (size_t)total * EW * 8));
             int drc = dispatch_wi(W_, I_, [&](auto w, auto i) {
                 ovf_move_k<decltype(w)::value, decltype(i)::value><<<dim3(grid_for(n_buckets) > 65536 ? 65536 : grid_for(n_buckets)), dim3(256), 0, st>>>(
-                    d_table, n_buckets, bw, cnt, prefix, d_mrecs, packed);
+                    d_table, n_buckets, bw, cnt, prefix, d_mrecs, chains_on, packed);
             });
             if (drc) { rc = drc; goto done; }
             CK(hipMemcpyAsync(d_mrecs, packed, (size_t)total * EW * 8, hipMemcpyDeviceToDevice, st));

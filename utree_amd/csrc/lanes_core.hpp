@@ -640,6 +640,7 @@ _Pragma("unroll") \
         // same-box 16 is 3.5 % faster and 64 or more 12-20 % slower; UTREE_OVF_SCAN overrides)
         constexpr uint32_t OVF_WAYS = UTREE_LANES_OVF_WAYS;
         const uint32_t OVF_SCAN = im.ovf_scan;
+        const bool OVF_CHAINS = W == 8 && (im.flags & UTREE_F_OVF_CHAINS) != 0u;      // heavy runs are lists of chains (device_common.hpp)
         // the descriptor of overflowing run i: the key word of its bucket's last entry (a line phase B has fetched: an L2 hit mostly)
         auto fetch_desc = [&](uint32_t i) -> uint64_t {
             uint64_t dsc = 0;
@@ -670,7 +671,8 @@ _Pragma("unroll") \
                 const uint32_t rec = runs[i];
                 const uint64_t n = ovf_count(dsc);
                 ost[lane] = dsc;
-                if (n <= OVF_SCAN) nrec = (uint32_t)n; else wn = ((rec >> 16) & 0xFFu) - ((rec >> 8) & 0xFFu);
+                // (a heavy run stored as chains counts its chains: searched per window whatever their number)
+                if (n <= OVF_SCAN && !(OVF_CHAINS && (dsc & OVF_HAS_DIR))) nrec = (uint32_t)n; else wn = ((rec >> 16) & 0xFFu) - ((rec >> 8) & 0xFFu);
             }
             // (t-th unit of work -> item: inclusive prefix sums in LDS, first item whose sum exceeds t)
             auto spread = [&](uint32_t mine) -> uint32_t {
@@ -749,11 +751,14 @@ _Pragma("unroll") for (uint32_t x = 0; x < NA; ++x) { A[x] = RA[x]; B[x] = RB[x]
                 MinKey<W> mk[OVF_WAYS];
                 uint32_t qs[OVF_WAYS];
                 const uint16_t *dirp[OVF_WAYS];                                    // where a heavy run's directory says which of its records have the window's position
+                const uint64_t *chp[OVF_WAYS];                                     // a heavy run stored as chains: the run, its chains, where the window's rank is
+                uint32_t chn[OVF_WAYS], chat[OVF_WAYS];
 #pragma unroll
                 for (uint32_t u = 0; u < OVF_WAYS; ++u) {
                     const uint32_t t = t0 + 64u * u + lane;
                     lo[u] = hi[u] = 0; qs[u] = 0; mk[u].lo = mk[u].hi = 0;
                     dirp[u] = nullptr;
+                    chp[u] = im.mrecs; chn[u] = 0; chat[u] = ~0u;
                     if (t < total_win) {
                         uint32_t j;
                         const uint32_t it_ = item_of(t, j);
@@ -770,7 +775,8 @@ _Pragma("unroll") for (uint32_t x = 0; x < NA; ++x) { A[x] = RA[x]; B[x] = RB[x]
                         const uint32_t hlow = h & 0xFFu;
                         const uint64_t dsc = ost[it_];
                         lo[u] = ovf_first<W, I>(dsc); hi[u] = lo[u] + ovf_count(dsc); qs[u] = q;
-                        if (dsc & OVF_HAS_DIR) dirp[u] = (const uint16_t *)(im.mrecs + (dsc & M39) * EW) + pos;
+                        if (OVF_CHAINS && (dsc & OVF_HAS_DIR)) { chp[u] = im.mrecs + (dsc & M39) * EW; chn[u] = (uint32_t)ovf_count(dsc); hi[u] = lo[u]; }
+                        else if (dsc & OVF_HAS_DIR) dirp[u] = (const uint16_t *)(im.mrecs + (dsc & M39) * EW) + pos;
                         if constexpr (W == 8) {
                             const uint32_t rest = (uint32_t)((((uint64_t)A[0] << 32) | B[0]) >> (2u * pos));
                             mk[u].hi = 0; mk[u].lo = ((uint64_t)((hlow << 5) | pos) << 32) | rest;
@@ -779,6 +785,44 @@ _Pragma("unroll") for (uint32_t x = 0; x < NA; ++x) { A[x] = RA[x]; B[x] = RB[x]
                             rest96(A, B, pos, r0, r1, r2);
                             mk[u].lo = ((uint64_t)r1 << 32) | r2; mk[u].hi = ((uint64_t)hlow << 38) | ((uint64_t)pos << 32) | r0;
                         }
+                    }
+                }
+                // a heavy run stored as chains: every search of the round walks its run's chains in step, two chains a turn (16 bytes each; the windows of one
+                // run read the same addresses), then one load fetches the rank
+                if constexpr (W == 8) {
+                    bool anych = false;
+#pragma unroll
+                    for (uint32_t u = 0; u < OVF_WAYS; ++u) anych = anych || chn[u] != 0u;
+                    if (OVF_CHAINS && ballot64(anych)) {
+                        for (uint32_t c = 0;; c += 2) {
+                            bool more = false;
+#pragma unroll
+                            for (uint32_t u = 0; u < OVF_WAYS; ++u) more = more || (c < chn[u] && chat[u] == ~0u);
+                            if (!ballot64(more)) break;
+                            uint64_t h0[OVF_WAYS][2], h1[OVF_WAYS][2];
+#pragma unroll
+                            for (uint32_t u = 0; u < OVF_WAYS; ++u) {
+                                const uint32_t c0 = c < chn[u] ? c : 0u, c1 = c + 1u < chn[u] ? c + 1u : 0u;     // (beyond the run's chains: its first again, or the image's first bytes)
+                                h0[u][0] = chp[u][2u * c0]; h0[u][1] = chp[u][2u * c0 + 1u];
+                                h1[u][0] = chp[u][2u * c1]; h1[u][1] = chp[u][2u * c1 + 1u];
+                            }
+#pragma unroll
+                            for (uint32_t u = 0; u < OVF_WAYS; ++u) {
+                                const uint32_t pos = (uint32_t)(mk[u].lo >> 32) & 31u, rest = (uint32_t)mk[u].lo;
+                                const uint32_t a0 = chain_hit(h0[u][0], h0[u][1], pos, rest), a1 = chain_hit(h1[u][0], h1[u][1], pos, rest);
+                                if (c < chn[u] && chat[u] == ~0u) chat[u] = a0;
+                                if (c + 1u < chn[u] && chat[u] == ~0u) chat[u] = a1;
+                            }
+                        }
+                        uint32_t rk[OVF_WAYS];
+#pragma unroll
+                        for (uint32_t u = 0; u < OVF_WAYS; ++u) {
+                            const uint32_t at = chat[u] == ~0u ? 0u : chat[u];
+                            if constexpr (I == 2) rk[u] = ((const uint16_t *)(chp[u] + 2u * chn[u]))[at]; else rk[u] = ((const uint32_t *)(chp[u] + 2u * chn[u]))[at];
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < OVF_WAYS; ++u)
+                            if (chat[u] != ~0u && (I == 4 ? rk[u] != INVALID : rk[u] != 0xFFFFu)) push(qs[u], rk[u]);
                     }
                 }
                 // a heavy run: its directory narrows the range to the records of the window's own minimizer position (one trip for all the searches of the

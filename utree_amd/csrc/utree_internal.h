@@ -13,7 +13,7 @@ extern "C" {
 #define UTREE_INVALID 0xFFFFFFFFu
 #define UTREE_IMG_MAGIC 0x31474d4945525455ull    /* "UTREIMG1" */
 #define UTREE_IMG_HEADER_BYTES 4096u
-#define UTREE_IMG_VERSION 13u                    /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region; 10: the vote records carry the file-order index; 11: canonical minimizers, strand-paired buckets; 12: heavy overflow runs start with a position directory; 13: k = 64: minimizers keep two bases' distance from the k-mer's ends and those four bases split a hash value's pair of buckets (UTREE_MIN_MARGIN, sub-slices) */
+#define UTREE_IMG_VERSION 14u                    /* 9: buckets of 64 or 128 bytes; any number of buckets per hash region; 10: the vote records carry the file-order index; 11: canonical minimizers, strand-paired buckets; 12: heavy overflow runs start with a position directory; 13: k = 64: minimizers keep two bases' distance from the k-mer's ends and those four bases split a hash value's pair of buckets (UTREE_MIN_MARGIN, sub-slices); 14: k = 32: heavy overflow runs are stored as CHAINS of consecutive k-mers (UTREE_F_OVF_CHAINS) */
 /* How a 16-mer gets its strand-independent rank and address (image version 11, device_common.hpp):
  *   1: the hash of its canonical form, the smaller of the 16-mer and its reverse complement -- three vector instructions per base of a read
  *      on top of the forward walk, but only every other hash value is some canonical 16-mer's: where the table has a pair of buckets per
@@ -69,6 +69,8 @@ extern "C" {
                                     complement is found from the window's own minimizer run, in the other bucket of the pair */
 #define UTREE_F_DIRECT 64u       /* PACKSIZE=16 (W = 4): off_table is a direct-address table, 2^32 ranks of I bytes (all ones: no node), every word's
                                     answer as the reference gives it; no buckets, no records                               */
+#define UTREE_F_OVF_CHAINS 128u  /* k = 32: a heavy overflow run (descriptor bit 39) is a list of CHAINS -- the k-mers that walk one stretch of sequence across the
+                                    minimizer, 16 bytes per chain + one rank per k-mer -- instead of a position directory + records (device_common.hpp) */
 #define UTREE_F_INVALID_RANKS 8u   /* some node's label index is >= the number of labels (itree.c:929: never a hit): wave-per-read kernels only */
 
 /* At offset 0 of the flat device image (position independent: offsets, never pointers). */
@@ -144,7 +146,8 @@ int utk_build_min(uint32_t W, uint32_t I, int off64, const void *d_coarse, const
                   uint32_t *d_irreg, unsigned long long *d_overflow, uint64_t *n_min, int *views, void *stream);
 int utk_build_direct(uint32_t I, int off64, int generic, const void *d_coarse, const uint64_t *d_recs, uint64_t n_nodes, uint64_t c0, uint64_t m,
                      const uint32_t *d_irreg, uint64_t n_irregular, void *d_table, void *stream);
-int utk_compact_overflow(uint32_t W, uint32_t I, uint64_t *d_table, uint64_t n_buckets, uint32_t bucket_words, uint64_t *d_mrecs, uint64_t *n_kept, void *stream);
+/* *chains = 1: heavy runs were written as chains (k = 32 unless UTREE_OVF_CHAINS=0): the image carries UTREE_F_OVF_CHAINS */
+int utk_compact_overflow(uint32_t W, uint32_t I, uint64_t *d_table, uint64_t n_buckets, uint32_t bucket_words, uint64_t *d_mrecs, uint64_t *n_kept, int *chains, void *stream);
 int utk_compress_chunk(uint32_t W, uint32_t I, const void *d_in, uint64_t first, uint64_t count, unsigned long long *d_first,
                        void *d_out, void *stream);
 int utk_fill_recs_pad(uint64_t *d_recs_end, uint32_t words, void *stream);

@@ -134,6 +134,10 @@ __device__ __forceinline__ uint32_t resolve_bucket(const utk_image &im, const Bu
     } else if (im.bucket_words == 16u) last = 0;                                           // (the lower half's last entry is never a descriptor)
     if ((last >> 62) == 2 && rank == INVALID) {                                            // the rest of the bucket's nodes
         uint64_t start = ovf_first<W, I>(last), n = ovf_count(last);
+        if constexpr (W == 8) {
+            if ((last & OVF_HAS_DIR) && (im.flags & UTREE_F_OVF_CHAINS))                  // a heavy run stored as chains
+                return chain_find<I>(im.mrecs + (last & M39) * RecTraits<W, I>::EW, (uint32_t)n, (uint32_t)(mk.lo >> 32) & 31u, (uint32_t)mk.lo);
+        }
         if (last & OVF_HAS_DIR) {                                                         // a heavy run: only the records of the key's own position
             const uint16_t *dir = (const uint16_t *)(im.mrecs + (last & M39) * RecTraits<W, I>::EW);
             const uint32_t pos = W == 16 ? (uint32_t)(mk.hi >> 32) & 63u : (uint32_t)(mk.lo >> 32) & 31u;

@@ -35,7 +35,8 @@ class CtrInfo(C.Structure):
 class DevInfo(C.Structure):
     _fields_ = [("fine_bits", C.c_uint32), ("record_bytes", C.c_uint32), ("image_bytes", C.c_uint64),
                 ("irregular_bins", C.c_uint64), ("generic_mode", C.c_uint32), ("device", C.c_int32),
-                ("vote_table", C.c_uint32), ("lane_pass", C.c_uint32), ("bucket_bytes", C.c_uint32), ("strand_views", C.c_uint32)]
+                ("vote_table", C.c_uint32), ("lane_pass", C.c_uint32), ("bucket_bytes", C.c_uint32), ("strand_views", C.c_uint32),
+                ("overflow_chains", C.c_uint32), ("pad0", C.c_uint32), ("overflow_bytes", C.c_uint64)]
 
 
 class FastaError(C.Structure):
