@@ -31,7 +31,10 @@ extern "C" int CAT(utk_lanes_part_, LANES_W, LANES_I, LANES_NL, LANES_BS)(int se
 #ifndef UTREE_LANES_TIMERS_W
 #define UTREE_LANES_TIMERS_W 8
 #endif
-#if defined(UTREE_LANES_TIMERS) && LANES_W == UTREE_LANES_TIMERS_W && LANES_I == 2 && LANES_NL == 1 && !LANES_BS
+#ifndef UTREE_LANES_TIMERS_BS
+#define UTREE_LANES_TIMERS_BS 0                                 // 1: the both-strands set's counters
+#endif
+#if defined(UTREE_LANES_TIMERS) && LANES_W == UTREE_LANES_TIMERS_W && LANES_I == 2 && LANES_NL == 1 && LANES_BS == UTREE_LANES_TIMERS_BS
 extern "C" {
 void utk_lanes_phase_dump(void) {
     unsigned long long h[8];
