@@ -231,6 +231,23 @@ def test_replicate_rccl_over_all_visible_devices(torch_cuda, tmp_path):
         assert torch.equal(res, want), "replica on device %d differs" % g
 
 
+def test_a_lane_without_buffers_steps_aside(torch_cuda, tmp_path, monkeypatch):
+    """A lane of the file pipeline whose buffers cannot be allocated (pinned host memory, HBM) leaves the chunks to the other lanes; the
+    search fails only when no lane is left.  UTREE_TEST_LANE_NOMEM=1: every lane but the first gets UTREE_E_NOMEM instead of its buffers."""
+    db = CtrDB.open(util.fixture_ctr("toy"))
+    tree = DeviceTree.upload(db, 0)                                 # a fresh handle: no lane has its buffers yet
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    monkeypatch.setenv("UTREE_CHUNK_BYTES", "20000")
+    monkeypatch.setenv("UTREE_TEST_LANE_NOMEM", "1")
+    code, st, got = run(db, [tree], data, tmp_path, rc=True)
+    assert code == lib.OK and st.pipeline == 1 and st.n_lanes >= 2
+    assert got == util.fixture_bytes("toy_out_rc.txt.gz")
+    monkeypatch.delenv("UTREE_TEST_LANE_NOMEM")
+    code, st, got = run(db, [tree], data, tmp_path, rc=True)         # the lanes that stepped aside get their buffers now
+    assert code == lib.OK and got == util.fixture_bytes("toy_out_rc.txt.gz")
+    tree.close()
+
+
 def test_rccl_on_a_communicator_of_one_rank(torch_cuda, tmp_path, monkeypatch):
     """UTREE_RCCL_FORCE=1 (csrc/rccl_replicate.c): with one device / one rank the early returns are skipped, so ncclCommInitAll,
     ncclCommInitRank, the 8-byte size broadcast and the image's ncclBroadcast pieces all execute on this lease's single card --

@@ -191,6 +191,7 @@ struct dpipe {
     uint64_t printed;                           /* progress lines already on stdout (a host re-run must not repeat them) */
     uint64_t n_reads, good, next_progress, bytes_in;
     int rc, stop;                               /* first error; UTREE_RETRY_HOST = input for the host path          */
+    int lanes_alive; lane_t *lane0;             /* lanes that have not given up for want of buffers (lane_main); the test hook's surviving lane */
     /* seq_out: a chunk that needs the host framing does not stop the chunks in front of it -- they are written, in order, and the host
      * pipeline continues from that chunk's first byte (search_dev.h: utree_search_resume); the chunks behind it are dropped */
     int retry_set; uint64_t retry_at; off_t retry_off;
@@ -296,15 +297,29 @@ static void *lane_main(void *arg) {
     if (hipSetDevice(L->dev->device) != hipSuccess) { dfail(P, UTREE_E_HIP); return NULL; }
     for (;;) {
         off_t off = 0; size_t len = 0; int final = 0, part = 0; uint64_t c = 0, cp = 0;      /* c: the chunk's number; cp: its number within its output part */
+        if (!b->stream || b->ws_rc < P->do_rc) {                  /* before this lane's first chunk: its buffers (only if there is a chunk to take) */
+            pthread_mutex_lock(&P->mu);
+            int work = !(P->stop || P->retry_set);
+            if (work) { work = 0; for (int k = 0; k < P->n_parts; ++k) if (P->next_off_part[k] < P->part_end[k]) work = 1; }
+            pthread_mutex_unlock(&P->mu);
+            if (!work) return NULL;
+            int arc = getenv("UTREE_TEST_LANE_NOMEM") && L != P->lane0 ? UTREE_E_NOMEM : lane_alloc(L->dev, b, P->do_rc);
+            if (arc) {
+                /* a lane that cannot get its buffers (~200 MB of pinned host memory, ~1 GB of HBM) steps aside: the other lanes take the chunks.
+                 * Only when no lane is left does the search fail. */
+                pthread_mutex_lock(&P->mu);
+                const int left = --P->lanes_alive;
+                pthread_mutex_unlock(&P->mu);
+                if (getenv("UTREE_DEBUG") || getenv("UTREE_TIMING")) fprintf(stderr, "[utree_amd] device %d: a lane could not allocate its buffers (%s); %d lane(s) left\n", L->dev->device, utree_strerror(arc), left);
+                if (left <= 0) dfail(P, arc);
+                return NULL;
+            }
+        }
         pthread_mutex_lock(&P->mu);
         int got = (P->stop || P->retry_set) ? 0 : take_chunk(P, &off, &len, &final, &c, &part, &cp);
         if (got < 0) dretry(P, P->n_taken, P->next_off, 1);                    /* no record boundary within a chunk's bytes */
         pthread_mutex_unlock(&P->mu);
         if (got <= 0) return NULL;
-        if (!b->stream || b->ws_rc < P->do_rc) {                  /* first chunk of this lane: its buffers */
-            int arc = lane_alloc(L->dev, b, P->do_rc);
-            if (arc) { dfail(P, arc); return NULL; }
-        }
         /* ---- file -> pinned memory (the page-cache copy), a small team ---- */
         double t0 = now_s();
         {
@@ -493,6 +508,7 @@ int utree_search_file_device(const utree_ctr *ctr, utree_dev **devs, int n_dev, 
             lanes[i].P = P; lanes[i].dev = devs[i % n_dev];
             lanes[i].b = &((struct utree_search_ctx *)devs[i % n_dev]->search_ctx)->lane[i / n_dev];
             lanes[i].read_threads = per_lane;
+            if (i == 0) { P->lane0 = &lanes[0]; P->lanes_alive = n_lanes; }
             if (pthread_create(&lanes[i].th, NULL, lane_main, &lanes[i])) { dfail(P, UTREE_E_NOMEM); break; }
             ++started;
         }
