@@ -32,6 +32,8 @@ _TREES = {}
 def tree_for(name, fine_bits=lib.FINE_AUTO):
     key = (name, fine_bits)
     if key not in _TREES:
+        while len(_TREES) >= 6:                         # (handles keep their buffers until closed: the oldest go)
+            _TREES.pop(next(iter(_TREES)))[1].close()
         db = CtrDB.open(util.fixture_ctr(name))
         _TREES[key] = (db, DeviceTree.upload(db, 0, fine_bits))
     return _TREES[key]

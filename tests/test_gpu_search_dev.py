@@ -31,6 +31,8 @@ _TREES = {}
 
 def tree_for(name):
     if name not in _TREES:
+        while len(_TREES) >= 4:                         # (a handle that has searched a file keeps its lanes' buffers, ~14 GB of HBM: the oldest go)
+            _TREES.pop(next(iter(_TREES)))[1].close()
         db = CtrDB.open(util.fixture_ctr(name))
         _TREES[name] = (db, DeviceTree.upload(db, 0))
     return _TREES[name]
@@ -245,6 +247,20 @@ def test_a_lane_without_buffers_steps_aside(torch_cuda, tmp_path, monkeypatch):
     monkeypatch.delenv("UTREE_TEST_LANE_NOMEM")
     code, st, got = run(db, [tree], data, tmp_path, rc=True)         # the lanes that stepped aside get their buffers now
     assert code == lib.OK and got == util.fixture_bytes("toy_out_rc.txt.gz")
+    tree.close()
+
+
+def test_without_pinned_host_memory_the_search_still_runs(torch_cuda, tmp_path, monkeypatch):
+    """Pinned host memory is a resource the users of a machine share: when hipHostMalloc fails a lane takes ordinary memory for its chunk and
+    text buffers (the copies are then staged by the runtime).  UTREE_TEST_NO_PINNED=1 takes that branch."""
+    db = CtrDB.open(util.fixture_ctr("toy"))
+    tree = DeviceTree.upload(db, 0)
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    monkeypatch.setenv("UTREE_CHUNK_BYTES", "20000")
+    monkeypatch.setenv("UTREE_TEST_NO_PINNED", "1")
+    code, st, got = run(db, [tree], data, tmp_path, rc=True)
+    assert code == lib.OK and st.pipeline == 1
+    assert got == util.fixture_bytes("toy_out_rc.txt.gz")
     tree.close()
 
 

@@ -70,6 +70,7 @@ typedef struct {
     void *d_scan, *d_ws;
     size_t scan_bytes, ws_bytes;
     int ws_rc;                                  /* do_rc the workspace was sized for                                */
+    int pageable;                               /* bit 0 / 1 / 2: h_in / h_out / h_meta are ordinary memory (no pinned memory was to be had) */
 } lane_buf;
 
 struct utree_search_ctx {
@@ -79,10 +80,26 @@ struct utree_search_ctx {
     lane_buf lane[MAX_LANES];
 };
 
+static void host_free(void *p, int pageable) { if (!p) return; if (pageable) free(p); else hipHostFree(p); }
+/* Pinned host memory, or -- when the host has none left to pin (it is a resource all the GPUs' users of a machine share) -- ordinary memory:
+ * the copies to and from it are then staged by the runtime, slower, and the search still runs. */
+static void *host_alloc(size_t bytes, int *pageable, const char *what) {
+    void *p = NULL;
+    *pageable = 0;
+    if (!getenv("UTREE_TEST_NO_PINNED") && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess) return p;
+    const hipError_t e = hipGetLastError();
+    p = NULL;
+    if (posix_memalign(&p, 4096, bytes) != 0) p = NULL;
+    if (getenv("UTREE_DEBUG") || getenv("UTREE_TIMING") || !p)
+        fprintf(stderr, "[utree_amd] warning: no pinned host memory for %s (%zu bytes: %s); %s\n", what, bytes, hipGetErrorString(e), p ? "using pageable memory" : "and no ordinary memory either");
+    *pageable = 1;
+    return p;
+}
+
 static void lane_free(lane_buf *b) {
-    if (b->h_in) hipHostFree(b->h_in);
-    if (b->h_out) hipHostFree(b->h_out);
-    if (b->h_meta) hipHostFree(b->h_meta);
+    host_free(b->h_in, b->pageable & 1);
+    host_free(b->h_out, b->pageable & 2);
+    host_free(b->h_meta, b->pageable & 4);
     void *dp[] = {b->d_in, b->d_out, b->d_counts, b->d_nl, b->d_seq_len, b->d_name_off, b->d_name_len, b->d_line_len, b->d_seq_off,
                   b->d_line_off, b->d_res, b->d_meta, b->d_scan, b->d_ws};
     for (size_t i = 0; i < sizeof dp / sizeof dp[0]; ++i) if (dp[i]) hipFree(dp[i]);
@@ -100,14 +117,17 @@ void utree_search_ctx_free(void *p) {
 }
 
 /* (a lane whose allocation fails half way is freed whole: the next search starts it from nothing) */
-#define HA(x) do { if ((x) != hipSuccess) { (void)hipGetLastError(); lane_free(b); return UTREE_E_NOMEM; } } while (0)
+#define HA(x) do { const hipError_t e_ = (x); if (e_ != hipSuccess) { (void)hipGetLastError(); size_t fr_ = 0, to_ = 0; (void)hipMemGetInfo(&fr_, &to_); \
+    fprintf(stderr, "[utree_amd] warning: device %d: %s failed (%s; %.1f of %.1f GiB of HBM free)\n", dev->device, #x, hipGetErrorString(e_), (double)fr_ / 1073741824.0, (double)to_ / 1073741824.0); \
+    lane_free(b); return UTREE_E_NOMEM; } } while (0)
+#define HH(field, bytes, bit) do { int pg_ = 0; b->field = host_alloc((bytes), &pg_, #field); if (pg_) b->pageable |= (bit); if (!b->field) { lane_free(b); return UTREE_E_NOMEM; } } while (0)
 static int lane_alloc(utree_dev *dev, lane_buf *b, int do_rc) {
     if (!b->stream) {
         b->ws_rc = -1;
         if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); b->stream = NULL; return UTREE_E_HIP; }
-        HA(hipHostMalloc((void **)&b->h_in, DCHUNK_BYTES + 64, hipHostMallocDefault));
-        HA(hipHostMalloc((void **)&b->h_out, DOUT_BYTES, hipHostMallocDefault));
-        HA(hipHostMalloc((void **)&b->h_meta, sizeof(utk_text_meta), hipHostMallocDefault));
+        HH(h_in, DCHUNK_BYTES + 64, 1);
+        HH(h_out, DOUT_BYTES, 2);
+        HH(h_meta, sizeof(utk_text_meta), 4);
         HA(hipMalloc((void **)&b->d_in, DCHUNK_BYTES + 256));
         HA(hipMalloc((void **)&b->d_out, DOUT_BYTES));
         HA(hipMalloc((void **)&b->d_counts, (DCHUNK_BYTES / 4096 + 2) * 4));
