@@ -17,6 +17,7 @@ Fixture sets:
   kat     F3  direct-written DB: bin sizes 1,2,3.., min/max suffix, first-bin quirk; one probe per read
   k64     F4  PACKSIZE=64 build of a smaller toy + reads (+RC)
   ix32    F4  IXTYPE=uint32_t build of a smaller toy + reads
+  k64ix32 F4  PACKSIZE=64 and IXTYPE=uint32_t together (+RC)
 """
 import gzip
 import hashlib
@@ -749,6 +750,11 @@ def main():
         gen_toy(manifest, "k16", "-k16", "xtree-searchGG-k16", 120, 900, 3000, 100, seed=16, complevel=0)
         json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "k64ix32":        # add the PACKSIZE=64 + IXTYPE=uint32_t fixture (oracle/_ref/*-k64-ix32)
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+        gen_toy(manifest, "k64ix32", "-k64-ix32", "xtree-searchGG-k64-ix32", 150, 1200, 3000, 150, seed=6432)
+        json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "irregular":      # add the irregular-bin fixtures to an existing golden set
         manifest = json.load(open(os.path.join(HERE, "manifest.json")))
         gen_irregular(manifest)
@@ -759,6 +765,7 @@ def main():
     gen_toy(manifest, "k64", "-k64", "xtree-searchGG-k64", 150, 1200, 3000, 150, seed=64)
     gen_toy(manifest, "ix32", "-ix32", "xtree-searchGG-ix32", 150, 1200, 3000, 120, seed=32)
     gen_toy(manifest, "k16", "-k16", "xtree-searchGG-k16", 120, 900, 3000, 100, seed=16, complevel=0)
+    gen_toy(manifest, "k64ix32", "-k64-ix32", "xtree-searchGG-k64-ix32", 150, 1200, 3000, 150, seed=6432)
     gen_vote(manifest)
     gen_kat(manifest)
     gen_irregular(manifest)

@@ -21,7 +21,7 @@ def _ubt_from_db_fixture(name, path):
     return d
 
 
-@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "k16"])
+@pytest.mark.parametrize("name", ["toy", "k64", "ix32", "k64ix32", "k16"])
 def test_compress_reference_built_databases(name, tmp_path):
     """The toy databases went through the reference's BUILD_GG + COMPRESS; re-compressing their `.ubt` must give the
     same `.ctr` bytes."""

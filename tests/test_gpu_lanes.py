@@ -184,7 +184,7 @@ def genome_db(tmp_path, rng, n_contigs=12, contig=6000):
     return ctr, contigs
 
 
-def related_db(tmp_path, rng, label_bytes, roots=3, length=3000, relatives=40):
+def related_db(tmp_path, rng, label_bytes, roots=3, length=3000, relatives=40, k=32):
     """Every 32-mer of `relatives` mutated copies (3 % substitutions, every fifth 10 %) of a few random roots: the k-mers of the copies
     crowd around each minimizer -- hundreds of records of one hash value, a HEAVY overflow run."""
     seqs, kmers, labs = [], {}, []
@@ -197,14 +197,14 @@ def related_db(tmp_path, rng, label_bytes, roots=3, length=3000, relatives=40):
             seqs.append("".join("ACGT"[int(x)] for x in s))
             labs.append("k__B;p__P%d;c__C%d;o__O%d" % (r, c % 4, r * relatives + c))
     for ci, s in enumerate(seqs):
-        for i in range(len(s) - 31):
-            kmers.setdefault(s[i:i + 32], ci)
+        for i in range(len(s) - k + 1):
+            kmers.setdefault(s[i:i + k], ci)
     ks = sorted(kmers)
     hi, lo = ctrfile.encode_kmers(ks)
     ix = np.array([kmers[x] for x in ks], dtype=np.uint32)
     order = np.lexsort((lo, hi))
-    ctr = str(tmp_path / ("related%d.ctr" % label_bytes))
-    ctrfile.write_ctr(ctr, 8, label_bytes, hi[order], lo[order], ix[order], labs)
+    ctr = str(tmp_path / ("related%d_%d.ctr" % (k, label_bytes)))
+    ctrfile.write_ctr(ctr, k // 4, label_bytes, hi[order], lo[order], ix[order], labs)
     return ctr, seqs
 
 
@@ -249,6 +249,39 @@ def test_heavy_overflow_runs_as_chains(torch_cuda, tmp_path, monkeypatch, label_
     monkeypatch.setenv("UTREE_LANE_PASS", "1")
     for rc in (False, True):
         assert classify_fasta_bytes(db, tree, data, rc=rc) == want[rc]
+    tree.close()
+
+
+@pytest.mark.parametrize("label_bytes", [2, 4])
+def test_related_genomes_k64(torch_cuda, tmp_path, monkeypatch, label_bytes):
+    """k = 64 databases of related genomes: heavy overflow runs behind a position directory, with u16 labels (the lane pass and the wave-per-read
+    kernels) and with u32 labels (32-byte records: the wave-per-read kernels only, README.md:87-88 of the reference allows the combination), both
+    strand modes, against the oracle."""
+    rng = np.random.default_rng(64 + label_bytes)
+    ctr, seqs = related_db(tmp_path, rng, label_bytes, roots=2, length=2500, relatives=40, k=64)
+    db = CtrDB.open(ctr)
+    o = orc.OracleDB.load(ctr)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    reads = []
+    for i in range(4000):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        p = int(rng.integers(0, len(s) - 150))
+        r = list(s[p:p + 150])
+        for x in np.nonzero(rng.random(150) < 0.005)[0]:
+            r[int(x)] = "ACGT"[int(rng.integers(0, 4))]
+        r = "".join(r)
+        if i % 4 == 0:
+            r = "".join(comp[c] for c in reversed(r))
+        reads.append(("h%d" % i, r))
+    data = fasta_bytes(reads + [("sparse%d" % i, "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 150))) for i in range(300)])
+    want = {rc: oracle_text(o, data, tmp_path, rc=rc) for rc in (False, True)}
+    assert want[False].count(b"\n") > 2000
+    tree = DeviceTree.upload(db, 0)
+    assert tree.info.lane_pass == (1 if label_bytes == 2 else 0)
+    for lane_pass in ("1", "0"):
+        monkeypatch.setenv("UTREE_LANE_PASS", lane_pass)
+        for rc in (False, True):
+            assert classify_fasta_bytes(db, tree, data, rc=rc) == want[rc], (lane_pass, rc)
     tree.close()
 
 

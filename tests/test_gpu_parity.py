@@ -39,7 +39,7 @@ def tree_for(name, fine_bits=lib.FINE_AUTO):
     return _TREES[key]
 
 
-GOLDEN = [("toy", 0), ("toy", 1), ("k64", 0), ("k64", 1), ("ix32", 0), ("ix32", 1), ("vote", 0), ("kat", 0), ("katq", 0),
+GOLDEN = [("toy", 0), ("toy", 1), ("k64", 0), ("k64", 1), ("ix32", 0), ("ix32", 1), ("k64ix32", 0), ("k64ix32", 1), ("vote", 0), ("kat", 0), ("katq", 0),
           ("katq2", 0), ("generic", 0), ("k16", 0), ("k16", 1)]
 
 

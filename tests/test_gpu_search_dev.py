@@ -47,7 +47,7 @@ def run(db, trees, data, tmp_path, rc=False, threads=4):
     return code, st, out.read_bytes()
 
 
-@pytest.mark.parametrize("name,rc", [("toy", 0), ("toy", 1), ("k64", 1), ("ix32", 0), ("vote", 0), ("katq2", 0), ("generic", 0), ("k16", 1)])
+@pytest.mark.parametrize("name,rc", [("toy", 0), ("toy", 1), ("k64", 1), ("ix32", 0), ("k64ix32", 1), ("vote", 0), ("katq2", 0), ("generic", 0), ("k16", 1)])
 def test_golden_files_take_the_device_pipeline(torch_cuda, name, rc, tmp_path):
     db, tree = tree_for(name)
     data = util.fixture_bytes(util.READS_OF.get(name, name) + "_reads.fa.gz")

@@ -26,7 +26,7 @@ def run_oracle(name, rc, tmpdir, threads=1):
     return code, nr, good, open(out, "rb").read()
 
 
-@pytest.mark.parametrize("name,rcs", [("toy", (0, 1)), ("k64", (0, 1)), ("ix32", (0, 1)), ("k16", (0, 1)), ("vote", (0,)),
+@pytest.mark.parametrize("name,rcs", [("toy", (0, 1)), ("k64", (0, 1)), ("ix32", (0, 1)), ("k64ix32", (0, 1)), ("k16", (0, 1)), ("vote", (0,)),
                                       ("kat", (0,)), ("katq", (0,)), ("katq2", (0,)), ("generic", (0,))])
 def test_search_file_matches_reference(name, rcs, tmpdir_mod):
     for rc in rcs:
@@ -58,7 +58,7 @@ def test_edge_cases_match_reference(tmpdir_mod):
 
 def test_ctr_regenerated_by_our_writer_matches_reference_sha():
     # fixture_ctr asserts the SHA-256 of the reference-built file
-    for name in ("toy", "k64", "ix32", "k16", "vote", "kat", "katq", "katq2", "generic"):
+    for name in ("toy", "k64", "ix32", "k64ix32", "k16", "vote", "kat", "katq", "katq2", "generic"):
         p = util.fixture_ctr(name)
         d = ctrfile.read_ctr(p)
         assert d.n_nodes == util.manifest()[name + "_nodes"]
@@ -67,7 +67,7 @@ def test_ctr_regenerated_by_our_writer_matches_reference_sha():
 
 def test_compress_style_bin_table_reproduces_reference_compress():
     # toy.ctr came out of the reference's COMPRESS: our like_compress bin table must equal its table
-    for name in ("toy", "k64", "ix32"):
+    for name in ("toy", "k64", "ix32", "k64ix32"):
         d = util.load_db_fixture(name)
         hi, lo = d.words()
         pref = ctrfile.word_prefix(d.W, hi, lo)
@@ -216,7 +216,7 @@ def test_rank_search_adversarial_case_oracle_vs_reference(tmp_path):
 
 
 @pytest.mark.skipif(not util.have_ref(), reason="needs oracle/_ref (the genuine reference, built from /root/reference by `make -C oracle ref`)")
-@pytest.mark.parametrize("name,with_gt", [("toy", False), ("toy", True), ("k64", False), ("ix32", False), ("vote", False), ("k16", False)])
+@pytest.mark.parametrize("name,with_gt", [("toy", False), ("toy", True), ("k64", False), ("ix32", False), ("k64ix32", False), ("vote", False), ("k16", False)])
 def test_byte_fuzz_oracle_vs_reference(name, with_gt, tmp_path):
     """Sequence lines with arbitrary 7-bit bytes, both strands: output file AND exit code of the oracle equal the genuine
     reference's (with '>' allowed, both stop at the same record with the format error)."""
@@ -224,7 +224,7 @@ def test_byte_fuzz_oracle_vs_reference(name, with_gt, tmp_path):
     data = util.byte_fuzz_reads(name, 21, with_gt)
     fa = tmp_path / "f.fa"
     fa.write_bytes(data)
-    exe = "xtree-searchGG" + {"k64": "-k64", "ix32": "-ix32", "k16": "-k16"}.get(name, "")
+    exe = "xtree-searchGG" + {"k64": "-k64", "ix32": "-ix32", "k64ix32": "-k64-ix32", "k16": "-k16"}.get(name, "")
     o = orc.OracleDB.load(util.fixture_ctr(name))
     for rc in (False, True):
         want, got = tmp_path / "ref.txt", tmp_path / "orc.txt"
