@@ -108,6 +108,39 @@ def test_two_device_handles_share_the_chunks(torch_cuda, tmp_path, monkeypatch):
     t2.close()
 
 
+def test_eight_device_handles_on_one_card(torch_cuda, tmp_path, monkeypatch):
+    """The command line's shape on an 8-GPU node -- one process, eight handles, one input, one output -- rehearsed on one card: seven byte copies
+    of the image attached beside the built one, three lanes per handle (the pipeline's choice beyond two devices): 24 lanes share the chunks,
+    the output is the reference's, with one output file and with the output in parts."""
+    torch = torch_cuda
+    monkeypatch.setenv("UTREE_CHUNK_BYTES", "20000")
+    db, tree = tree_for("toy")
+    ptr, used = tree.image_ptr()
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (used,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    src = torch.as_tensor(_Raw(), device="cuda:0")
+    copies, trees = [], [tree]
+    for _ in range(7):
+        c = torch.empty(used + 4096, dtype=torch.uint8, device="cuda:0")[4096:]
+        c.copy_(src)
+        copies.append(c)
+    torch.cuda.synchronize()
+    trees += [DeviceTree.attach(db, c, 0) for c in copies]
+    data = util.fixture_bytes("toy_reads.fa.gz")
+    code, st, got = run(db, trees, data, tmp_path, rc=True, threads=16)
+    assert code == lib.OK and st.pipeline == 1 and st.n_lanes == 24
+    assert got == util.fixture_bytes("toy_out_rc.txt.gz")
+    monkeypatch.setenv("UTREE_OUTPUT_PARTS", "8")
+    fa, out = tmp_path / "in.fa", tmp_path / "parts.txt"
+    fa.write_bytes(data)
+    code, st = search_gg(db, trees, str(fa), str(out), rc=True, threads=16)
+    assert code == lib.OK
+    assert b"".join((tmp_path / ("parts.txt.part%03d" % i)).read_bytes() for i in range(8)) == util.fixture_bytes("toy_out_rc.txt.gz")
+    for t in trees[1:]:
+        t.close()
+
+
 def test_last_line_without_newline_crlf_and_empty_file(torch_cuda, tmp_path):
     db, tree = tree_for("toy")
     o = orc.OracleDB.load(util.fixture_ctr("toy"))
